@@ -1,0 +1,277 @@
+// nco_walk.h -- exact closed-form evaluation of the reference's sequential FP64 NCO recurrences.
+//
+// The reference advances two phases per channel per sample (src/galileo-sdr.cpp:528-532):
+//     code_phase += f_code * delt;                       (wrap check at the top of the next sample, :491-507)
+//     carr_phase += f_carr * delt;  carr_phase -= (long)carr_phase;
+// Both are chains of *rounded* double additions, so x0 + n*step is not bit-exact.
+// What IS exact: while x stays inside one binade [2^k, 2^(k+1)) it sits on that binade's ulp grid
+// g = 2^(k-52), and   fl(x + d) == x + RN_g(d)   for every such x, where RN_g(d) is d rounded to a
+// multiple of g (ties: to even, valid once x/g is even -- which one genuine tie step guarantees).
+// n such steps therefore collapse into ONE exact fma: x_n = fma(n, RN_g(d), x).  A genuine single
+// step is taken at every binade crossing and at every wrap.  Magnitude-decreasing runs (phase and
+// step of opposite sign) are the mirror image inside a binade.
+//
+// The same functions are compiled for the device (hipcc) and for the host (g++, CPU unit tests
+// against brute-force stepping in tests/test_walker_cpu.py).  Compile with -ffp-contract=off.
+#ifndef GAL_NCO_WALK_H_
+#define GAL_NCO_WALK_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GAL_HD __host__ __device__ __forceinline__
+#else
+#define GAL_HD static inline
+#endif
+
+namespace galnco {
+
+GAL_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
+GAL_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+
+GAL_HD double fma_exact(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+static constexpr uint64_t kSign = 0x8000000000000000ull;
+static constexpr uint64_t kExpMask = 0x7ff0000000000000ull;
+
+// One genuine carrier step, src/galileo-sdr.cpp:531-532.  |p| < 2 always, so (int) == (long).
+GAL_HD double carr_step(double p, double d)
+{
+    p = p + d;
+    p = p - (double)(int)p;
+    return p;
+}
+
+struct Batch {
+    int n;       // steps that may be taken in closed form (>= 0)
+    double inc;  // x_j = fma(j, inc, x) exactly for 0 <= j <= n
+};
+
+// How many genuine steps `x <- fl(x + d)` starting at x can be replaced by x + j*inc, with every
+// visited state strictly inside x's binade and below `cap` in magnitude (cap = 1.0 for the carrier
+// phase, 4092.0 for the code phase: no wrap can trigger inside a batch).  Conservative: may return
+// fewer steps than possible, never more.
+GAL_HD Batch nco_batch(double x, double d, int n_max, double cap)
+{
+    Batch b;
+    b.n = 0;
+    b.inc = 0.0;
+    const uint64_t xb = d2u(x), db = d2u(d);
+    const uint64_t xa = xb & ~kSign, da = db & ~kSign;
+    const int ex = (int)(xa >> 52), ed = (int)(da >> 52);
+    if (n_max <= 0) return b;
+    if (ex <= ed || ex < 54 || ex >= 0x7ff) return b;  // x not above d's binade (or grid not normal)
+    const double pk = u2d(xa & kExpMask);               // 2^k
+    const double g = u2d((uint64_t)(ex - 52) << 52);    // ulp of the binade
+    const double ad = u2d(da), ax = u2d(xa);
+    const double dk = (ad + pk) - pk;                   // RN_g(|d|), ties to even
+    const double rem = ad - dk;                         // exact
+    const bool tie = (rem + rem == g) || (rem + rem == -g);
+    if (tie && (xa & 1ull)) return b;                   // need x/g even first: caller takes a genuine step
+    const bool asc = ((xb ^ db) & kSign) == 0;
+    double t;
+    if (asc) {
+        double lim = pk + pk;
+        if (lim > cap) lim = cap;
+        t = (lim - g) - ax;                             // exact: multiples of g below 2^(k+1)
+    } else {
+        t = ax - (pk + g);                              // stay strictly above the binade floor
+    }
+    if (dk == 0.0) {                                    // |d| <= g/2: x is a fixed point of the rounded add
+        if (t >= 0.0) b.n = n_max;                      // (not at the binade floor, where the grid below is finer)
+        return b;
+    }
+    if (!(t >= dk)) return b;
+    double q = t / dk;
+    if (q > (double)n_max) q = (double)n_max;
+    int n = (int)q;
+    // division may have rounded up across an integer: n*dk is exactly representable (multiple of g, < 2^(k+1))
+    if (fma_exact(-(double)n, dk, t) < 0.0) n -= 1;
+    if (n <= 0) return b;
+    b.n = n;
+    const double sdk = asc ? dk : -dk;
+    b.inc = (xb & kSign) ? -sdk : sdk;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Carrier chain: N samples with constant step d.  `emit(c, p)` receives the phase BEFORE sample
+// c*R for c = 0 .. ceil(N/R)-1; the return value is the phase after sample N-1 (what the next epoch
+// starts from).
+template <class Emit>
+GAL_HD double carr_walk(double p, double d, int N, int R, Emit emit)
+{
+    int i = 0;
+    int next_cp = 0, c = 0;
+    while (i < N) {
+        if (next_cp == i) {
+            emit(c, p);
+            ++c;
+            next_cp += R;
+        }
+        const Batch b = nco_batch(p, d, N - i, 1.0);
+        const int iend = i + b.n;
+        while (next_cp <= iend && next_cp < N) {
+            emit(c, fma_exact((double)(next_cp - i), b.inc, p));
+            ++c;
+            next_cp += R;
+        }
+        if (b.n) p = fma_exact((double)b.n, b.inc, p);
+        i = iend;
+        if (i < N) {
+            p = carr_step(p, d);
+            ++i;
+        }
+    }
+    return p;
+}
+
+// Code chain: N samples, step c > 0, wrap at 4092 checked BEFORE each sample's use
+// (src/galileo-sdr.cpp:491-507).  `emit(cidx, x, ibit, flipped)` receives the PRE-check state before
+// sample cidx*R.  Returns the pre-check state after sample N-1 through the reference parameters.
+struct CodeEnd {
+    double x;
+    int ibit;
+    int flipped;
+};
+
+template <class Emit>
+GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, int N, int R, Emit emit)
+{
+    int i = 0;
+    int next_cp = 0, c = 0;
+    int flipped = 0;
+    while (i < N) {
+        if (next_cp == i) {
+            emit(c, x, ibit, flipped);
+            ++c;
+            next_cp += R;
+        }
+        if (x >= 4092.0) {
+            x -= 4092.0;
+            ++ibit;
+            if (ibit >= 500) {
+                ibit = 0;
+                flipped = 1;
+            }
+        }
+        const Batch b = nco_batch(x, cstep, N - i, 4092.0);
+        const int iend = i + b.n;
+        while (next_cp <= iend && next_cp < N) {
+            emit(c, fma_exact((double)(next_cp - i), b.inc, x), ibit, flipped);
+            ++c;
+            next_cp += R;
+        }
+        if (b.n) x = fma_exact((double)b.n, b.inc, x);
+        i = iend;
+        if (i < N) {
+            x = x + cstep;
+            ++i;
+        }
+    }
+    CodeEnd r;
+    r.x = x;
+    r.ibit = ibit;
+    r.flipped = flipped;
+    return r;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Speculative evaluation of the carrier chain across epochs (one slot).  The chain is sequential over
+// the whole run, but rounded-add chains commute with shifts that are multiples of 2^-52 as long as the
+// itinerary (binade crossings, wraps) is unchanged, so epochs are walked in parallel from guessed start
+// phases and stitched by these two routines.  All [E][S] arrays are indexed e * S + s.
+//
+// carr_guess_slot: ideal-arithmetic guesses for every epoch start.
+GAL_HD void carr_guess_slot(int s, int E, int S, int N, const int *prn, const uint32_t *flags, const double *p0,
+                            const double *dstep, double start0, double *pst, uint8_t *verified, uint8_t *dirty)
+{
+    double p = 0.0;
+    bool have = false;
+    for (int e = 0; e < E; ++e) {
+        const int idx = e * S + s;
+        if (prn[idx] <= 0) {
+            have = false;
+            continue;
+        }
+        if (flags[idx] & 1u) {  // GAL_CH_RESTART
+            p = p0[idx];
+            have = true;
+        } else if (e == 0) {
+            p = start0;
+            have = true;
+        } else if (!have) {
+            p = 0.0;  // malformed batch (rejected on the host); keep the routine total
+            have = true;
+        }
+        pst[idx] = p;
+        dirty[idx] = 1;
+        verified[idx] = 0;
+        p = p + (double)N * dstep[idx];
+        p = p - (double)(long long)p;
+    }
+}
+
+// carr_scan_slot: walk the epochs in order.  A chunk is VERIFIED only if the start phase its last walk
+// used is bitwise the true one (given at a restart / batch start, or the end of a verified predecessor).
+// Unverified chunks get a new start: jacobi != 0 -> the predecessor's last end as is (this puts the
+// guess on the right sub-2^-52 residue: after one wrap every phase is a multiple of 2^-52 plus a
+// residue fixed by the itinerary); else that end shifted by the predecessor's own start correction.
+// Returns the number of still unverified chunks.
+GAL_HD int carr_scan_slot(int s, int E, int S, const int *prn, const uint32_t *flags, const double *p0,
+                          double start0, double *pst, const double *pend, uint8_t *verified, uint8_t *dirty,
+                          int jacobi)
+{
+    int unver = 0;
+    bool prev_true = false;  // previous chunk verified -> its pend is the true start of this one
+    bool have_prev = false;  // previous chunk active
+    double prev_end_true = 0.0, prev_end_guess = 0.0;
+    for (int e = 0; e < E; ++e) {
+        const int idx = e * S + s;
+        if (prn[idx] <= 0) {
+            prev_true = false;
+            have_prev = false;
+            continue;
+        }
+        const double cur = pst[idx];
+        bool known = false;
+        double tstart = 0.0;
+        if (flags[idx] & 1u) {
+            known = true;
+            tstart = p0[idx];
+        } else if (e == 0) {
+            known = true;
+            tstart = start0;
+        } else if (prev_true) {
+            known = true;
+            tstart = prev_end_true;
+        }
+        double nstart = cur;
+        if (known) nstart = tstart;
+        else if (have_prev) nstart = prev_end_guess;
+        const bool same = d2u(nstart) == d2u(cur);
+        const double pend_old = pend[idx];
+        if (known && same && !dirty[idx]) {
+            verified[idx] = 1;
+            prev_true = true;
+            prev_end_true = pend_old;
+            prev_end_guess = pend_old;
+        } else {
+            ++unver;
+            prev_true = false;
+            if (!same) {
+                pst[idx] = nstart;
+                dirty[idx] = 1;
+                prev_end_guess = jacobi ? pend_old : pend_old + (nstart - cur);
+            } else {
+                prev_end_guess = pend_old;
+            }
+        }
+        have_prev = true;
+    }
+    return unver;
+}
+
+}  // namespace galnco
+#endif  // GAL_NCO_WALK_H_

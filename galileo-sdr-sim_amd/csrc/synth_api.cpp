@@ -1,0 +1,489 @@
+// synth_api.cpp -- C ABI (include/galsynth.h) over the gfx950 kernels in synth_kernels.hip.
+// Host-side plumbing only: validation, HBM arena, kernel sequencing.  There is deliberately no CPU
+// implementation behind these entry points: without a usable GPU they fail with GAL_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "synth_dev.h"
+#include "e1_tables.inc"
+
+extern "C" {
+void galk_launch_prep(const DevPlan *P, hipStream_t st);
+void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
+void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
+void galk_launch_walk_carr(const DevPlan *P, hipStream_t st);
+void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st);
+void galk_launch_pages(const DevPlan *P, hipStream_t st);
+int galk_launch_synth(const DevPlan *P, int nch, int accumulate, const uint8_t *act, const int *nact,
+                      uint32_t *iq, hipStream_t st);
+}
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t err__ = (expr);                                                                 \
+        if (err__ != hipSuccess)                                                                   \
+            return fail(GAL_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__),   \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+int16_t g_cos[512], g_sin[512];
+bool g_tables_ready = false;
+
+void init_tables()
+{
+    if (g_tables_ready) return;
+    // quarter-wave expansion of the 512-entry table of include/constants.h:216-284
+    for (int k = 0; k < 512; ++k) {
+        int q;
+        if (k < 128) q = kCosQ[k];
+        else if (k < 256) q = -kCosQ[255 - k];
+        else if (k < 384) q = -kCosQ[k - 256];
+        else q = kCosQ[511 - k];
+        g_cos[k] = (int16_t)q;
+    }
+    for (int k = 0; k < 512; ++k) g_sin[k] = g_cos[(k - 128) & 511];
+    g_tables_ready = true;
+}
+
+constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
+constexpr int kDefaultPasses = 6;   // speculative carrier passes enqueued up front (3 normally suffice)
+
+}  // namespace
+
+struct gal_synth {
+    gal_synth_cfg_t cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    // tables in HBM
+    uint32_t *d_e1b = nullptr, *d_e1c = nullptr;
+    int *d_lut = nullptr;
+
+    // arena for the planned batch
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    DevPlan P{};
+    bool planned = false;
+    bool executed = false;
+    int n_groups = 0;  // channel groups (each <= kKernelMaxChan) -> synth launches per execute
+    std::vector<int> group_nch;
+    uint8_t *d_act = nullptr;  // [groups][E][S]
+    int *d_nact = nullptr;     // [groups][E]
+    int nact_max = 0;
+    uint32_t *last_iq = nullptr;
+    void *own_iq = nullptr;
+    size_t own_iq_bytes = 0;
+    int *h_ctr = nullptr;  // pinned
+    gal_chan_state_t *h_state = nullptr;  // pinned [S]
+    gal_synth_stats_t stats{};
+};
+
+extern "C" {
+
+const char *gal_synth_version(void) { return "galsynth 0.1 (gfx950, HIP)"; }
+const char *gal_synth_last_error(void) { return g_err; }
+
+int gal_synth_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strstr(prop.gcnArchName, "gfx950")) ++ok;
+    }
+    return ok;
+}
+
+const uint32_t *gal_tables_e1b(void) { return &kE1B[0][0]; }
+const uint32_t *gal_tables_e1c(void) { return &kE1C[0][0]; }
+const int16_t *gal_tables_cos512(void) { init_tables(); return g_cos; }
+const int16_t *gal_tables_sin512(void) { init_tables(); return g_sin; }
+uint32_t gal_tables_cs25(void) { return kCS25; }
+
+int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
+{
+    if (!cfg || !out) return fail(GAL_E_INVAL, "gal_synth_create: null argument");
+    *out = nullptr;
+    if (!(cfg->sample_rate > 0.0) || cfg->samples_per_epoch < 4 || cfg->n_slots < 1 ||
+        cfg->n_slots > GAL_ENGINE_MAX_CHAN)
+        return fail(GAL_E_INVAL, "gal_synth_create: bad cfg (rate %g, samples/epoch %d, slots %d)",
+                    cfg->sample_rate, cfg->samples_per_epoch, cfg->n_slots);
+    if (cfg->chunk_samples < 0 || (cfg->chunk_samples & 3))
+        return fail(GAL_E_INVAL, "gal_synth_create: chunk_samples must be a multiple of 4");
+    init_tables();
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(GAL_E_DEVICE, "no HIP device: the synthesis engine has no CPU fallback");
+    int dev = cfg->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(GAL_E_INVAL, "device %d out of range (%d devices)", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(GAL_E_DEVICE, "device %d is %s; this library carries gfx950 code only", dev,
+                    prop.gcnArchName);
+
+    gal_synth *h = new (std::nothrow) gal_synth();
+    if (!h) return fail(GAL_E_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->device = dev;
+    auto bail = [&](int code) {
+        gal_synth_destroy(h);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
+    h->stream = h->own_stream;
+    for (auto &e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
+    if (hipHostMalloc((void **)&h->h_ctr, CTR_COUNT * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_state, sizeof(gal_chan_state_t) * GAL_ENGINE_MAX_CHAN,
+                      hipHostMallocDefault) != hipSuccess)
+        return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
+
+    const size_t code_bytes = sizeof(kE1B);
+    if (hipMalloc((void **)&h->d_e1b, code_bytes) != hipSuccess ||
+        hipMalloc((void **)&h->d_e1c, code_bytes) != hipSuccess ||
+        hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess)
+        return bail(fail(GAL_E_NOMEM, "table allocation failed"));
+    int lut[512];
+    for (int k = 0; k < 512; ++k) lut[k] = 2 * ((int)g_sin[k] * 65536 + (int)g_cos[k]);
+    if (hipMemcpy(h->d_e1b, kE1B, code_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_e1c, kE1C, code_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(GAL_E_DEVICE, "table upload failed"));
+    *out = h;
+    return GAL_OK;
+}
+
+int gal_synth_destroy(gal_synth_t *h)
+{
+    if (!h) return GAL_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->arena) hipFree(h->arena);
+    if (h->own_iq) hipFree(h->own_iq);
+    if (h->d_e1b) hipFree(h->d_e1b);
+    if (h->d_e1c) hipFree(h->d_e1c);
+    if (h->d_lut) hipFree(h->d_lut);
+    if (h->h_ctr) hipHostFree(h->h_ctr);
+    if (h->h_state) hipHostFree(h->h_state);
+    for (auto &e : h->ev)
+        if (e) hipEventDestroy(e);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return GAL_OK;
+}
+
+int gal_synth_set_stream(gal_synth_t *h, void *hip_stream)
+{
+    if (!h) return fail(GAL_E_INVAL, "null handle");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return GAL_OK;
+}
+
+size_t gal_synth_output_bytes(const gal_synth_t *h)
+{
+    if (!h || !h->planned) return 0;
+    return (size_t)h->P.E * (size_t)h->P.N * 4u;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                   const gal_chan_state_t *state_in)
+{
+    if (!h || !params || n_epochs < 1) return fail(GAL_E_INVAL, "gal_synth_plan: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const int E = n_epochs, S = h->cfg.n_slots, N = h->cfg.samples_per_epoch;
+    h->planned = false;
+    h->executed = false;
+
+    // ---- validate the batch and build the active-channel lists (host, O(E*S))
+    std::vector<uint8_t> act_all((size_t)E * S, 0);
+    std::vector<int> nact_all(E, 0);
+    int nact_max = 0;
+    std::vector<int> cur_prn(S, 0);
+    for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
+    for (int e = 0; e < E; ++e) {
+        int n = 0;
+        for (int s = 0; s < S; ++s) {
+            const gal_chan_epoch_t &r = params[(size_t)e * S + s];
+            if (r.prn <= 0) {
+                cur_prn[s] = 0;
+                continue;
+            }
+            if (r.prn > GAL_NUM_PRN) return fail(GAL_E_INVAL, "epoch %d slot %d: PRN %d out of range", e, s, r.prn);
+            if (r.ibit0 < 0 || r.ibit0 >= GAL_N_SYM_PAGE)
+                return fail(GAL_E_INVAL, "epoch %d slot %d: ibit0 %d out of range", e, s, r.ibit0);
+            if (!(r.code_phase0 >= 0.0) || !(r.code_phase0 < 2.0 * GAL_CODE_LEN) || !std::isfinite(r.f_code) ||
+                !(r.f_code > 0.0) || !std::isfinite(r.f_carr))
+                return fail(GAL_E_INVAL, "epoch %d slot %d: bad phase/frequency", e, s);
+            if (!(std::fabs(r.f_carr) < h->cfg.sample_rate) || !(r.f_code < h->cfg.sample_rate * 4000.0))
+                return fail(GAL_E_INVAL, "epoch %d slot %d: NCO step out of range", e, s);
+            if (r.flags & GAL_CH_RESTART) {
+                if (!(std::fabs(r.carr_phase0) < 1.0))
+                    return fail(GAL_E_INVAL, "epoch %d slot %d: carr_phase0 must be in (-1,1)", e, s);
+            } else if (cur_prn[s] != r.prn) {
+                return fail(GAL_E_INVAL,
+                            "epoch %d slot %d: PRN %d continues without GAL_CH_RESTART but the slot held PRN %d", e,
+                            s, r.prn, cur_prn[s]);
+            }
+            cur_prn[s] = r.prn;
+            act_all[(size_t)e * S + n] = (uint8_t)s;
+            ++n;
+        }
+        nact_all[e] = n;
+        if (n > nact_max) nact_max = n;
+    }
+    if (state_in) {
+        for (int s = 0; s < S; ++s)
+            if (state_in[s].prn > 0 && !(std::fabs(state_in[s].carr_phase) < 1.0))
+                return fail(GAL_E_INVAL, "state_in slot %d: carr_phase must be in (-1,1)", s);
+    }
+
+    // ---- chunking
+    int R = h->cfg.chunk_samples;
+    if (R <= 0) {
+        int target = (int)((N + 512) / 1024);
+        target = (target + 63) / 64 * 64;
+        if (target < 64) target = 64;
+        R = (N + target - 1) / target;
+        R = (R + 3) / 4 * 4;
+    }
+    if (R < 4) R = 4;
+    const int nchunks = (N + R - 1) / R;
+    const int tiles = (nchunks + 63) / 64;
+
+    // ---- channel groups (one synth launch each; later groups accumulate onto the first)
+    const int n_groups = nact_max == 0 ? 1 : (nact_max + kKernelMaxChan - 1) / kKernelMaxChan;
+    h->n_groups = n_groups;
+    h->group_nch.assign(n_groups, 0);
+    std::vector<uint8_t> act_g((size_t)n_groups * E * S, 0);
+    std::vector<int> nact_g((size_t)n_groups * E, 0);
+    for (int e = 0; e < E; ++e) {
+        const int n = nact_all[e];
+        // split evenly so every launch replays about the same number of channels
+        const int per = (n + n_groups - 1) / n_groups;
+        int k = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            int m = n - k < per ? n - k : per;
+            if (m < 0) m = 0;
+            for (int j = 0; j < m; ++j) act_g[((size_t)g * E + e) * S + j] = act_all[(size_t)e * S + k + j];
+            nact_g[(size_t)g * E + e] = m;
+            if (m > h->group_nch[g]) h->group_nch[g] = m;
+            k += m;
+        }
+    }
+
+    // ---- arena layout
+    const size_t ES = (size_t)E * S;
+    const size_t CP1 = (size_t)nchunks + 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const size_t o_params = take(ES * sizeof(gal_chan_epoch_t));
+    const size_t o_state_in = take(sizeof(gal_chan_state_t) * S);
+    const size_t o_state_out = take(sizeof(gal_chan_state_t) * S);
+    const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
+    const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
+    const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4), o_pcur = take(ES * GAL_PAGE_WORDS * 4);
+    const size_t o_flip = take(ES);
+    const size_t o_act = take((size_t)n_groups * ES), o_nact = take((size_t)n_groups * E * 4);
+    const size_t o_pst = take(ES * 8), o_pend = take(ES * 8), o_ver = take(ES), o_dirty = take(ES);
+    const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
+    const size_t o_ctr = take(CTR_COUNT * 4);
+    const size_t total = off;
+    if (total > h->arena_bytes) {
+        if (h->arena) hipFree(h->arena);
+        h->arena = nullptr;
+        h->arena_bytes = 0;
+        if (hipMalloc(&h->arena, total) != hipSuccess)
+            return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", total);
+        h->arena_bytes = total;
+    }
+    char *base = (char *)h->arena;
+    DevPlan &P = h->P;
+    P.E = E; P.S = S; P.N = N; P.R = R; P.nchunks = nchunks; P.CP1 = (int)CP1;
+    P.blocks_per_epoch = (tiles + 3) / 4;
+    P.delt = 1.0 / h->cfg.sample_rate;
+    P.cs25 = kCS25;
+    P.params = (const gal_chan_epoch_t *)(base + o_params);
+    P.state_in = (const gal_chan_state_t *)(base + o_state_in);
+    P.state_out = (gal_chan_state_t *)(base + o_state_out);
+    P.prn = (int *)(base + o_prn); P.flags = (uint32_t *)(base + o_flags); P.ib0 = (int *)(base + o_ib0);
+    P.x0 = (double *)(base + o_x0); P.p0 = (double *)(base + o_p0);
+    P.cstep = (double *)(base + o_cstep); P.dstep = (double *)(base + o_dstep);
+    P.page_next = (uint32_t *)(base + o_pnext); P.page_cur = (uint32_t *)(base + o_pcur);
+    P.flip_in = (uint8_t *)(base + o_flip);
+    P.act = nullptr; P.nact = nullptr;  // per group, set at launch
+    h->d_act = (uint8_t *)(base + o_act); h->d_nact = (int *)(base + o_nact);
+    P.pst = (double *)(base + o_pst); P.pend = (double *)(base + o_pend);
+    P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
+    P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
+    P.ctr = (int *)(base + o_ctr);
+    P.e1b = h->d_e1b; P.e1c = h->d_e1c; P.lut = h->d_lut;
+
+    // ---- upload (synchronous: after plan() the batch is resident in HBM)
+    HIP_TRY(hipMemcpy(base + o_params, params, ES * sizeof(gal_chan_epoch_t), hipMemcpyHostToDevice));
+    std::vector<gal_chan_state_t> st(S);
+    memset(st.data(), 0, sizeof(gal_chan_state_t) * S);
+    if (state_in) memcpy(st.data(), state_in, sizeof(gal_chan_state_t) * S);
+    HIP_TRY(hipMemcpy(base + o_state_in, st.data(), sizeof(gal_chan_state_t) * S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + o_act, act_g.data(), act_g.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + o_nact, nact_g.data(), nact_g.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(base + o_cpx, 0, ES * CP1 * 8));
+    HIP_TRY(hipMemset(base + o_cpp, 0, ES * CP1 * 8));
+    HIP_TRY(hipMemset(base + o_cpi, 0, ES * CP1 * 4));
+    HIP_TRY(hipMemset(base + o_pend, 0, ES * 8));
+
+    h->nact_max = nact_max;
+    memset(&h->stats, 0, sizeof(h->stats));
+    h->stats.n_epochs = E;
+    h->stats.n_active_max = nact_max;
+    h->stats.chunk_samples = R;
+    h->stats.chunks_per_epoch = nchunks;
+    h->planned = true;
+    return GAL_OK;
+}
+
+static int enqueue_synth(gal_synth *h, uint32_t *iq)
+{
+    const size_t ES = (size_t)h->P.E * h->P.S;
+    for (int g = 0; g < h->n_groups; ++g) {
+        const int rc = galk_launch_synth(&h->P, h->group_nch[g], g > 0, h->d_act + (size_t)g * ES,
+                                         h->d_nact + (size_t)g * h->P.E, iq, h->stream);
+        if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
+    }
+    HIP_TRY(hipGetLastError());
+    return GAL_OK;
+}
+
+int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
+{
+    if (!h || !iq_dev) return fail(GAL_E_INVAL, "gal_synth_execute: null argument");
+    if (!h->planned) return fail(GAL_E_STATE, "gal_synth_execute before gal_synth_plan");
+    if (((uintptr_t)iq_dev) & 15) return fail(GAL_E_INVAL, "iq_dev must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const DevPlan *P = &h->P;
+    HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), st));
+    HIP_TRY(hipEventRecord(h->ev[0], st));
+    galk_launch_prep(P, st);
+    galk_launch_walk_code(P, st);
+    galk_launch_carr_guess(P, st);
+    for (int pass = 0; pass < kDefaultPasses; ++pass) {
+        galk_launch_walk_carr(P, st);
+        galk_launch_carr_scan(P, pass == 0, st);
+    }
+    galk_launch_pages(P, st);
+    HIP_TRY(hipEventRecord(h->ev[1], st));
+    int rc = enqueue_synth(h, (uint32_t *)iq_dev);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev[2], st));
+    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+    h->last_iq = (uint32_t *)iq_dev;
+    h->executed = true;
+    return GAL_OK;
+}
+
+int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats)
+{
+    if (!h) return fail(GAL_E_INVAL, "null handle");
+    if (!h->executed) return fail(GAL_E_STATE, "gal_synth_finish before gal_synth_execute");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const DevPlan *P = &h->P;
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms_walk = 0, ms_synth = 0;
+    hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
+    hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[2]);
+
+    // The up-front passes did not converge (an itinerary mismatch cascaded): keep iterating from the
+    // host, then redo pages + synthesis with the now exact checkpoints.
+    const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 32 + P->E;
+    bool redo = false;
+    while (h->h_ctr[CTR_UNVERIFIED] != 0) {
+        if (h->h_ctr[CTR_PASSES] >= max_passes)
+            return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes (%d chunks unverified)",
+                        h->h_ctr[CTR_PASSES], h->h_ctr[CTR_UNVERIFIED]);
+        galk_launch_walk_carr(P, st);
+        galk_launch_carr_scan(P, 0, st);
+        HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        redo = true;
+    }
+    if (redo) {
+        HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
+        galk_launch_pages(P, st);
+        int rc = enqueue_synth(h, h->last_iq);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    h->stats.walk_passes = h->h_ctr[CTR_PASSES];
+    h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
+    h->stats.ms_walk = ms_walk;
+    h->stats.ms_synth = ms_synth;
+    if (stats) *stats = h->stats;
+    if (state_out) {
+        HIP_TRY(hipMemcpy(state_out, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost));
+    }
+    if (h->stats.chain_mismatch != 0)
+        return fail(GAL_E_CHAIN, "replay kernel disagreed with the NCO walker at %d chunk boundaries",
+                    h->stats.chain_mismatch);
+    return GAL_OK;
+}
+
+int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                       const gal_chan_state_t *state_in, int16_t *iq_host, gal_chan_state_t *state_out,
+                       gal_synth_stats_t *stats)
+{
+    if (!h || !iq_host) return fail(GAL_E_INVAL, "gal_synth_run_host: null argument");
+    int rc = gal_synth_plan(h, params, n_epochs, state_in);
+    if (rc) return rc;
+    const size_t bytes = gal_synth_output_bytes(h);
+    if (bytes > h->own_iq_bytes) {
+        if (h->own_iq) hipFree(h->own_iq);
+        h->own_iq = nullptr;
+        h->own_iq_bytes = 0;
+        if (hipMalloc(&h->own_iq, bytes) != hipSuccess) return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+        h->own_iq_bytes = bytes;
+    }
+    rc = gal_synth_execute(h, (int16_t *)h->own_iq);
+    if (rc) return rc;
+    rc = gal_synth_finish(h, state_out, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(iq_host, h->own_iq, bytes, hipMemcpyDeviceToHost));
+    return GAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// synth_dev.h -- device-side view of one planned batch (shared by synth_kernels.hip and synth_api.cpp).
+#ifndef GAL_SYNTH_DEV_H_
+#define GAL_SYNTH_DEV_H_
+
+#include <stdint.h>
+
+#include "../../include/galsynth.h"
+
+enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_COUNT = 4 };
+
+// Everything lives in HBM; [E][S] arrays are indexed e * S + s.
+struct DevPlan {
+    int E;        // epochs in the batch
+    int S;        // channel slots per epoch row
+    int N;        // samples per epoch
+    int R;        // samples replayed by one lane (chunk)
+    int nchunks;  // ceil(N / R)
+    int CP1;      // checkpoint row stride = nchunks + 1 (last entry = end-of-epoch state)
+    int blocks_per_epoch;
+    double delt;  // 1.0 / sample_rate, src/galileo-sdr.cpp:162
+    uint32_t cs25;
+
+    const gal_chan_epoch_t *params;  // [E][S] as uploaded
+    const gal_chan_state_t *state_in;  // [S]
+    gal_chan_state_t *state_out;       // [S]
+
+    // SoA copies (k_prep)
+    int *prn;           // [E][S]
+    uint32_t *flags;    // [E][S]
+    int *ib0;           // [E][S]
+    double *x0;         // [E][S] code phase at epoch start
+    double *p0;         // [E][S] carrier phase for restarts
+    double *cstep;      // [E][S] fl(f_code * delt)
+    double *dstep;      // [E][S] fl(f_carr * delt)
+    uint32_t *page_next;  // [E][S][16]
+    uint32_t *page_cur;   // [E][S][16] page in force at epoch start (k_pages)
+    uint8_t *flip_in;     // [E][S] symbol counter wrapped inside this epoch
+
+    // active-channel compaction (host built)
+    const uint8_t *act;  // [E][S] slots with prn > 0, first nact[e] entries valid
+    const int *nact;     // [E]
+
+    // carrier speculation
+    double *pst;        // [E][S] start phase the last walk used
+    double *pend;       // [E][S] end phase of that walk
+    uint8_t *verified;  // [E][S]
+    uint8_t *dirty;     // [E][S]
+
+    // checkpoints, one per chunk + end state
+    double *cp_x;     // [E][S][CP1]
+    double *cp_p;     // [E][S][CP1]
+    uint32_t *cp_ib;  // [E][S][CP1]  ibit | flipped << 16
+
+    int *ctr;  // [CTR_COUNT]
+
+    // tables
+    const uint32_t *e1b;  // [50][128]
+    const uint32_t *e1c;  // [50][128]
+    const int *lut;       // [512] 2 * (sin << 16 + cos)
+};
+
+#endif

@@ -1,0 +1,393 @@
+// synth_kernels.hip -- gfx950 (CDNA4) kernels of the Galileo E1B/C IQ synthesis engine.
+//
+// Replaces the per-sample loop of the reference, src/galileo-sdr.cpp:481-539.
+// Pipeline per batch of epochs (all on one HIP stream):
+//   k_prep         AoS epoch records -> SoA, NCO steps c = f_code*delt, d = f_carr*delt (one rounding each,
+//                  exactly the product the reference recomputes every sample, :528,:531)
+//   k_walk_code    one lane per (epoch, slot): exact closed-form walk of the code-phase chain, emitting a
+//                  checkpoint (phase, symbol index, page-flip flag) every R samples           [nco_walk.h]
+//   k_carr_guess / k_walk_carr / k_carr_scan
+//                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively:
+//                  every (epoch, slot) lane walks its epoch from a guessed start phase; a scan accepts
+//                  a chunk only when its start is BITWISE equal to the verified end of the previous one and
+//                  otherwise shifts the guess (rounded-add chains commute with shifts on the 2^-52 grid);
+//                  repeat until every chunk is verified -- typically 3 passes.
+//   k_pages        which page is in force at each epoch start (pages change only when a symbol counter
+//                  wraps inside the sample loop, :497-506)
+//   k_synth<NCH>   the hot kernel: one lane replays R consecutive samples for ALL active channels with the
+//                  reference's exact operation sequence from its checkpoint, accumulates packed
+//                  (Q<<16)+I in a register, and stores int16 I/Q with 16-byte stores.  PRN memory codes
+//                  (bit packed) and the sin/cos LUT live in LDS.  Each lane finally checks its end state
+//                  against the next checkpoint, so the closed-form walkers are verified against genuine
+//                  stepping on every run.
+// No MFMA anywhere: this is FP64/integer ALU work bounded above by the 4 B/sample HBM write.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nco_walk.h"
+#include "synth_dev.h"
+
+using namespace galnco;
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prep(DevPlan P)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.E * P.S) return;
+    const gal_chan_epoch_t *r = &P.params[idx];
+    const int prn = r->prn;
+    P.prn[idx] = prn;
+    P.flags[idx] = r->flags;
+    P.ib0[idx] = r->ibit0;
+    P.x0[idx] = r->code_phase0;
+    P.p0[idx] = r->carr_phase0;
+    // src/galileo-sdr.cpp:528,531: the product is rounded to double before it is added
+    P.cstep[idx] = r->f_code * P.delt;
+    P.dstep[idx] = r->f_carr * P.delt;
+#pragma unroll
+    for (int w = 0; w < GAL_PAGE_WORDS; ++w) {
+        P.page_next[(size_t)idx * GAL_PAGE_WORDS + w] = r->page_next[w];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_walk_code(DevPlan P)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.E * P.S) return;
+    if (P.prn[idx] <= 0) return;
+    double *cpx = P.cp_x + (size_t)idx * P.CP1;
+    uint32_t *cpi = P.cp_ib + (size_t)idx * P.CP1;
+    const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], P.cstep[idx], P.N, P.R,
+                                  [&](int c, double x, int ibit, int flipped) {
+                                      cpx[c] = x;
+                                      cpi[c] = (uint32_t)ibit | ((uint32_t)flipped << 16);
+                                  });
+    cpx[P.nchunks] = end.x;
+    cpi[P.nchunks] = (uint32_t)end.ibit | ((uint32_t)end.flipped << 16);
+    // a wrap still pending after the last sample is discarded by the next epoch's overwrite
+    // (SURVEY.md §7.3-3), so only flips that happened inside the loop count
+    P.flip_in[idx] = (uint8_t)end.flipped;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Initial guesses for the carrier phase at every epoch start: ideal (unrounded-chain) arithmetic.
+__global__ void k_carr_guess(DevPlan P)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < P.S)
+        carr_guess_slot(s, P.E, P.S, P.N, P.prn, P.flags, P.p0, P.dstep, P.state_in[s].carr_phase, P.pst,
+                        P.verified, P.dirty);
+    if (s == 0) {
+        P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk
+        P.ctr[CTR_PASSES] = 0;
+    }
+}
+
+__global__ void k_walk_carr(DevPlan P)
+{
+    if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.E * P.S) return;
+    if (P.prn[idx] <= 0 || !P.dirty[idx]) return;
+    double *cpp = P.cp_p + (size_t)idx * P.CP1;
+    const double pe = carr_walk(P.pst[idx], P.dstep[idx], P.N, P.R, [&](int c, double p) { cpp[c] = p; });
+    cpp[P.nchunks] = pe;
+    P.pend[idx] = pe;
+    P.dirty[idx] = 0;
+}
+
+// One lane per slot stitches the epochs (carr_scan_slot, nco_walk.h).
+__global__ void k_carr_scan(DevPlan P, int jacobi)
+{
+    if (P.ctr[CTR_UNVERIFIED] == 0) return;
+    __shared__ int s_unver;
+    if (threadIdx.x == 0) s_unver = 0;
+    __syncthreads();
+    const int s = threadIdx.x;
+    if (s < P.S) {
+        const int unver = carr_scan_slot(s, P.E, P.S, P.prn, P.flags, P.p0, P.state_in[s].carr_phase, P.pst,
+                                         P.pend, P.verified, P.dirty, jacobi);
+        if (unver) atomicAdd(&s_unver, unver);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        P.ctr[CTR_UNVERIFIED] = s_unver;
+        P.ctr[CTR_PASSES] += 1;
+    }
+}
+
+// Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88.
+// blockDim = (16 words, S slots)
+__global__ void k_pages(DevPlan P)
+{
+    const int w = threadIdx.x, s = threadIdx.y;
+    if (s >= P.S) return;
+    uint32_t cur = P.state_in[s].page[w];
+    for (int e = 0; e < P.E; ++e) {
+        const int idx = e * P.S + s;
+        if (P.prn[idx] <= 0) continue;
+        if (P.flags[idx] & GAL_CH_RESTART) cur = P.params[idx].page_init[w];
+        P.page_cur[(size_t)idx * GAL_PAGE_WORDS + w] = cur;
+        if (P.flip_in[idx]) cur = P.page_next[(size_t)idx * GAL_PAGE_WORDS + w];
+    }
+    // end-of-batch state for the next call
+    const int last = (P.E - 1) * P.S + s;
+    P.state_out[s].page[w] = cur;
+    if (w == 0) {
+        const int prn = P.prn[last];
+        P.state_out[s].prn = prn > 0 ? prn : 0;
+        P.state_out[s].carr_phase = prn > 0 ? P.pend[last] : 0.0;
+        P.state_out[s].reserved = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hot kernel.  Block = 256 threads = 4 waves = 4 tiles of 64 chunks of ONE epoch, so every per-epoch
+// constant (NCO steps, active PRNs, record index) is wave-uniform and lives in SGPRs.
+// LDS: [NCH][2][128] packed code words + 512-entry LUT.
+// Per-lane state per channel: code phase (2 VGPR), carrier phase (2), two cached 32-chip code words
+// already XORed with the data / secondary-code sign (2), and one packed word
+//     st = ibit[8:0] | use_next_page[9] | cached_word_index[23:16] (0xff = invalid).
+#define SYN_BLOCK 256
+#define ST_WI_INVALID 0x00ff0000u
+
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const uint64_t u = d2u(v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+
+// data symbol (page bit) and secondary-code chip for symbol index `ibit`: bit0 / bit1, 1 => sign -1
+// (src/galileo-sdr.cpp:517-518)
+__device__ __forceinline__ uint32_t sym_bits(const DevPlan &P, int idx, int ibit, int use_next)
+{
+    const uint32_t *pg = (use_next ? P.page_next : P.page_cur) + (size_t)idx * GAL_PAGE_WORDS;
+    const uint32_t dbit = (pg[ibit >> 5] >> (ibit & 31)) & 1u;
+    const uint32_t sbit = (P.cs25 >> (ibit % 25)) & 1u;
+    return dbit | (sbit << 1);
+}
+
+// Per-channel replay state.  Kept as individually named scalars (macro-expanded below), NOT arrays:
+// hipcc turns small per-thread arrays into wide vector registers and then copies whole tuples around
+// every conditional update (measured: 242 VGPR + 162 AGPR for 12 channels vs ~10 VGPR/channel as scalars).
+struct ChanState {
+    double x;     // code phase, chips (pre wrap-check)
+    double p;     // carrier phase, cycles
+    uint32_t wB;  // cached 32 chips of E1-B  ^ data-symbol mask
+    uint32_t wC;  // cached 32 chips of E1-C  ^ secondary-code mask
+    uint32_t st;  // ibit | use_next<<9 | cached word index<<16
+};
+
+// One sample of one channel: src/galileo-sdr.cpp:491-532.  J = channel position in the launch
+// (LDS code bank, fmask bit pair).  Returns the packed contribution (ip + (qp << 16)).
+template <int J>
+__device__ __forceinline__ int chan_step(ChanState &c, const double cs, const double ds, const int sidx,
+                                         uint32_t &fmask, const DevPlan &P, const uint32_t *s_code,
+                                         const int *s_lut)
+{
+    // --- symbol / page advance, :491-507 (rare: once per 4 ms of signal)
+    if (__builtin_expect(c.x >= 4092.0, 0)) {
+        int idx = sidx;
+        asm volatile("" : "+s"(idx));  // keep the address math inside the rare path
+        c.x -= 4092.0;
+        int ibit = (int)(c.st & 0x1ffu) + 1;
+        int nx = (int)((c.st >> 9) & 1u);
+        if (ibit >= GAL_N_SYM_PAGE) {
+            ibit = 0;
+            nx = 1;
+        }
+        c.st = (uint32_t)ibit | ((uint32_t)nx << 9) | ST_WI_INVALID;  // sign masks change: drop the cached words
+        fmask = (fmask & ~(3u << (2 * J))) | (sym_bits(P, idx, ibit, nx) << (2 * J));
+    }
+    // --- chip lookup, :512-515.  boc[2c] = -chip, boc[2c+1] = +chip (src/gal-sig.cpp:198-213)
+    const int ic = (int)(c.x * 2.0);
+    const uint32_t w = (uint32_t)ic >> 6;  // 32-chip word index
+    if (__builtin_expect(w != (c.st >> 16), 0)) {
+        c.st = (c.st & 0xffffu) | (w << 16);
+        const uint32_t dm = 0u - ((fmask >> (2 * J)) & 1u);
+        const uint32_t sm = 0u - ((fmask >> (2 * J + 1)) & 1u);
+        c.wB = s_code[J * 256 + w] ^ dm;
+        c.wC = s_code[J * 256 + 128 + w] ^ sm;
+    }
+    const uint32_t sh = ((uint32_t)ic >> 1) & 31u;
+    const uint32_t eb = c.wB >> sh;  // bit0: E1B chip * data symbol is -1
+    const uint32_t ec = c.wC >> sh;  // bit0: E1C chip * secondary chip is -1
+    // v = E1B*d - E1C*s in {-2,0,+2}, times the BOC half-chip sign (:517-521)
+    const uint32_t nz = (eb ^ ec) & 1u;
+    const uint32_t neg = (ec ^ (uint32_t)ic) & 1u;
+    // --- carrier LUT, :509-510: trunc toward zero, then two's-complement mask
+    const int k = ((int)(511.0 * c.p)) & 511;
+    const int t = s_lut[k];  // 2*(sin<<16 + cos)
+    const int m = 0 - (int)neg;
+    // --- NCO updates, :528-532
+    c.x = c.x + cs;
+    c.p = carr_step(c.p, ds);
+    return ((t ^ m) - m) & (0 - (int)nz);
+}
+
+#define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
+#define GAL_MAX_NCH 12
+
+// ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
+template <int NCH, bool ACC>
+__global__ __launch_bounds__(SYN_BLOCK) void k_synth(DevPlan P, const uint8_t *__restrict__ act_all,
+                                                     const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
+{
+    static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
+    __shared__ uint32_t s_code[NCH * 2 * 128];
+    __shared__ int s_lut[512];
+
+    const int bpe = P.blocks_per_epoch;
+    const int e = blockIdx.x / bpe;
+    const int tg = blockIdx.x - e * bpe;
+    const int tid = threadIdx.x;
+    const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
+    const uint8_t *act = act_all + (size_t)e * P.S;
+
+    for (int i = tid; i < 512; i += SYN_BLOCK) s_lut[i] = P.lut[i];
+    for (int j = 0; j < nact; ++j) {
+        const int prn = P.prn[e * P.S + act[j]];
+        for (int i = tid; i < 256; i += SYN_BLOCK) {
+            const uint32_t *src = (i < 128) ? (P.e1b + (prn - 1) * 128 + i) : (P.e1c + (prn - 1) * 128 + (i - 128));
+            s_code[j * 256 + i] = *src;
+        }
+    }
+    __syncthreads();
+
+    const int c = (tg * (SYN_BLOCK / 64) + (tid >> 6)) * 64 + (tid & 63);  // chunk index within the epoch
+    if (c >= P.nchunks) return;
+    const int n0 = c * P.R;
+    int nsteps = P.N - n0;
+    if (nsteps > P.R) nsteps = P.R;
+
+    uint32_t fmask = 0;  // bit 2j: data symbol, bit 2j+1: secondary chip (1 => sign -1)
+
+#define GAL_DECL(j)                                                                         \
+    ChanState ch##j = {0.0, 0.0, 0u, 0u, ST_WI_INVALID};                                    \
+    double cs##j = 0.0, ds##j = 0.0;                                                        \
+    int sidx##j = 0;                                                                        \
+    if (j < NCH && j < nact) {                                                              \
+        const int idx = __builtin_amdgcn_readfirstlane(e * P.S + (int)act[j]);              \
+        sidx##j = idx;                                                                      \
+        const size_t cp = (size_t)idx * P.CP1 + c;                                          \
+        ch##j.x = P.cp_x[cp];                                                               \
+        ch##j.p = P.cp_p[cp];                                                               \
+        const uint32_t v = P.cp_ib[cp]; /* ibit | flipped<<16 */                            \
+        cs##j = uniform_f64(P.cstep[idx]);                                                  \
+        ds##j = uniform_f64(P.dstep[idx]);                                                  \
+        const int ibit = (int)(v & 0xffffu);                                                \
+        const int nx = (int)(v >> 16);                                                      \
+        ch##j.st = (uint32_t)ibit | ((uint32_t)nx << 9) | ST_WI_INVALID;                    \
+        fmask |= sym_bits(P, idx, ibit, nx) << (2 * j);                                     \
+    }
+    GAL_CH_LIST(GAL_DECL)
+#undef GAL_DECL
+
+    uint32_t *out = iq + (size_t)e * P.N + n0;
+    const bool vec_ok = ((((size_t)e * P.N + n0) & 3) == 0);
+
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        uint32_t o[4];
+        if (ACC) {
+            if (vec_ok && s0 + 4 <= nsteps) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(out + s0);
+                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = (s0 + u < nsteps) ? out[s0 + u] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int acc = ACC ? (int)(o[u] & 0xffff0000u) + (int)(short)(o[u] & 0xffffu) : 0;
+#define GAL_STEP(j) \
+    if (j < NCH && j < nact) acc += chan_step<j>(ch##j, cs##j, ds##j, sidx##j, fmask, P, s_code, s_lut);
+            GAL_CH_LIST(GAL_STEP)
+#undef GAL_STEP
+            // acc = Q*65536 + I with |I|,|Q| < 32768  ->  little-endian int16 pair I,Q (:536-537)
+            o[u] = (((uint32_t)acc + 0x8000u) & 0xffff0000u) | ((uint32_t)acc & 0xffffu);
+        }
+        if (vec_ok && s0 + 4 <= nsteps) {
+            *reinterpret_cast<uint4 *>(out + s0) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < nsteps) out[s0 + u] = o[u];
+        }
+    }
+
+    // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit.
+    // (When nsteps % 4 != 0 the loop above overran by up to 3 steps, so only chunks whose length is a
+    // multiple of 4 are checkable -- every chunk when samples_per_epoch % 4 == 0.)
+    if ((nsteps & 3) == 0) {
+        int bad = 0;
+#define GAL_CHECK(j)                                                                  \
+    if (j < NCH && j < nact) {                                                        \
+        const size_t cp = (size_t)sidx##j * P.CP1 + c + 1;                            \
+        const uint32_t v = P.cp_ib[cp];                                               \
+        bad += d2u(ch##j.x) != d2u(P.cp_x[cp]);                                       \
+        bad += d2u(ch##j.p) != d2u(P.cp_p[cp]);                                       \
+        bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
+    }
+        GAL_CH_LIST(GAL_CHECK)
+#undef GAL_CHECK
+        if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers (called from synth_api.cpp, which is plain C++ and does not see <<<>>>).
+extern "C" void galk_launch_prep(const DevPlan *P, hipStream_t st)
+{
+    const int n = P->E * P->S;
+    hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, *P);
+}
+
+extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
+{
+    const int n = P->E * P->S;
+    hipLaunchKernelGGL(k_walk_code, dim3((n + 63) / 64), dim3(64), 0, st, *P);
+}
+
+extern "C" void galk_launch_carr_guess(const DevPlan *P, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_carr_guess, dim3(1), dim3(64), 0, st, *P);
+}
+
+extern "C" void galk_launch_walk_carr(const DevPlan *P, hipStream_t st)
+{
+    const int n = P->E * P->S;
+    hipLaunchKernelGGL(k_walk_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P);
+}
+
+extern "C" void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_carr_scan, dim3(1), dim3(64), 0, st, *P, jacobi);
+}
+
+extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pages, dim3(1), dim3(GAL_PAGE_WORDS, P->S), 0, st, *P);
+}
+
+template <bool ACC>
+static int launch_synth_t(const DevPlan *P, int nch, const uint8_t *act, const int *nact, uint32_t *iq,
+                          hipStream_t st)
+{
+    const dim3 grid(P->E * P->blocks_per_epoch), block(SYN_BLOCK);
+    if (nch <= 4) hipLaunchKernelGGL((k_synth<4, ACC>), grid, block, 0, st, *P, act, nact, iq);
+    else if (nch <= 8) hipLaunchKernelGGL((k_synth<8, ACC>), grid, block, 0, st, *P, act, nact, iq);
+    else if (nch <= 12) hipLaunchKernelGGL((k_synth<12, ACC>), grid, block, 0, st, *P, act, nact, iq);
+    else return -1;
+    return 0;
+}
+
+extern "C" int galk_launch_synth(const DevPlan *P, int nch, int accumulate, const uint8_t *act, const int *nact,
+                                 uint32_t *iq, hipStream_t st)
+{
+    return accumulate ? launch_synth_t<true>(P, nch, act, nact, iq, st)
+                      : launch_synth_t<false>(P, nch, act, nact, iq, st);
+}

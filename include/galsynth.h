@@ -1,0 +1,148 @@
+/*
+ * galsynth.h -- C ABI of the MI355X Galileo E1B/C baseband IQ synthesis engine.
+ *
+ * This is the drop-in boundary for the reference's per-sample hot loop.  The reference
+ * (harshadms/galileo-sdr-sim) exposes no plugin/FFI interface for this path: the loop is inline in
+ * galileo_task() at src/galileo-sdr.cpp:481-539.  The entry points below are what a maintainer
+ * would call where that loop stands: everything the loop READS is carried by
+ * gal_chan_epoch_t / gal_chan_state_t, everything it WRITES is the interleaved int16 IQ buffer
+ * (src/galileo-sdr.cpp:536-537, the `ishort` wire format of gnss-sdr_Galileo_E1_ishort.conf:14-21)
+ * plus the per-channel state that survives an epoch (carr_phase and page, §7.3-3 of SURVEY.md).
+ *
+ * Plain C, plain pointers and sizes; no torch / HIP types in the signatures (a hipStream_t is passed
+ * as void*).  One handle per GPU/stream; a handle is thread-compatible, not thread-safe.
+ * All functions return GAL_OK (0) or a negative gal_status_t; gal_synth_last_error() gives text.
+ */
+#ifndef GALSYNTH_H_
+#define GALSYNTH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAL_MAX_CHAN 16          /* reference MAX_CHAN, include/constants.h:10 (engine accepts up to 64) */
+#define GAL_ENGINE_MAX_CHAN 64   /* packed I/Q accumulation stays inside int16 up to 65 channels       */
+#define GAL_N_SYM_PAGE 500       /* symbols per page, include/constants.h:34                            */
+#define GAL_PAGE_WORDS 16        /* 500 symbols, bit i of word i>>5 (LSB first) = symbol i              */
+#define GAL_CODE_LEN 4092        /* CA_SEQ_LEN_E1, include/constants.h:124                              */
+#define GAL_NUM_PRN 50
+
+typedef enum gal_status {
+    GAL_OK = 0,
+    GAL_E_INVAL = -1,     /* bad argument                                                   */
+    GAL_E_NOMEM = -2,     /* host or device allocation failed                               */
+    GAL_E_DEVICE = -3,    /* HIP runtime error / no usable GPU (there is NO CPU fallback)   */
+    GAL_E_STATE = -4,     /* call sequence error (execute before plan, ...)                 */
+    GAL_E_CHAIN = -5,     /* NCO chain self-check failed (see gal_synth_stats_t)            */
+    GAL_E_IO = -6
+} gal_status_t;
+
+/* gal_chan_epoch_t.flags */
+#define GAL_CH_RESTART 1u /* channel (re)allocated before this epoch: carrier phase := carr_phase0, page := page_init
+                             (src/channel.cpp:81-99) */
+
+/*
+ * What the hot loop reads for ONE channel slot in ONE 0.1 s epoch -- the values
+ * computeCodePhase() (src/gal-sig.cpp:308-347) leaves in channel_t (include/structures.h:140-162)
+ * right before `for (isamp...)` (src/galileo-sdr.cpp:481), plus the two pages the loop may use.
+ */
+typedef struct gal_chan_epoch {
+    int32_t  prn;          /* 1..50; 0 = idle slot (chan[i].prn, src/galileo-sdr.cpp:489)                      */
+    int32_t  ibit0;        /* chan.ibit at epoch start, 0..499 (src/gal-sig.cpp:334,338)                         */
+    uint32_t flags;        /* GAL_CH_*                                                                           */
+    uint32_t reserved;
+    double   f_carr;       /* Hz, chan.f_carr (src/gal-sig.cpp:318)                                             */
+    double   f_code;       /* Hz, chan.f_code (src/gal-sig.cpp:320)                                             */
+    double   code_phase0;  /* chips, chan.code_phase at epoch start (src/gal-sig.cpp:336)                       */
+    double   carr_phase0;  /* cycles; used only with GAL_CH_RESTART (src/channel.cpp:98-99)                     */
+    uint32_t page_next[GAL_PAGE_WORDS]; /* page generateINavMsg(grx_of_this_epoch) would produce: installed when
+                                           ibit wraps 499->0 inside this epoch (src/galileo-sdr.cpp:497-506)    */
+    uint32_t page_init[GAL_PAGE_WORDS]; /* page in force at epoch start; used only with GAL_CH_RESTART          */
+} gal_chan_epoch_t;        /* 176 bytes */
+
+/* State that survives an epoch (and a call): carr_phase and the current page, per slot. */
+typedef struct gal_chan_state {
+    double   carr_phase;               /* chan.carr_phase after the last sample (src/galileo-sdr.cpp:531-532) */
+    uint32_t page[GAL_PAGE_WORDS];     /* chan.page                                                            */
+    int32_t  prn;                      /* PRN the state belongs to (0 = none)                                   */
+    int32_t  reserved;
+} gal_chan_state_t;        /* 80 bytes */
+
+typedef struct gal_synth_cfg {
+    double  sample_rate;        /* Hz; reference: 2.6e6 (include/constants.h:96). delt = 1.0 / sample_rate     */
+    int32_t samples_per_epoch;  /* reference: NUM_IQ_SAMPLES = 260000 (include/constants.h:82)                 */
+    int32_t n_slots;            /* channel slots per epoch record row; reference MAX_CHAN = 16                 */
+    int32_t device;             /* HIP device ordinal; -1 = current device                                     */
+    int32_t chunk_samples;      /* 0 = auto (~1024); samples replayed by one lane (multiple of 4)              */
+    int32_t max_walk_passes;    /* 0 = default (32); cap on speculative carrier-walk passes before GAL_E_CHAIN */
+    int32_t reserved[3];
+} gal_synth_cfg_t;
+
+typedef struct gal_synth_stats {
+    int32_t walk_passes;        /* carrier-walker passes the last execute needed                               */
+    int32_t chain_mismatch;     /* #chunk boundaries where the replay kernel disagreed with the walker (must be 0) */
+    int32_t n_epochs;
+    int32_t n_active_max;       /* max simultaneously active channels in the plan                              */
+    int32_t chunk_samples;
+    int32_t chunks_per_epoch;
+    float   ms_walk;            /* device time of the walker kernels, last execute (0 if timing disabled)      */
+    float   ms_synth;           /* device time of the synthesis kernel, last execute                           */
+} gal_synth_stats_t;
+
+typedef struct gal_synth gal_synth_t;
+
+/* Library / build identification; never fails. */
+const char *gal_synth_version(void);
+/* Text of the last error on this thread. */
+const char *gal_synth_last_error(void);
+/* Number of usable gfx950 devices (0 if none). */
+int gal_synth_device_count(void);
+
+int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out);
+int gal_synth_destroy(gal_synth_t *h);
+
+/* Use `hip_stream` (a hipStream_t) for all work of this handle; NULL = the handle's own stream. */
+int gal_synth_set_stream(gal_synth_t *h, void *hip_stream);
+
+/*
+ * Upload the per-epoch parameters of a batch: params[e * n_slots + s], e < n_epochs (host memory).
+ * state_in (host, n_slots entries, may be NULL for a fresh run) gives carr_phase/page for channels
+ * that continue from a previous batch (records without GAL_CH_RESTART in their first active epoch).
+ * After this call the batch is resident in HBM.
+ */
+int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                   const gal_chan_state_t *state_in);
+
+/* Bytes of IQ the planned batch produces: n_epochs * samples_per_epoch * 4. */
+size_t gal_synth_output_bytes(const gal_synth_t *h);
+
+/*
+ * Run the hot path for the planned batch: NCO walk + per-sample synthesis, writing
+ * interleaved int16 I,Q (little endian) to iq_dev (DEVICE memory, 16-byte aligned).  Asynchronous on
+ * the handle's stream; may be called repeatedly for the same plan (bench loop).
+ */
+int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
+
+/* Wait for the stream, check the chain self-check, return the end-of-batch channel state (host,
+ * n_slots entries, may be NULL) and statistics (may be NULL). */
+int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats);
+
+/* Convenience: plan + execute into an internal device buffer + copy to host `iq_host` + finish. */
+int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                       const gal_chan_state_t *state_in, int16_t *iq_host,
+                       gal_chan_state_t *state_out, gal_synth_stats_t *stats);
+
+/* Signal tables as the engine uses them (for tests and for the oracle to share DATA, not code). */
+const uint32_t *gal_tables_e1b(void);   /* [50][128] */
+const uint32_t *gal_tables_e1c(void);   /* [50][128] */
+const int16_t  *gal_tables_cos512(void);/* [512]     */
+const int16_t  *gal_tables_sin512(void);/* [512]     */
+uint32_t        gal_tables_cs25(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GALSYNTH_H_ */

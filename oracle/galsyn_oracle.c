@@ -1,0 +1,221 @@
+/*
+ * galsyn_oracle.c -- CPU restatement of the reference's per-sample synthesis loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (galileo-sdr-sim_amd/, the C-ABI library, the
+ * CLI) may include, link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and only as the checker.
+ *
+ * It follows harshadms/galileo-sdr-sim @2024_10_08 operation for operation:
+ *   - sample loop, channel loop, accumulate, store ......... src/galileo-sdr.cpp:481-539
+ *   - code expansion hex -> chips -> BOC(1,1) half chips ... src/gal-sig.cpp:9-233
+ *   - tables (carrier LUT, CS25) ............................ include/constants.h:213-284
+ *   - state overwritten at epoch start ..................... src/gal-sig.cpp:308-347 (values arrive
+ *     in gal_chan_epoch_t), carrier phase / page carried ... src/galileo-sdr.cpp:531-532, :505
+ * Compile with -O2 -ffp-contract=off (x86-64 baseline has no FMA, so the reference never fuses).
+ *
+ * Parity pin: the reference cannot be built in this image without stand-ins for UHD/Boost headers
+ * (every TU includes include/galileo-sdr.h:12-15 and include/structures.h:2), so oracle/_ref holds
+ * only a dumper for include/constants.h (tables).  The loop itself is pinned end to end by the
+ * reference's own output checksum recorded in BASELINE.md §2 (md5 7ab498dea29a96ff4c4729995d309222,
+ * `-l -6,51,100 -t 2022/02/20,12:00:00 -d 10 -I 1`): tests/test_golden_g1.py feeds this oracle with the
+ * host front-end's parameters for that scenario and requires the same md5.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/galsynth.h"
+#include "../galileo-sdr-sim_amd/csrc/e1_tables.inc" /* DATA shared with the engine, not code */
+
+#define HALF_CHIPS (2 * GAL_CODE_LEN)
+
+typedef struct {
+    int    prn;
+    short  ca_E1B[HALF_CHIPS];
+    short  ca_E1C[HALF_CHIPS];
+    double f_carr, f_code;
+    int    page[GAL_N_SYM_PAGE];
+    double carr_phase;
+    double code_phase;
+    int    ibit;
+} ochan_t;
+
+static int o_cos[512], o_sin[512];
+static char o_cs25[25];
+static int o_tables_ready = 0;
+
+static void o_init_tables(void)
+{
+    int k;
+    if (o_tables_ready) return;
+    for (k = 0; k < 512; k++) {
+        int c;
+        if (k < 128) c = kCosQ[k];
+        else if (k < 256) c = -kCosQ[255 - k];
+        else c = (511 - k) < 128 ? kCosQ[511 - k] : -kCosQ[255 - (511 - k)];
+        o_cos[k] = c;
+    }
+    for (k = 0; k < 512; k++) o_sin[k] = o_cos[(k - 128) & 511];
+    for (k = 0; k < 25; k++) o_cs25[k] = (char)((kCS25 >> k) & 1u);
+    o_tables_ready = 1;
+}
+
+/* hex_to_binary_converter + sboc(…,1,1): logic level 0 -> +1, 1 -> -1; each chip c becomes [-c, +c]
+ * (src/gal-sig.cpp:9-191, 198-213, 219-233). */
+static void o_codegen(short *ca, const uint32_t *packed)
+{
+    int i;
+    for (i = 0; i < GAL_CODE_LEN; i++) {
+        short c = ((packed[i >> 5] >> (i & 31)) & 1u) ? -1 : 1;
+        ca[2 * i] = (short)-c;
+        ca[2 * i + 1] = c;
+    }
+}
+
+static void o_unpack_page(int *page, const uint32_t *w)
+{
+    int i;
+    for (i = 0; i < GAL_N_SYM_PAGE; i++) page[i] = (int)((w[i >> 5] >> (i & 31)) & 1u);
+}
+
+static void o_pack_page(uint32_t *w, const int *page)
+{
+    int i;
+    memset(w, 0, GAL_PAGE_WORDS * sizeof(uint32_t));
+    for (i = 0; i < GAL_N_SYM_PAGE; i++)
+        if (page[i] > 0) w[i >> 5] |= 1u << (i & 31);
+}
+
+static long o_get_nanos(void)
+{
+    struct timespec ts;
+    timespec_get(&ts, TIME_UTC);
+    return (long)ts.tv_sec * 1000000000L + ts.tv_nsec;
+}
+
+/*
+ * Returns 0, or -1 on a malformed batch.  clock_read != 0 reproduces the reference's per-sample
+ * get_nanos() (src/galileo-sdr.cpp:485) for the timed CPU baseline.
+ */
+int gal_oracle_run(const gal_chan_epoch_t *params, int n_epochs, int n_slots, int samples_per_epoch,
+                   double sample_rate, const gal_chan_state_t *state_in, int16_t *iq_out,
+                   gal_chan_state_t *state_out, int clock_read)
+{
+    ochan_t *chan;
+    int e, i, isamp;
+    double delt = 1.0 / sample_rate; /* src/galileo-sdr.cpp:162 */
+    volatile double sink = 0;
+
+    o_init_tables();
+    if (n_slots < 1 || n_slots > GAL_ENGINE_MAX_CHAN) return -1;
+    chan = (ochan_t *)calloc((size_t)n_slots, sizeof(ochan_t));
+    if (!chan) return -1;
+
+    for (i = 0; i < n_slots; i++) {
+        chan[i].prn = 0;
+        if (state_in && state_in[i].prn > 0) {
+            chan[i].prn = state_in[i].prn;
+            chan[i].carr_phase = state_in[i].carr_phase;
+            o_unpack_page(chan[i].page, state_in[i].page);
+            o_codegen(chan[i].ca_E1B, kE1B[chan[i].prn - 1]);
+            o_codegen(chan[i].ca_E1C, kE1C[chan[i].prn - 1]);
+        }
+    }
+
+    for (e = 0; e < n_epochs; e++) {
+        const gal_chan_epoch_t *row = params + (size_t)e * n_slots;
+        int16_t *iq_buff = iq_out + (size_t)e * samples_per_epoch * 2;
+
+        /* epoch start: what allocateChannel / computeCodePhase left in chan[] */
+        for (i = 0; i < n_slots; i++) {
+            const gal_chan_epoch_t *r = &row[i];
+            if (r->prn <= 0) { chan[i].prn = 0; continue; }
+            if (r->prn > GAL_NUM_PRN) { free(chan); return -1; }
+            if (r->flags & GAL_CH_RESTART) {
+                chan[i].prn = r->prn;
+                o_codegen(chan[i].ca_E1B, kE1B[r->prn - 1]);
+                o_codegen(chan[i].ca_E1C, kE1C[r->prn - 1]);
+                o_unpack_page(chan[i].page, r->page_init);
+                chan[i].carr_phase = r->carr_phase0;
+            } else if (chan[i].prn != r->prn) {
+                free(chan);
+                return -1; /* continuing channel without state */
+            }
+            chan[i].f_carr = r->f_carr;
+            chan[i].f_code = r->f_code;
+            chan[i].code_phase = r->code_phase0;
+            chan[i].ibit = r->ibit0;
+        }
+
+        for (isamp = 0; isamp < samples_per_epoch; isamp++) {
+            int i_acc = 0;
+            int q_acc = 0;
+            if (clock_read) sink = (double)o_get_nanos();
+            for (i = 0; i < n_slots; i++) {
+                if (chan[i].prn > 0) {
+                    int cosPh, sinPh, icode, E1B_chip, E1C_chip, databit, secCode, ip, qp;
+                    if (chan[i].code_phase >= GAL_CODE_LEN) {
+                        chan[i].code_phase -= GAL_CODE_LEN;
+                        chan[i].ibit++;
+                        if (chan[i].ibit >= GAL_N_SYM_PAGE) {
+                            chan[i].ibit = 0;
+                            o_unpack_page(chan[i].page, row[i].page_next);
+                        }
+                    }
+                    cosPh = o_cos[((int)(511 * chan[i].carr_phase)) & 511];
+                    sinPh = o_sin[((int)(511 * chan[i].carr_phase)) & 511];
+
+                    icode = (int)(chan[i].code_phase * 2);
+
+                    E1B_chip = chan[i].ca_E1B[icode];
+                    E1C_chip = chan[i].ca_E1C[icode];
+
+                    databit = chan[i].page[chan[i].ibit] > 0 ? -1 : 1;
+                    secCode = o_cs25[chan[i].ibit % 25] > 0 ? -1 : 1;
+
+                    ip = (E1B_chip * databit - E1C_chip * secCode) * cosPh;
+                    qp = (E1B_chip * databit - E1C_chip * secCode) * sinPh;
+
+                    i_acc += ip;
+                    q_acc += qp;
+
+                    chan[i].code_phase += chan[i].f_code * delt;
+
+                    chan[i].carr_phase += (chan[i].f_carr) * delt;
+                    chan[i].carr_phase -= (long)chan[i].carr_phase;
+                }
+            }
+            iq_buff[isamp * 2] = (short)i_acc;
+            iq_buff[isamp * 2 + 1] = (short)q_acc;
+        }
+    }
+
+    if (state_out) {
+        for (i = 0; i < n_slots; i++) {
+            memset(&state_out[i], 0, sizeof(state_out[i]));
+            state_out[i].prn = chan[i].prn;
+            if (chan[i].prn > 0) {
+                state_out[i].carr_phase = chan[i].carr_phase;
+                o_pack_page(state_out[i].page, chan[i].page);
+            }
+        }
+    }
+    (void)sink;
+    free(chan);
+    return 0;
+}
+
+/* Expanded tables, for checking against oracle/_ref's dump of the reference header. */
+void gal_oracle_tables(int *cos512, int *sin512, char *cs25)
+{
+    o_init_tables();
+    memcpy(cos512, o_cos, sizeof(o_cos));
+    memcpy(sin512, o_sin, sizeof(o_sin));
+    memcpy(cs25, o_cs25, sizeof(o_cs25));
+}
+
+void gal_oracle_codegen(int prn, int e1c, short *ca /* 8184 */)
+{
+    o_codegen(ca, e1c ? kE1C[prn - 1] : kE1B[prn - 1]);
+}

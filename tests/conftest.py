@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    from __graft_entry__ import load_pkg
+
+    p = load_pkg()
+    lib_missing = not os.path.exists(os.path.join(ROOT, "galileo-sdr-sim_amd", "libgalsynth.so"))
+    if lib_missing:
+        p.build_all()
+    return p
+
+
+@pytest.fixture(scope="session")
+def gpu_engine_factory(pkg):
+    """Creating an engine fails loudly when there is no usable gfx950 device."""
+
+    def make(**kw):
+        return pkg.SynthEngine(**kw)
+
+    return make

@@ -1,0 +1,125 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle, bit for bit, on seeded inputs.
+int16 IQ is integer work: the bar is exact equality, pre-quantisation tolerance is 0."""
+import numpy as np
+import pytest
+
+from oracle_binding import oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(pkg, params, n_samp, rate=2.6e6, state_in=None, **eng_kw):
+    n_slots = params.shape[1]
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=0, **eng_kw) as eng:
+        iq, st, stats = eng.run_host(params, state_in)
+    ref_iq, ref_st = oracle_run(params, n_samp, rate, state_in)
+    assert stats["chain_mismatch"] == 0
+    nbad = int(np.count_nonzero(iq != ref_iq))
+    assert nbad == 0, "%d of %d int16 values differ (first at %d)" % (nbad, iq.size, int(np.flatnonzero(iq != ref_iq)[0]))
+    act = ref_st["prn"] > 0
+    assert np.array_equal(st["prn"], ref_st["prn"])
+    assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+    assert np.array_equal(st["page"][act], ref_st["page"][act])
+    return iq, st, stats
+
+
+@pytest.mark.parametrize("n_chan", [1, 4, 9, 12])
+def test_small_batches_bit_exact(pkg, n_chan):
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=n_chan, n_slots=16, samples_per_epoch=26000, seed=100 + n_chan)
+    _compare(pkg, p, 26000)
+
+
+def test_full_epoch_size_bit_exact(pkg):
+    """Reference geometry: 260000 samples per epoch, 12 channels, several epochs."""
+    p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=12, n_slots=16, samples_per_epoch=260000, seed=5)
+    iq, st, stats = _compare(pkg, p, 260000)
+    assert stats["chunk_samples"] == 1016 and stats["chunks_per_epoch"] == 256
+
+
+def test_page_flip_mid_epoch(pkg):
+    """ibit0 near 499 forces the symbol counter to wrap (page_next installed) inside the first epochs."""
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=16, samples_per_epoch=260000, seed=9)
+    p["ibit0"][0, :6] = [499, 498, 480, 476, 0, 250]
+    # keep later epochs consistent with the forced start (as geometry would)
+    for e in range(1, 3):
+        p["ibit0"][e, :6] = (p["ibit0"][0, :6] + 25 * e) % 500
+    _compare(pkg, p, 260000)
+
+
+def test_negative_and_tiny_doppler(pkg):
+    p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=8, n_slots=16, samples_per_epoch=52000, seed=11)
+    f = np.array([-3400.0, -1000.0, -3.0, -0.02, 0.03, 2.5, 700.0, 3499.0])
+    for e in range(5):
+        p["f_carr"][e, :8] = f + 0.01 * e * np.sign(f)
+        p["f_code"][e, :8] = 1.023e6 + p["f_carr"][e, :8] * 0.0006493506493506494
+    _compare(pkg, p, 52000)
+
+
+def test_doppler_sign_change_between_epochs(pkg):
+    p = pkg.workloads.make_synthetic(n_epochs=8, n_chan=3, n_slots=16, samples_per_epoch=52000, seed=12)
+    for j in range(3):
+        f = np.linspace(40.0, -40.0, 8) * (j + 1)
+        p["f_carr"][:, j] = f
+        p["f_code"][:, j] = 1.023e6 + f * 0.0006493506493506494
+    _compare(pkg, p, 52000)
+
+
+def test_ragged_sizes(pkg):
+    """samples_per_epoch not a multiple of the chunk, tiny epochs, odd chunk sizes."""
+    for n_samp, chunk in [(1000, 0), (2604, 0), (26000, 100), (26000, 252), (4096, 4)]:
+        p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=5, n_slots=8, samples_per_epoch=n_samp, seed=n_samp)
+        _compare(pkg, p, n_samp, chunk_samples=chunk)
+
+
+def test_channel_comes_and_goes_and_state_carry(pkg):
+    """Slots freed / re-allocated between epochs (src/channel.cpp:112-119) and a run split in two calls."""
+    from galileo_sdr_sim_amd import GAL_CH_RESTART
+
+    n_samp = 26000
+    p = pkg.workloads.make_synthetic(n_epochs=10, n_chan=6, n_slots=16, samples_per_epoch=n_samp, seed=21)
+    # slot 2 disappears at epoch 4; slot 7 appears at epoch 5 with a fresh carrier / page; slot 1 is
+    # re-allocated to another PRN at epoch 6
+    p[4:, 2] = np.zeros((), dtype=p.dtype)
+    q = pkg.workloads.make_synthetic(n_epochs=10, n_chan=1, n_slots=16, samples_per_epoch=n_samp, seed=22, prns=[33])
+    p[5:, 7] = q[5:, 0]
+    p["flags"][5, 7] = GAL_CH_RESTART
+    p["carr_phase0"][5, 7] = 0.625
+    p["page_init"][5, 7] = q["page_next"][0, 0]
+    r = pkg.workloads.make_synthetic(n_epochs=10, n_chan=1, n_slots=16, samples_per_epoch=n_samp, seed=23, prns=[41])
+    p[6:, 1] = r[6:, 0]
+    p["flags"][6, 1] = GAL_CH_RESTART
+    p["carr_phase0"][6, 1] = 0.125
+    p["page_init"][6, 1] = r["page_next"][1, 0]
+    iq_all, st_all, _ = _compare(pkg, p, n_samp)
+    # same run as two calls carrying gal_chan_state_t across the boundary
+    with pkg.SynthEngine(sample_rate=2.6e6, samples_per_epoch=n_samp, n_slots=16, device=0) as eng:
+        iq_a, st_a, _ = eng.run_host(p[:7])
+        iq_b, st_b, _ = eng.run_host(p[7:], st_a)
+    assert np.array_equal(np.concatenate([iq_a, iq_b]), iq_all)
+    assert np.array_equal(st_b["carr_phase"].view(np.uint64), st_all["carr_phase"].view(np.uint64))
+
+
+def test_more_channels_than_one_launch(pkg):
+    """> 12 active channels: channel groups, later groups accumulate onto the first."""
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=16, n_slots=16, samples_per_epoch=26000, seed=31)
+    _compare(pkg, p, 26000)
+    p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=24, n_slots=24, samples_per_epoch=25000, sample_rate=25e6,
+                                     seed=32)
+    _compare(pkg, p, 25000, rate=25e6)
+
+
+def test_invalid_batches_are_rejected(pkg):
+    p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=2, n_slots=4, samples_per_epoch=1000, seed=1)
+    with pkg.SynthEngine(samples_per_epoch=1000, n_slots=4, device=0) as eng:
+        bad = p.copy()
+        bad["flags"][0, 0] = 0  # continues without state
+        with pytest.raises(pkg.GalSynthError):
+            eng.run_host(bad)
+        bad = p.copy()
+        bad["prn"][1, 1] = 51
+        with pytest.raises(pkg.GalSynthError):
+            eng.run_host(bad)
+        bad = p.copy()
+        bad["ibit0"][0, 0] = 500
+        with pytest.raises(pkg.GalSynthError):
+            eng.run_host(bad)
