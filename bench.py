@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Galileo E1B/C IQ synthesis hot path on MI355X.
+
+One "step" = one pass of the hot path (NCO walk + per-sample synthesis, reference
+src/galileo-sdr.cpp:481-539) over one batch of synthetic input already resident in HBM:
+workload M-SYN12 of SURVEY.md §8(d) = BASELINE.json configs[1] geometry (static, 12 SVs, 120 s at
+2.6 MS/s -> 1199 epochs x 260000 samples = 311.74 M complex samples = 1.247 GB of int16 IQ).
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`;
+one process per GPU, each rank synthesises its OWN independent scenario of the same size (weak scaling,
+no data-path collective: scenarios shard embarrassingly); torch.distributed (RCCL)
+is used only for the barrier and the max-over-ranks time.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "IQ Msamples/s (×real-time @2.6MS/s), 12-SV static E1B/C, 1/2/4/8 GPU"
+
+
+def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
+    """Time the CPU restatement of the reference loop (oracle/galsyn_oracle.c, 1 thread, -O2
+    -ffp-contract=off) on a bounded prefix of the same workload.  Checker code used ONLY as the
+    reported baseline, never in the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import oracle_run
+
+    probe = 4
+    t0 = time.perf_counter()
+    oracle_run(params[:probe], n_samp, rate)
+    dt = time.perf_counter() - t0
+    n_ep = int(max(probe, min(params.shape[0], target_seconds / max(dt / probe, 1e-6))))
+    t0 = time.perf_counter()
+    oracle_run(params[:n_ep], n_samp, rate)
+    dt = time.perf_counter() - t0
+    plain = n_ep * n_samp / dt / 1e6
+    # with the reference's per-sample clock read (src/galileo-sdr.cpp:485), on a shorter prefix
+    n_ck = max(probe, n_ep // 4)
+    t0 = time.perf_counter()
+    oracle_run(params[:n_ck], n_samp, rate, clock_read=True)
+    dtc = time.perf_counter() - t0
+    with_clock = n_ck * n_samp / dtc / 1e6
+    n_act = int((params["prn"][0] > 0).sum())
+    return {
+        "value": round(plain, 3),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "first %d of %d epochs of the same workload (%d SVs, %d samples/epoch), %.1f s of CPU; "
+        "with the reference's per-sample get_nanos(): %.3f Msamples/s" % (n_ep, params.shape[0], n_act, n_samp, dt,
+                                                                          with_clock),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--epochs", type=int, default=1199, help="epochs per step (default: the 120 s scenario)")
+    ap.add_argument("--channels", type=int, default=12)
+    ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the synthesis engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from __graft_entry__ import load_pkg
+
+    pkg = load_pkg()
+    n_samp, rate, n_slots = 260000, 2.6e6, 16
+    # each rank: an independent scenario of identical size (different seed)
+    params = pkg.workloads.make_synthetic(n_epochs=args.epochs, n_chan=args.channels, n_slots=n_slots,
+                                          samples_per_epoch=n_samp, sample_rate=rate,
+                                          seed=pkg.workloads.SEED + rank)
+    eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
+                          chunk_samples=args.chunk)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.plan(params)  # inputs resident in HBM before the timed region
+    out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+
+    def step():
+        eng.execute(out.data_ptr())
+        return eng.finish()[1]
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    ms_synth = 0.0
+    ms_walk = 0.0
+    stats = None
+    for _ in range(args.steps):
+        stats = step()
+        ms_synth += stats["ms_synth"]
+        ms_walk += stats["ms_walk"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = args.epochs * n_samp
+    total_samples = samples_per_step * args.steps * world
+    value = total_samples / elapsed / 1e6
+
+    if rank == 0:
+        # integrity of what was timed: a checksum of the last output (not part of the timed region)
+        chk = int(out.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFF
+        avg_synth_ms = ms_synth / args.steps
+        achieved = 4.0 * samples_per_step / (avg_synth_ms * 1e-3) / 1e9 if avg_synth_ms > 0 else 0.0
+        line = {
+            "metric": METRIC,
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "x_realtime": round(value / 2.6, 2),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 phase NCO -> int32 accumulate -> int16 IQ",
+            "data": "synthetic",
+            "config": {
+                "workload": "M-SYN12: static-geometry 12-SV E1B/C, %d epochs x %d samples @%.1f MS/s per GPU "
+                "(BASELINE configs[1] size; one independent scenario per rank)" % (args.epochs, n_samp, rate / 1e6),
+                "channels": args.channels,
+                "chunk_samples": stats["chunk_samples"],
+                "walk_passes": stats["walk_passes"],
+                "chain_mismatch": stats["chain_mismatch"],
+                "output_checksum": "%08x" % chk,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_synth<12,false>",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "avg_kernel_ms": round(avg_synth_ms, 4),
+                "avg_walk_ms": round(ms_walk / args.steps, 4),
+                "algorithmic_bytes_per_launch": 4 * samples_per_step,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,7 +51,7 @@ struct Batch {
 // visited state strictly inside x's binade and below `cap` in magnitude (cap = 1.0 for the carrier
 // phase, 4092.0 for the code phase: no wrap can trigger inside a batch).  Conservative: may return
 // fewer steps than possible, never more.
-GAL_HD Batch nco_batch(double x, double d, int n_max, double cap)
+GAL_HD Batch nco_batch(double x, double d, int n_max, double cap, double inv_ad)
 {
     Batch b;
     b.n = 0;
@@ -82,10 +82,13 @@ GAL_HD Batch nco_batch(double x, double d, int n_max, double cap)
         return b;
     }
     if (!(t >= dk)) return b;
-    double q = t / dk;
+    // t / dk through the caller's reciprocal of |d| (one division per walk instead of one per batch):
+    // |dk - |d|| <= g/2 and n < 2^20 keep the estimate within 2^-20 of the true quotient, so it can only
+    // overshoot floor(t/dk) by one, which the exact remainder test below catches (n*dk is a multiple of
+    // g below 2^(k+1), hence exactly representable); an undershoot is merely conservative.
+    double q = t * inv_ad;
     if (q > (double)n_max) q = (double)n_max;
     int n = (int)q;
-    // division may have rounded up across an integer: n*dk is exactly representable (multiple of g, < 2^(k+1))
     if (fma_exact(-(double)n, dk, t) < 0.0) n -= 1;
     if (n <= 0) return b;
     b.n = n;
@@ -97,9 +100,9 @@ GAL_HD Batch nco_batch(double x, double d, int n_max, double cap)
 // ---------------------------------------------------------------------------------------------
 // Carrier chain: N samples with constant step d.  `emit(c, p)` receives the phase BEFORE sample
 // c*R for c = 0 .. ceil(N/R)-1; the return value is the phase after sample N-1 (what the next epoch
-// starts from).
+// starts from).  inv_ad = 1.0 / fabs(d) (any value if d == 0).
 template <class Emit>
-GAL_HD double carr_walk(double p, double d, int N, int R, Emit emit)
+GAL_HD double carr_walk(double p, double d, double inv_ad, int N, int R, Emit emit)
 {
     int i = 0;
     int next_cp = 0, c = 0;
@@ -109,7 +112,7 @@ GAL_HD double carr_walk(double p, double d, int N, int R, Emit emit)
             ++c;
             next_cp += R;
         }
-        const Batch b = nco_batch(p, d, N - i, 1.0);
+        const Batch b = nco_batch(p, d, N - i, 1.0, inv_ad);
         const int iend = i + b.n;
         while (next_cp <= iend && next_cp < N) {
             emit(c, fma_exact((double)(next_cp - i), b.inc, p));
@@ -136,7 +139,7 @@ struct CodeEnd {
 };
 
 template <class Emit>
-GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, int N, int R, Emit emit)
+GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, int R, Emit emit)
 {
     int i = 0;
     int next_cp = 0, c = 0;
@@ -155,7 +158,7 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, int N, int R, Emit em
                 flipped = 1;
             }
         }
-        const Batch b = nco_batch(x, cstep, N - i, 4092.0);
+        const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
         const int iend = i + b.n;
         while (next_cp <= iend && next_cp < N) {
             emit(c, fma_exact((double)(next_cp - i), b.inc, x), ibit, flipped);

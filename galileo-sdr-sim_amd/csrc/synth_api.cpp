@@ -18,7 +18,7 @@ extern "C" {
 void galk_launch_prep(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
-void galk_launch_walk_carr(const DevPlan *P, hipStream_t st);
+void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 int galk_launch_synth(const DevPlan *P, int nch, int accumulate, const uint8_t *act, const int *nact,
@@ -66,7 +66,7 @@ void init_tables()
 }
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
-constexpr int kDefaultPasses = 6;   // speculative carrier passes enqueued up front (3 normally suffice)
+constexpr int kDefaultPasses = 4;   // speculative carrier passes enqueued up front (3 normally suffice)
 
 }  // namespace
 
@@ -279,6 +279,11 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     if (R < 4) R = 4;
     const int nchunks = (N + R - 1) / R;
     const int tiles = (nchunks + 63) / 64;
+    // carrier-walk legs: ~8 per epoch so that (legs x channels) fills the chip
+    int Lc = (nchunks + 7) / 8;
+    if (Lc < 1) Lc = 1;
+    const int W = (nchunks + Lc - 1) / Lc;
+    const size_t LEGS = (size_t)E * W;
 
     // ---- channel groups (one synth launch each; later groups accumulate onto the first)
     const int n_groups = nact_max == 0 ? 1 : (nact_max + kKernelMaxChan - 1) / kKernelMaxChan;
@@ -318,7 +323,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4), o_pcur = take(ES * GAL_PAGE_WORDS * 4);
     const size_t o_flip = take(ES);
     const size_t o_act = take((size_t)n_groups * ES), o_nact = take((size_t)n_groups * E * 4);
-    const size_t o_pst = take(ES * 8), o_pend = take(ES * 8), o_ver = take(ES), o_dirty = take(ES);
+    const size_t o_pguess = take(ES * 8);
+    const size_t o_pst = take(LEGS * S * 8), o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ctr = take(CTR_COUNT * 4);
     const size_t total = off;
@@ -334,6 +340,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     DevPlan &P = h->P;
     P.E = E; P.S = S; P.N = N; P.R = R; P.nchunks = nchunks; P.CP1 = (int)CP1;
     P.blocks_per_epoch = (tiles + 3) / 4;
+    P.W = W; P.Lc = Lc; P.LEGS = (int)LEGS;
     P.delt = 1.0 / h->cfg.sample_rate;
     P.cs25 = kCS25;
     P.params = (const gal_chan_epoch_t *)(base + o_params);
@@ -346,6 +353,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.flip_in = (uint8_t *)(base + o_flip);
     P.act = nullptr; P.nact = nullptr;  // per group, set at launch
     h->d_act = (uint8_t *)(base + o_act); h->d_nact = (int *)(base + o_nact);
+    P.pguess = (double *)(base + o_pguess);
     P.pst = (double *)(base + o_pst); P.pend = (double *)(base + o_pend);
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
@@ -363,7 +371,11 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     HIP_TRY(hipMemset(base + o_cpx, 0, ES * CP1 * 8));
     HIP_TRY(hipMemset(base + o_cpp, 0, ES * CP1 * 8));
     HIP_TRY(hipMemset(base + o_cpi, 0, ES * CP1 * 4));
-    HIP_TRY(hipMemset(base + o_pend, 0, ES * 8));
+    HIP_TRY(hipMemset(base + o_pguess, 0, ES * 8));
+    HIP_TRY(hipMemset(base + o_pst, 0, LEGS * S * 8));
+    HIP_TRY(hipMemset(base + o_pend, 0, LEGS * S * 8));
+    HIP_TRY(hipMemset(base + o_ver, 0, LEGS * S));
+    HIP_TRY(hipMemset(base + o_dirty, 0, LEGS * S));
 
     h->nact_max = nact_max;
     memset(&h->stats, 0, sizeof(h->stats));
@@ -400,10 +412,28 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     galk_launch_prep(P, st);
     galk_launch_walk_code(P, st);
     galk_launch_carr_guess(P, st);
+    // Speculative carrier walk: a few passes are enqueued back to back (each is a no-op once the chain
+    // is verified), then the host looks at the counter once; stragglers (itinerary mismatches, low-Doppler
+    // legs) iterate from the host until every leg is verified.
+    const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
     for (int pass = 0; pass < kDefaultPasses; ++pass) {
-        galk_launch_walk_carr(P, st);
+        galk_launch_walk_carr(P, pass == 0, st);
         galk_launch_carr_scan(P, pass == 0, st);
     }
+    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    while (h->h_ctr[CTR_UNVERIFIED] != 0) {
+        if (h->h_ctr[CTR_PASSES] >= max_passes)
+            return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes (%d legs unverified)",
+                        h->h_ctr[CTR_PASSES], h->h_ctr[CTR_UNVERIFIED]);
+        for (int k = 0; k < 4; ++k) {
+            galk_launch_walk_carr(P, 0, st);
+            galk_launch_carr_scan(P, 0, st);
+        }
+        HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    h->stats.walk_passes = h->h_ctr[CTR_PASSES];
     galk_launch_pages(P, st);
     HIP_TRY(hipEventRecord(h->ev[1], st));
     int rc = enqueue_synth(h, (uint32_t *)iq_dev);
@@ -427,29 +457,6 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
     hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[2]);
 
-    // The up-front passes did not converge (an itinerary mismatch cascaded): keep iterating from the
-    // host, then redo pages + synthesis with the now exact checkpoints.
-    const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 32 + P->E;
-    bool redo = false;
-    while (h->h_ctr[CTR_UNVERIFIED] != 0) {
-        if (h->h_ctr[CTR_PASSES] >= max_passes)
-            return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes (%d chunks unverified)",
-                        h->h_ctr[CTR_PASSES], h->h_ctr[CTR_UNVERIFIED]);
-        galk_launch_walk_carr(P, st);
-        galk_launch_carr_scan(P, 0, st);
-        HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        redo = true;
-    }
-    if (redo) {
-        HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
-        galk_launch_pages(P, st);
-        int rc = enqueue_synth(h, h->last_iq);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    h->stats.walk_passes = h->h_ctr[CTR_PASSES];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;

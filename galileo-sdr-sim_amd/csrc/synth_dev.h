@@ -6,7 +6,7 @@
 
 #include "../../include/galsynth.h"
 
-enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_COUNT = 4 };
+enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_UNVER_NEXT = 3, CTR_COUNT = 4 };
 
 // Everything lives in HBM; [E][S] arrays are indexed e * S + s.
 struct DevPlan {
@@ -17,6 +17,9 @@ struct DevPlan {
     int nchunks;  // ceil(N / R)
     int CP1;      // checkpoint row stride = nchunks + 1 (last entry = end-of-epoch state)
     int blocks_per_epoch;
+    int W;        // carrier-walk legs per epoch
+    int Lc;       // chunks per leg (leg length = Lc * R samples)
+    int LEGS;     // E * W
     double delt;  // 1.0 / sample_rate, src/galileo-sdr.cpp:162
     uint32_t cs25;
 
@@ -40,11 +43,12 @@ struct DevPlan {
     const uint8_t *act;  // [E][S] slots with prn > 0, first nact[e] entries valid
     const int *nact;     // [E]
 
-    // carrier speculation
-    double *pst;        // [E][S] start phase the last walk used
-    double *pend;       // [E][S] end phase of that walk
-    uint8_t *verified;  // [E][S]
-    uint8_t *dirty;     // [E][S]
+    // carrier speculation (leg arrays are slot-major)
+    double *pguess;     // [S][E] ideal-arithmetic phase at epoch start
+    double *pst;        // [S][LEGS] start phase the last walk of the leg used
+    double *pend;       // [S][LEGS] end phase of that walk
+    uint8_t *verified;  // [S][LEGS]
+    uint8_t *dirty;     // [S][LEGS]
 
     // checkpoints, one per chunk + end state
     double *cp_x;     // [E][S][CP1]

@@ -58,10 +58,11 @@ __global__ void k_walk_code(DevPlan P)
     if (P.prn[idx] <= 0) return;
     double *cpx = P.cp_x + (size_t)idx * P.CP1;
     uint32_t *cpi = P.cp_ib + (size_t)idx * P.CP1;
-    const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], P.cstep[idx], P.N, P.R,
-                                  [&](int c, double x, int ibit, int flipped) {
-                                      cpx[c] = x;
-                                      cpi[c] = (uint32_t)ibit | ((uint32_t)flipped << 16);
+    const double c = P.cstep[idx];
+    const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], c, 1.0 / c, P.N, P.R,
+                                  [&](int k, double x, int ibit, int flipped) {
+                                      cpx[k] = x;
+                                      cpi[k] = (uint32_t)ibit | ((uint32_t)flipped << 16);
                                   });
     cpx[P.nchunks] = end.x;
     cpi[P.nchunks] = (uint32_t)end.ibit | ((uint32_t)end.flipped << 16);
@@ -71,73 +72,238 @@ __global__ void k_walk_code(DevPlan P)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Initial guesses for the carrier phase at every epoch start: ideal (unrounded-chain) arithmetic.
-__global__ void k_carr_guess(DevPlan P)
+// Carrier chain.  It runs unbroken across epochs, so it is evaluated speculatively on LEGS: leg
+// i = e*W + w of slot s covers samples [w*L, (w+1)*L) of epoch e (L = Lc*R).  Leg arrays are slot-major,
+// [s][i], so one wave can stitch a slot with coalesced loads.
+//
+// k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start.  One wave per slot: 64 epochs are
+// loaded at once (one memory round trip), then the short sequential recurrence runs out of registers.
+__global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < P.S)
-        carr_guess_slot(s, P.E, P.S, P.N, P.prn, P.flags, P.p0, P.dstep, P.state_in[s].carr_phase, P.pst,
-                        P.verified, P.dirty);
-    if (s == 0) {
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    double p = 0.0;  // wave-uniform running phase
+    const double start0 = P.state_in[s].carr_phase;
+    for (int base = 0; base < P.E; base += 64) {
+        const int e = base + lane;
+        const bool in = e < P.E;
+        const int idx = (in ? e : 0) * P.S + s;
+        const int prn = in ? P.prn[idx] : 0;
+        const uint32_t fl = P.flags[idx];
+        const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
+        const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
+        const double adv = (double)P.N * P.dstep[idx];
+        double mine = 0.0;
+        for (int k = 0; k < 64; ++k) {
+            const int prn_k = __shfl(prn, k);
+            if (prn_k > 0) {  // wave-uniform branch
+                if (__shfl((int)reset, k)) p = __shfl(p0, k);
+                if (k == lane) mine = p;
+                p = p + __shfl(adv, k);
+                p = p - (double)(long long)p;
+            }
+        }
+        if (in && prn > 0) P.pguess[(size_t)s * P.E + e] = mine;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk
         P.ctr[CTR_PASSES] = 0;
     }
 }
 
-__global__ void k_walk_carr(DevPlan P)
+// k_walk_carr: one lane per (leg, slot) walks its leg in closed form from pst and records pend and the
+// chunk checkpoints.  first != 0: derive pst from the epoch guess.
+__global__ void k_walk_carr(DevPlan P, int first)
 {
     if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.E * P.S) return;
-    if (P.prn[idx] <= 0 || !P.dirty[idx]) return;
-    double *cpp = P.cp_p + (size_t)idx * P.CP1;
-    const double pe = carr_walk(P.pst[idx], P.dstep[idx], P.N, P.R, [&](int c, double p) { cpp[c] = p; });
-    cpp[P.nchunks] = pe;
-    P.pend[idx] = pe;
-    P.dirty[idx] = 0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.LEGS * P.S) return;
+    const int s = t % P.S;
+    const int i = t / P.S;
+    const int e = i / P.W, w = i - e * P.W;
+    const int idx = e * P.S + s;
+    if (P.prn[idx] <= 0) return;
+    const size_t li = (size_t)s * P.LEGS + i;
+    const double d = P.dstep[idx];
+    const int L = P.Lc * P.R;
+    double p;
+    if (first) {
+        const double x = P.pguess[(size_t)s * P.E + e] + (double)(w * L) * d;
+        p = x - (double)(long long)x;
+        P.pst[li] = p;
+        P.verified[li] = 0;
+    } else {
+        if (!P.dirty[li]) return;
+        p = P.pst[li];
+    }
+    int n = P.N - w * L;
+    if (n > L) n = L;
+    double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
+    const double pe = carr_walk(p, d, 1.0 / __builtin_fabs(d), n, P.R, [&](int c, double v) { cpp[c] = v; });
+    if (w == P.W - 1) P.cp_p[(size_t)idx * P.CP1 + P.nchunks] = pe;
+    P.pend[li] = pe;
+    P.dirty[li] = 0;
 }
 
-// One lane per slot stitches the epochs (carr_scan_slot, nco_walk.h).
-__global__ void k_carr_scan(DevPlan P, int jacobi)
+// k_carr_scan: one wave per slot stitches the legs, 64 at a time.
+//   link_ok[i]  : the start leg i was walked from is BITWISE its predecessor's end (or the given phase at
+//                 a root: restart / batch start)
+//   verified[i] : every link from the segment's root up to i holds  (segmented AND scan)
+//   otherwise a new start: predecessor's end, shifted by the predecessor's own start correction
+//   D[i-1] = sum of the gaps G[j] = pend[j-1] - pst[j] since the root (segmented SUM scan; the gaps
+//   are tiny exact multiples of the phase grid, so the order of summation is irrelevant).  Rounded-add
+//   chains commute with shifts that are multiples of 2^-52 while the itinerary is unchanged, which makes
+//   the shifted start exact in all but ~1e-5 of the legs; those are caught by link_ok on the next pass.
+//   jacobi != 0 (first scan, starts came from ideal arithmetic): no shift, which puts every start on the
+//   right sub-2^-52 residue (fixed by the itinerary since the last wrap).
+__global__ __launch_bounds__(64) void k_carr_scan(DevPlan P, int jacobi)
 {
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    __shared__ int s_unver;
-    if (threadIdx.x == 0) s_unver = 0;
-    __syncthreads();
-    const int s = threadIdx.x;
-    if (s < P.S) {
-        const int unver = carr_scan_slot(s, P.E, P.S, P.prn, P.flags, P.p0, P.state_in[s].carr_phase, P.pst,
-                                         P.pend, P.verified, P.dirty, jacobi);
-        if (unver) atomicAdd(&s_unver, unver);
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double start0 = P.state_in[s].carr_phase;
+    double *pst = P.pst + (size_t)s * P.LEGS;
+    const double *pend = P.pend + (size_t)s * P.LEGS;
+    uint8_t *verified = P.verified + (size_t)s * P.LEGS;
+    uint8_t *dirty = P.dirty + (size_t)s * P.LEGS;
+
+    int unver = 0;
+    // carries from the previous batch of 64 legs
+    bool c_act = false;   // last leg active
+    bool c_ver = false;   // last leg verified
+    double c_D = 0.0;     // last leg's start correction
+    for (int base = 0; base < P.LEGS; base += 64) {
+        const int i = base + lane;
+        const bool in = i < P.LEGS;
+        const int e = in ? i / P.W : 0;
+        const int w = i - e * P.W;
+        const int idx = e * P.S + s;
+        const bool act = in && P.prn[idx] > 0;
+        const bool root = act && w == 0 && (e == 0 || (P.flags[idx] & GAL_CH_RESTART));
+        const double known = (P.flags[idx] & GAL_CH_RESTART) ? P.p0[idx] : start0;
+        const double cur = act ? pst[i] : 0.0;
+        const double pprev = (act && i > 0) ? pend[i - 1] : 0.0;
+        bool prev_act = __shfl_up((int)act, 1) != 0;
+        if (lane == 0) prev_act = c_act;
+        const bool was_dirty = act && dirty[i] != 0;
+        // segment heads: roots, idle legs, and (malformed) active legs without an active predecessor
+        const bool head = root || !act || !prev_act;
+        const bool link_ok = act && !was_dirty &&
+                             (root ? d2u(cur) == d2u(known) : (prev_act && d2u(cur) == d2u(pprev)));
+        const double G = !act ? 0.0 : (root ? known - cur : (prev_act ? pprev - cur : 0.0));
+
+        // segmented inclusive scans (Hillis-Steele over the 64 lanes)
+        int f = head ? 1 : 0;
+        int v = link_ok ? 1 : 0;
+        double D = G;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int f_up = __shfl_up(f, off);
+            const int v_up = __shfl_up(v, off);
+            const double D_up = __shfl_up(D, off);
+            if (lane >= off && !f) {
+                v &= v_up;
+                D += D_up;
+                f |= f_up;
+            }
+        }
+        // lanes whose segment began before this batch continue the carries
+        if (!f) {
+            v &= c_ver ? 1 : 0;
+            D += c_D;
+        }
+        if (jacobi) D = G;
+        const bool ver = act && v != 0;
+        // start correction of the predecessor (0 at heads: a root's start is given).  Applied on the grid
+        // the predecessor's END lives on: phase differences survive a wrap only as multiples of 2^-52
+        // (the ulp of [1,2)), and only as multiples of 2^-51 when the step is an odd multiple of 2^-53
+        // ("tie epoch": every wrap rounds a tie to even).
+        double D_prev = __shfl_up(D, 1);
+        if (lane == 0) D_prev = c_D;
+        {
+            const int ep = (i > 0 ? i - 1 : 0) / P.W;
+            const double dp = P.dstep[(in ? ep : 0) * P.S + s];
+            const double t53 = dp * 9007199254740992.0;  // * 2^53, exact
+            const bool tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
+            D_prev = tie ? (D_prev + 3.0) - 3.0 : (D_prev + 1.5) - 1.5;
+        }
+        if (act) {
+            if (ver) {
+                verified[i] = 1;
+            } else {
+                ++unver;
+                const double nstart = root ? known : (prev_act ? pprev + (jacobi ? 0.0 : D_prev) : cur);
+                if (d2u(nstart) != d2u(cur)) {
+                    pst[i] = nstart;
+                    dirty[i] = 1;
+                }
+            }
+        }
+        // carries = lane 63's values
+        c_act = __shfl((int)act, 63) != 0;
+        c_ver = __shfl((int)ver, 63) != 0;
+        c_D = __shfl(D, 63);
+        if (!c_act) c_D = 0.0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        P.ctr[CTR_UNVERIFIED] = s_unver;
-        P.ctr[CTR_PASSES] += 1;
-    }
+    // wave-reduce the unverified count
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) unver += __shfl_down(unver, off);
+    if (lane == 0 && unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], unver);
 }
 
-// Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88.
-// blockDim = (16 words, S slots)
-__global__ void k_pages(DevPlan P)
+// after every slot's scan: publish the count the next pass looks at
+__global__ void k_carr_publish(DevPlan P)
 {
-    const int w = threadIdx.x, s = threadIdx.y;
-    if (s >= P.S) return;
-    uint32_t cur = P.state_in[s].page[w];
-    for (int e = 0; e < P.E; ++e) {
-        const int idx = e * P.S + s;
-        if (P.prn[idx] <= 0) continue;
-        if (P.flags[idx] & GAL_CH_RESTART) cur = P.params[idx].page_init[w];
-        P.page_cur[(size_t)idx * GAL_PAGE_WORDS + w] = cur;
-        if (P.flip_in[idx]) cur = P.page_next[(size_t)idx * GAL_PAGE_WORDS + w];
+    if (P.ctr[CTR_UNVERIFIED] == 0) return;
+    P.ctr[CTR_UNVERIFIED] = P.ctr[CTR_UNVER_NEXT];
+    P.ctr[CTR_UNVER_NEXT] = 0;
+    P.ctr[CTR_PASSES] += 1;
+}
+
+// Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88: the page
+// changes only at a (re)allocation or when the symbol counter wrapped inside the previous epoch.
+// One wave per slot, 64 epochs per round trip; `src` encodes where the page comes from:
+//   -1: state_in,  2*e: page_next of epoch e,  2*e+1: page_init of epoch e.
+__global__ __launch_bounds__(64) void k_pages(DevPlan P)
+{
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    int cur = -1;  // wave-uniform
+    for (int base = 0; base < P.E; base += 64) {
+        const int e = base + lane;
+        const bool in = e < P.E;
+        const int idx = (in ? e : 0) * P.S + s;
+        const int prn = in ? P.prn[idx] : 0;
+        const int restart = (P.flags[idx] & GAL_CH_RESTART) ? 1 : 0;
+        const int flip = P.flip_in[idx];
+        int mine = -1;
+        for (int k = 0; k < 64; ++k) {
+            if (__shfl(prn, k) > 0) {  // wave-uniform
+                if (__shfl(restart, k)) cur = 2 * (base + k) + 1;
+                if (k == lane) mine = cur;
+                if (__shfl(flip, k)) cur = 2 * (base + k);
+            }
+        }
+        if (in && prn > 0) {
+            const uint32_t *src = mine < 0 ? P.state_in[s].page
+                                  : (mine & 1) ? P.params[(size_t)(mine >> 1) * P.S + s].page_init
+                                               : P.page_next + ((size_t)(mine >> 1) * P.S + s) * GAL_PAGE_WORDS;
+            uint32_t *dst = P.page_cur + (size_t)idx * GAL_PAGE_WORDS;
+#pragma unroll
+            for (int w = 0; w < GAL_PAGE_WORDS; ++w) dst[w] = src[w];
+        }
     }
     // end-of-batch state for the next call
-    const int last = (P.E - 1) * P.S + s;
-    P.state_out[s].page[w] = cur;
-    if (w == 0) {
-        const int prn = P.prn[last];
+    if (lane < GAL_PAGE_WORDS) {
+        const uint32_t *src = cur < 0 ? P.state_in[s].page
+                              : (cur & 1) ? P.params[(size_t)(cur >> 1) * P.S + s].page_init
+                                          : P.page_next + ((size_t)(cur >> 1) * P.S + s) * GAL_PAGE_WORDS;
+        P.state_out[s].page[lane] = src[lane];
+    }
+    if (lane == 0) {
+        const int prn = P.prn[(P.E - 1) * P.S + s];
         P.state_out[s].prn = prn > 0 ? prn : 0;
-        P.state_out[s].carr_phase = prn > 0 ? P.pend[last] : 0.0;
+        P.state_out[s].carr_phase = prn > 0 ? P.pend[(size_t)s * P.LEGS + (P.LEGS - 1)] : 0.0;
         P.state_out[s].reserved = 0;
     }
 }
@@ -334,6 +500,17 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(DevPlan P, const uint8_t *_
     }
         GAL_CH_LIST(GAL_CHECK)
 #undef GAL_CHECK
+        // ... and the carrier must enter this epoch exactly where it left the previous one (:531-532)
+        if (c == 0 && e > 0) {
+#define GAL_LINK(j)                                                                                  \
+    if (j < NCH && j < nact && !(P.flags[sidx##j] & GAL_CH_RESTART)) {                               \
+        const double p_in = P.cp_p[(size_t)sidx##j * P.CP1];                                         \
+        const double p_prev = P.cp_p[(size_t)(sidx##j - P.S) * P.CP1 + P.nchunks];                   \
+        bad += d2u(p_in) != d2u(p_prev);                                                             \
+    }
+            GAL_CH_LIST(GAL_LINK)
+#undef GAL_LINK
+        }
         if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
     }
 }
@@ -354,23 +531,24 @@ extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 
 extern "C" void galk_launch_carr_guess(const DevPlan *P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_carr_guess, dim3(1), dim3(64), 0, st, *P);
+    hipLaunchKernelGGL(k_carr_guess, dim3(P->S), dim3(64), 0, st, *P);
 }
 
-extern "C" void galk_launch_walk_carr(const DevPlan *P, hipStream_t st)
+extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st)
 {
-    const int n = P->E * P->S;
-    hipLaunchKernelGGL(k_walk_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P);
+    const int n = P->LEGS * P->S;
+    hipLaunchKernelGGL(k_walk_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P, first);
 }
 
 extern "C" void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_carr_scan, dim3(1), dim3(64), 0, st, *P, jacobi);
+    hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(64), 0, st, *P, jacobi);
+    hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
 }
 
 extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pages, dim3(1), dim3(GAL_PAGE_WORDS, P->S), 0, st, *P);
+    hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(64), 0, st, *P);
 }
 
 template <bool ACC>

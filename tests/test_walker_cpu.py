@@ -1,0 +1,175 @@
+"""csrc/nco_walk.h on the HOST (libgalwalk_host.so, g++) against brute-force stepping of the reference
+recurrences (src/galileo-sdr.cpp:491-507, 528-532).  The product runs the same header on the GPU; these
+tests pin the closed forms, including the rounding-tie and sign-change corner cases, bit for bit."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBW = os.path.join(ROOT, "galileo-sdr-sim_amd", "libgalwalk_host.so")
+DELT = 1.0 / 2600000.0
+
+
+@pytest.fixture(scope="module")
+def W(pkg):
+    if not os.path.exists(LIBW):
+        pkg.build_all(targets=("libgalwalk_host.so",))
+    lib = ctypes.CDLL(LIBW)
+    d, i, vp = ctypes.c_double, ctypes.c_int, ctypes.c_void_p
+    lib.galwalk_carr.restype = d
+    lib.galwalk_carr.argtypes = [d, d, i, i, vp, vp]
+    lib.galwalk_carr_brute.restype = d
+    lib.galwalk_carr_brute.argtypes = [d, d, i, i, vp]
+    lib.galwalk_carr_iters.restype = ctypes.c_long
+    lib.galwalk_carr_iters.argtypes = [d, d, i]
+    lib.galwalk_code.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
+    lib.galwalk_code_brute.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
+    lib.galwalk_spec_chain.restype = i
+    lib.galwalk_spec_chain.argtypes = [i, i, vp, vp, vp, vp, d, i, vp, vp, vp]
+    lib.galwalk_spec_legs.restype = i
+    lib.galwalk_spec_legs.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i]
+    return lib
+
+
+def _carr_pair(W, p, d, N, R):
+    nc = (N + R - 1) // R
+    a, b = np.zeros(nc), np.zeros(nc)
+    e1 = W.galwalk_carr(p, d, N, R, a.ctypes.data, None)
+    e2 = W.galwalk_carr_brute(p, d, N, R, b.ctypes.data)
+    return e1, e2, a, b
+
+
+def _assert_carr(W, p, d, N=260000, R=1016):
+    e1, e2, a, b = _carr_pair(W, p, d, N, R)
+    assert np.float64(e1).view(np.uint64) == np.float64(e2).view(np.uint64), (p, d, e1, e2)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (p, d)
+
+
+def test_carrier_random(W):
+    rng = np.random.default_rng(1)
+    for t in range(200):
+        f = rng.uniform(-4000, 4000) if t % 3 else rng.uniform(-30, 30)
+        p = rng.uniform(-1, 1) if t % 2 else rng.uniform(0, 1)
+        _assert_carr(W, p, f * DELT)
+
+
+def test_carrier_rounding_ties(W):
+    """Steps that are exact half-ulps of a visited binade (ties to even) and steps with very few bits."""
+    rng = np.random.default_rng(2)
+    for k in range(40, 54):  # d = odd multiple of 2^-k
+        for _ in range(6):
+            m = int(rng.integers(1, 1 << 12)) | 1
+            d = np.ldexp(float(m), -k)
+            d = d * (0.0013 / d) if False else np.ldexp(float(int(0.0013 * 2.0**k) | 1), -k)
+            for sgn in (1.0, -1.0):
+                _assert_carr(W, rng.uniform(0, 1), sgn * d, N=60000, R=500)
+                _assert_carr(W, -rng.uniform(0, 1), sgn * d, N=60000, R=500)
+
+
+def test_carrier_edge_values(W):
+    for p, d in [(0.0, 1e-3), (0.0, -1e-3), (0.999999, 1e-9), (-0.999999, -1e-9), (0.5, 2.0**-60), (0.25, -(2.0**-70)),
+                 (0.3, 0.0), (1e-300, 1e-3), (0.75, 0.49), (-0.75, -0.49), (0.1, -0.3), (2.0**-30, 2.0**-29)]:
+        _assert_carr(W, p, d, N=20000, R=64)
+
+
+def test_carrier_iteration_budget(W):
+    """Closed form must stay O(binade crossings), not O(samples): regression guard for the batching."""
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        f = rng.uniform(-3500, 3500)
+        it = W.galwalk_carr_iters(rng.uniform(0, 1), f * DELT, 260000)
+        assert it < 40 * (abs(f) * 0.1 + 2) + 200, (f, it)
+
+
+def _code_pair(W, x, ib, c, N, R):
+    nc = (N + R - 1) // R
+    out = []
+    for fn in (W.galwalk_code, W.galwalk_code_brute):
+        cx, ci = np.zeros(nc), np.zeros(nc, dtype=np.uint32)
+        xe, ie, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+        fn(x, ib, c, N, R, cx.ctypes.data, ci.ctypes.data, ctypes.byref(xe), ctypes.byref(ie), ctypes.byref(fl))
+        out.append((cx, ci, xe.value, ie.value, fl.value))
+    return out
+
+
+def test_code_random_and_flips(W):
+    rng = np.random.default_rng(4)
+    for t in range(120):
+        f = rng.uniform(-3500, 3500)
+        c = (1.023e6 + f * 0.0006493506493506494) * DELT
+        x = rng.uniform(0, 4092)
+        ib = int(rng.integers(0, 500)) if t % 4 else int(rng.integers(470, 500))
+        (ax, ai, axe, aie, afl), (bx, bi, bxe, bie, bfl) = _code_pair(W, x, ib, c, 260000, 1016)
+        assert np.array_equal(ax.view(np.uint64), bx.view(np.uint64)) and np.array_equal(ai, bi)
+        assert (np.float64(axe).view(np.uint64), aie, afl) == (np.float64(bxe).view(np.uint64), bie, bfl)
+
+
+def test_code_other_rates_and_edges(W):
+    for rate, N in [(25e6, 250000), (2.0e6, 50000), (4.092e6, 40000), (1.0e6, 30000)]:
+        c = 1.023e6 / rate
+        for x, ib in [(0.0, 0), (4091.999, 499), (4092.0, 499), (2047.5, 250), (np.nextafter(4092.0, 0), 10)]:
+            (ax, ai, axe, aie, afl), (bx, bi, bxe, bie, bfl) = _code_pair(W, x, ib, c, N, 256)
+            assert np.array_equal(ax.view(np.uint64), bx.view(np.uint64)) and np.array_equal(ai, bi)
+            assert (np.float64(axe).view(np.uint64), aie, afl) == (np.float64(bxe).view(np.uint64), bie, bfl)
+
+
+def _chain_truth(W, p, d, N):
+    ends = np.zeros(len(d))
+    for e in range(len(d)):
+        p = W.galwalk_carr_brute(p, d[e], N, N, None)
+        ends[e] = p
+    return ends
+
+
+def test_speculative_chain_sequential_spec(W):
+    """Epoch-level speculation (carr_guess_slot / carr_scan_slot) reproduces the sequential chain exactly."""
+    rng = np.random.default_rng(5)
+    E, N = 60, 26000
+    for t in range(6):
+        f0 = rng.uniform(-3000, 3000)
+        d = (f0 - 0.05 * np.arange(E)) * DELT
+        prn = np.full(E, 7, dtype=np.int32)
+        flags = np.zeros(E, dtype=np.uint32)
+        p0 = np.zeros(E)
+        flags[0] = 1
+        p0[0] = rng.uniform(0, 1)
+        if t % 2:  # a re-allocation in the middle and an idle gap
+            prn[20:23] = 0
+            flags[23] = 1
+            p0[23] = rng.uniform(0, 1)
+        pst, pend = np.zeros(E), np.zeros(E)
+        walks = ctypes.c_long()
+        r = W.galwalk_spec_chain(E, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data, 0.0, 80,
+                                 pst.ctypes.data, pend.ctypes.data, ctypes.byref(walks))
+        assert r > 0, r
+        if t % 2:
+            truth = np.concatenate([_chain_truth(W, p0[0], d[:20], N), np.zeros(3), _chain_truth(W, p0[23], d[23:], N)])
+            act = prn > 0
+            assert np.array_equal(pend[act].view(np.uint64), truth[act].view(np.uint64))
+        else:
+            assert np.array_equal(pend.view(np.uint64), _chain_truth(W, p0[0], d, N).view(np.uint64))
+
+
+def test_speculative_legs_emulation(W):
+    """Leg-level speculation as the GPU runs it (k_walk_carr / k_carr_scan): whatever the number of passes,
+    only bitwise-verified legs are accepted, so the stitched chain equals the sequential one."""
+    rng = np.random.default_rng(6)
+    E, N, Wl, L = 40, 26000, 8, 3252
+    for t in range(5):
+        f0 = rng.uniform(-3000, 3000) if t else 35.0
+        d = (f0 - 0.05 * np.arange(E)) * DELT
+        prn = np.full(E, 3, dtype=np.int32)
+        flags = np.zeros(E, dtype=np.uint32)
+        p0 = np.zeros(E)
+        flags[0] = 1
+        p0[0] = rng.uniform(0, 1)
+        pend = np.zeros(E * Wl)
+        hist = np.zeros(400, dtype=np.int32)
+        walks = ctypes.c_long()
+        r = W.galwalk_spec_legs(E, Wl, L, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data, 0.0,
+                                400, pend.ctypes.data, ctypes.byref(walks), hist.ctypes.data, 3)
+        assert r > 0
+        truth = _chain_truth(W, p0[0], d, N)
+        assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), truth.view(np.uint64))
