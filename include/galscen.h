@@ -1,0 +1,60 @@
+/*
+ * galscen.h -- C ABI of the host-side scenario front-end: RINEX navigation file + receiver position +
+ * start time  ->  per-epoch channel parameters (gal_chan_epoch_t rows) for the synthesis engine.
+ *
+ * It stands where the reference computes everything its sample loop reads, i.e. the part of
+ * galileo_task() around the loop: src/galileo-sdr.cpp:202-352 (setup), :438-479 (per-epoch range /
+ * code phase), :545-564 (30 s re-allocation), with src/rinex.cpp, src/gnss-time.cpp, src/geodesy.cpp,
+ * src/gal-sig.cpp:242-347, src/channel.cpp and src/inav-msg.cpp behind it.  Host C++, double precision,
+ * same operation order as the reference so that the doubles -- and therefore the int16 IQ -- match.
+ *
+ * Usage:  gal_scen_open() -> repeat gal_scen_next() until it returns 0 -> gal_scen_close().
+ */
+#ifndef GALSCEN_H_
+#define GALSCEN_H_
+
+#include <stdint.h>
+
+#include "galsynth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gal_scen_cfg {
+    const char *nav_file;     /* -e : RINEX 3 Galileo navigation file (src/main.cpp:220)                    */
+    const char *motion_file;  /* -u : user motion, CSV `t,x,y,z` ECEF metres at 10 Hz; NULL = static (-l)   */
+    double llh[3];            /* -l : lat [deg], lon [deg], height [m]; reference default 42.3601,-71.0589,2 */
+    int32_t have_start;       /* -t given                                                                   */
+    int32_t start[5];         /* Y, M, D, h, m                                                              */
+    double start_sec;         /* s (floored like src/main.cpp:269)                                          */
+    double duration_s;        /* -d : seconds; epochs produced = (int)(d*10+0.5) - 1 (src/galileo-sdr.cpp:438) */
+    int32_t iono_enable;      /* 0 with -I (src/main.cpp:300); 1 = the obliquity model the reference build runs */
+    int32_t n_slots;          /* channel slots per row; reference MAX_CHAN = 16                              */
+    int32_t verbose;          /* print the reference's allocation lines to stderr (src/channel.cpp:101)      */
+    int32_t reserved[4];
+} gal_scen_cfg_t;
+
+typedef struct gal_scen gal_scen_t;
+
+/* Returns GAL_OK or a negative gal_status_t; text via gal_scen_last_error(). */
+int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out);
+const char *gal_scen_last_error(void);
+/* Total epochs the scenario will produce. */
+int32_t gal_scen_total_epochs(const gal_scen_t *s);
+/* Scenario start as Galileo week / seconds (after start-time selection, src/gnss-time.cpp:101-165). */
+int gal_scen_start_time(const gal_scen_t *s, int32_t *week, double *sec);
+/* Produce up to max_epochs further rows of n_slots records into `rows`; returns the number produced
+ * (0 at the end) or a negative gal_status_t. */
+int32_t gal_scen_next(gal_scen_t *s, int32_t max_epochs, gal_chan_epoch_t *rows);
+int gal_scen_close(gal_scen_t *s);
+
+/* I/NAV page generator on its own (reference src/inav-msg.cpp:28-54): 500 symbols of the page that
+ * starts at Galileo time (week, sec) for the ephemeris record `eph_index` of `svid` in the opened file. */
+int gal_scen_inav_page(gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t week, double sec,
+                       uint32_t page_words[GAL_PAGE_WORDS]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GALSCEN_H_ */
