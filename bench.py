@@ -63,6 +63,22 @@ def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
     }
 
 
+def measured_traffic():
+    """HBM bytes per k_synth launch from the newest committed PMC summary (rocprofv3 --pmc WRITE_SIZE /
+    FETCH_SIZE passes, profiles/*_pmc_k_synth.json); None if there is none.  bench.py cannot run
+    rocprofv3 on itself, so this is the last profiled value for the same workload, not a live one."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_k_synth.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,9 +112,8 @@ def main():
     pkg = load_pkg()
     n_samp, rate, n_slots = 260000, 2.6e6, 16
     # each rank: an independent scenario of identical size (different seed)
-    params = pkg.workloads.make_synthetic(n_epochs=args.epochs, n_chan=args.channels, n_slots=n_slots,
-                                          samples_per_epoch=n_samp, sample_rate=rate,
-                                          seed=pkg.workloads.SEED + rank)
+    params = pkg.shard.rank_workload(rank, args.epochs, n_chan=args.channels, n_slots=n_slots,
+                                     samples_per_epoch=n_samp, sample_rate=rate)
     eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
                           chunk_samples=args.chunk)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -128,19 +143,15 @@ def main():
         ms_walk += stats["ms_walk"]
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     samples_per_step = args.epochs * n_samp
-    total_samples = samples_per_step * args.steps * world
+    # integrity of what was timed: a checksum of the last output (outside the timed region)
+    chk = int(out.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFF
+    elapsed, total_samples, chk = pkg.shard.reduce_report(dist, "cuda", elapsed, samples_per_step * args.steps, chk)
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
-        # integrity of what was timed: a checksum of the last output (not part of the timed region)
-        chk = int(out.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFF
         avg_synth_ms = ms_synth / args.steps
+        traffic, traffic_src = measured_traffic() if (args.epochs == 1199 and args.channels == 12) else (None, None)
         achieved = 4.0 * samples_per_step / (avg_synth_ms * 1e-3) / 1e9 if avg_synth_ms > 0 else 0.0
         line = {
             "metric": METRIC,
@@ -172,7 +183,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_kernel_ms": round(avg_synth_ms, 4),
                 "avg_walk_ms": round(ms_walk / args.steps, 4),
                 "algorithmic_bytes_per_launch": 4 * samples_per_step,

@@ -274,7 +274,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         target = (target + 63) / 64 * 64;
         if (target < 64) target = 64;
         R = (N + target - 1) / target;
-        R = (R + 3) / 4 * 4;
+        R = (R + 15) / 16 * 16;  // 64-byte store bursts stay aligned
     }
     if (R < 4) R = 4;
     const int nchunks = (N + R - 1) / R;

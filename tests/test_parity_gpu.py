@@ -33,7 +33,7 @@ def test_full_epoch_size_bit_exact(pkg):
     """Reference geometry: 260000 samples per epoch, 12 channels, several epochs."""
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=12, n_slots=16, samples_per_epoch=260000, seed=5)
     iq, st, stats = _compare(pkg, p, 260000)
-    assert stats["chunk_samples"] == 1016 and stats["chunks_per_epoch"] == 256
+    assert stats["chunk_samples"] == 1024 and stats["chunks_per_epoch"] == 254
 
 
 def test_page_flip_mid_epoch(pkg):
