@@ -34,11 +34,14 @@ GAL_HD double fma_exact(double a, double b, double c) { return __builtin_fma(a, 
 static constexpr uint64_t kSign = 0x8000000000000000ull;
 static constexpr uint64_t kExpMask = 0x7ff0000000000000ull;
 
-// One genuine carrier step, src/galileo-sdr.cpp:531-532.  |p| < 2 always, so (int) == (long).
+// One genuine carrier step, src/galileo-sdr.cpp:531-532: `p += d; p -= (long)p`.  trunc(p) equals
+// (double)(long)p for every p except p == -0.0 (trunc keeps the sign of zero), and -0.0 can only come out
+// of the addition when p and d are both -0.0, which gal_synth_plan() excludes by canonicalising a -0.0
+// start phase to +0.0 (the int16 output is the same either way; only the sign of a zero state differed).
 GAL_HD double carr_step(double p, double d)
 {
     p = p + d;
-    p = p - (double)(int)p;
+    p = p - __builtin_trunc(p);
     return p;
 }
 

@@ -21,8 +21,8 @@ void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
-int galk_launch_synth(const DevPlan *P, int nch, int accumulate, const uint8_t *act, const int *nact,
-                      uint32_t *iq, hipStream_t st);
+int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
+                      const int *nact, uint32_t *iq, hipStream_t st);
 }
 
 namespace {
@@ -80,6 +80,8 @@ struct gal_synth {
     // tables in HBM
     uint32_t *d_e1b = nullptr, *d_e1c = nullptr;
     int *d_lut = nullptr;
+    uint2 *d_win = nullptr;      // [50][130] periodic {B^C, C} windows
+    DevPlan *d_plan = nullptr;   // device copy of P (the hot kernel reads rarely used fields through it)
 
     // arena for the planned batch
     void *arena = nullptr;
@@ -169,8 +171,18 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     const size_t code_bytes = sizeof(kE1B);
     if (hipMalloc((void **)&h->d_e1b, code_bytes) != hipSuccess ||
         hipMalloc((void **)&h->d_e1c, code_bytes) != hipSuccess ||
-        hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess)
+        hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->d_win, 50 * 128 * sizeof(uint2)) != hipSuccess ||
+        hipMalloc((void **)&h->d_plan, sizeof(DevPlan)) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "table allocation failed"));
+    {
+        // bit planes D = E1B ^ E1C and C = E1C, 32 chips per word (bits 4092..4095 of the last word unused)
+        std::vector<uint2> win(50 * 128);
+        for (int prn = 0; prn < 50; ++prn)
+            for (int w = 0; w < 128; ++w) win[prn * 128 + w] = make_uint2(kE1B[prn][w] ^ kE1C[prn][w], kE1C[prn][w]);
+        if (hipMemcpy(h->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(GAL_E_DEVICE, "table upload failed"));
+    }
     int lut[512];
     for (int k = 0; k < 512; ++k) lut[k] = 2 * ((int)g_sin[k] * 65536 + (int)g_cos[k]);
     if (hipMemcpy(h->d_e1b, kE1B, code_bytes, hipMemcpyHostToDevice) != hipSuccess ||
@@ -191,6 +203,8 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->d_e1b) hipFree(h->d_e1b);
     if (h->d_e1c) hipFree(h->d_e1c);
     if (h->d_lut) hipFree(h->d_lut);
+    if (h->d_win) hipFree(h->d_win);
+    if (h->d_plan) hipFree(h->d_plan);
     if (h->h_ctr) hipHostFree(h->h_ctr);
     if (h->h_state) hipHostFree(h->h_state);
     for (auto &e : h->ev)
@@ -246,6 +260,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 return fail(GAL_E_INVAL, "epoch %d slot %d: bad phase/frequency", e, s);
             if (!(std::fabs(r.f_carr) < h->cfg.sample_rate) || !(r.f_code < h->cfg.sample_rate * 4000.0))
                 return fail(GAL_E_INVAL, "epoch %d slot %d: NCO step out of range", e, s);
+            // 16 samples must fit the 32-chip window of k_synth (28 in the code's last word)
+            if (!(r.f_code / h->cfg.sample_rate * 16.0 + 2.0 <= 28.0))
+                return fail(GAL_E_INVAL, "epoch %d slot %d: sample rate too low for the chip window (f_code/fs > 1.6)", e, s);
             if (r.flags & GAL_CH_RESTART) {
                 if (!(std::fabs(r.carr_phase0) < 1.0))
                     return fail(GAL_E_INVAL, "epoch %d slot %d: carr_phase0 must be in (-1,1)", e, s);
@@ -358,13 +375,21 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
-    P.e1b = h->d_e1b; P.e1c = h->d_e1c; P.lut = h->d_lut;
+    P.e1b = h->d_e1b; P.e1c = h->d_e1c; P.lut = h->d_lut; P.win = h->d_win;
 
-    // ---- upload (synchronous: after plan() the batch is resident in HBM)
-    HIP_TRY(hipMemcpy(base + o_params, params, ES * sizeof(gal_chan_epoch_t), hipMemcpyHostToDevice));
+    // ---- upload (synchronous: after plan() the batch is resident in HBM).  A start phase of -0.0 is
+    // canonicalised to +0.0 (see carr_step in nco_walk.h).
+    {
+        std::vector<gal_chan_epoch_t> up(params, params + ES);
+        for (auto &r : up)
+            if (r.carr_phase0 == 0.0) r.carr_phase0 = 0.0;
+        HIP_TRY(hipMemcpy(base + o_params, up.data(), ES * sizeof(gal_chan_epoch_t), hipMemcpyHostToDevice));
+    }
     std::vector<gal_chan_state_t> st(S);
     memset(st.data(), 0, sizeof(gal_chan_state_t) * S);
     if (state_in) memcpy(st.data(), state_in, sizeof(gal_chan_state_t) * S);
+    for (auto &c : st)
+        if (c.carr_phase == 0.0) c.carr_phase = 0.0;
     HIP_TRY(hipMemcpy(base + o_state_in, st.data(), sizeof(gal_chan_state_t) * S, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + o_act, act_g.data(), act_g.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(base + o_nact, nact_g.data(), nact_g.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -377,6 +402,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     HIP_TRY(hipMemset(base + o_ver, 0, LEGS * S));
     HIP_TRY(hipMemset(base + o_dirty, 0, LEGS * S));
 
+    HIP_TRY(hipMemcpy(h->d_plan, &P, sizeof(DevPlan), hipMemcpyHostToDevice));
     h->nact_max = nact_max;
     memset(&h->stats, 0, sizeof(h->stats));
     h->stats.n_epochs = E;
@@ -391,7 +417,7 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq)
 {
     const size_t ES = (size_t)h->P.E * h->P.S;
     for (int g = 0; g < h->n_groups; ++g) {
-        const int rc = galk_launch_synth(&h->P, h->group_nch[g], g > 0, h->d_act + (size_t)g * ES,
+        const int rc = galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, h->d_act + (size_t)g * ES,
                                          h->d_nact + (size_t)g * h->P.E, iq, h->stream);
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
     }

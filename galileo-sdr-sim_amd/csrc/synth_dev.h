@@ -4,6 +4,8 @@
 
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/galsynth.h"
 
 enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_UNVER_NEXT = 3, CTR_COUNT = 4 };
@@ -61,6 +63,13 @@ struct DevPlan {
     const uint32_t *e1b;  // [50][128]
     const uint32_t *e1c;  // [50][128]
     const int *lut;       // [512] 2 * (sin << 16 + cos)
+    const uint2 *win;     // [50][130] {E1B^E1C, E1C} 32-chip words of the periodically extended codes
+};
+
+// by-value geometry of the hot kernel (everything else it reaches through a device copy of DevPlan, so
+// that rarely used pointers do not occupy SGPRs inside the sample loop)
+struct SynGeom {
+    int S, N, R, nchunks, CP1, blocks_per_epoch;
 };
 
 #endif

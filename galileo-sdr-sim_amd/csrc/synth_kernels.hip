@@ -310,13 +310,23 @@ __global__ __launch_bounds__(64) void k_pages(DevPlan P)
 
 // ------------------------------------------------------------------------------------------------
 // Hot kernel.  Block = 256 threads = 4 waves = 4 tiles of 64 chunks of ONE epoch, so every per-epoch
-// constant (NCO steps, active PRNs, record index) is wave-uniform and lives in SGPRs.
-// LDS: [NCH][2][128] packed code words + 512-entry LUT.
-// Per-lane state per channel: code phase (2 VGPR), carrier phase (2), two cached 32-chip code words
-// already XORed with the data / secondary-code sign (2), and one packed word
-//     st = ibit[8:0] | use_next_page[9] | cached_word_index[23:16] (0xff = invalid).
+// constant (NCO steps, active PRNs) is wave-uniform and lives in SGPRs.
+//
+// A lane replays its chunk in GROUPS of 16 samples.  Inside a group the per-sample work of every channel
+// is BRANCH-FREE, so the 16 x NCH channel-steps form one basic block and the compiler interleaves the
+// channels' dependency chains (FP64 add/cvt latency and the LDS LUT read are hidden by ILP instead of by
+// occupancy).  What used to be rare branches is hoisted to the group boundaries:
+//   * chips: 16 samples advance the code by < 7 chips, so the group prologue builds a 32-chip window per
+//     channel from two LDS words (bit planes D = E1B^E1C and C = E1C), pre-XORed with the data/secondary
+//     signs; the window may straddle a word boundary and the code wrap (see ChanGroup).
+//   * code wrap (x >= 4092, src/galileo-sdr.cpp:491-507): `x -= ge ? 4092 : 0; ibit += ge`; the signs of
+//     the NEXT symbol are kept ready in `st`, the group epilogue refills them (and flips the page).
+// Per-lane persistent state per channel: x, p (FP64) and one packed word
+//     st = ibit[8:0] | use_next_page[9] | sg[11:10] | sg_next[13:12],  sg = (data^sec) | sec<<1.
+// LDS: [NCH][128]{D,C} code words + 512-entry LUT.
 #define SYN_BLOCK 256
-#define ST_WI_INVALID 0x00ff0000u
+#define SYN_GROUP 16
+#define WIN_WORDS 128
 
 __device__ __forceinline__ double uniform_f64(double v)
 {
@@ -326,190 +336,242 @@ __device__ __forceinline__ double uniform_f64(double v)
     return u2d(((uint64_t)hi << 32) | lo);
 }
 
-// data symbol (page bit) and secondary-code chip for symbol index `ibit`: bit0 / bit1, 1 => sign -1
-// (src/galileo-sdr.cpp:517-518)
-__device__ __forceinline__ uint32_t sym_bits(const DevPlan &P, int idx, int ibit, int use_next)
+// sign bits of symbol `ibit`: bit0 = data ^ secondary, bit1 = secondary (1 => factor -1);
+// data symbol = page bit, secondary = CS25[ibit % 25] (src/galileo-sdr.cpp:517-518)
+__device__ __forceinline__ uint32_t sym_signs(const DevPlan *Pd, int idx, int ibit, int use_next)
 {
-    const uint32_t *pg = (use_next ? P.page_next : P.page_cur) + (size_t)idx * GAL_PAGE_WORDS;
+    const uint32_t *pg = (use_next ? Pd->page_next : Pd->page_cur) + (size_t)idx * GAL_PAGE_WORDS;
     const uint32_t dbit = (pg[ibit >> 5] >> (ibit & 31)) & 1u;
-    const uint32_t sbit = (P.cs25 >> (ibit % 25)) & 1u;
-    return dbit | (sbit << 1);
+    const uint32_t sbit = (Pd->cs25 >> (ibit % 25)) & 1u;
+    return (dbit ^ sbit) | (sbit << 1);
 }
 
-// Per-channel replay state.  Kept as individually named scalars (macro-expanded below), NOT arrays:
-// hipcc turns small per-thread arrays into wide vector registers and then copies whole tuples around
-// every conditional update (measured: 242 VGPR + 162 AGPR for 12 channels vs ~10 VGPR/channel as scalars).
+// st for symbol (ibit, nx) with the signs of it and of its successor
+__device__ __forceinline__ uint32_t sym_state(const DevPlan *Pd, int idx, int ibit, int nx)
+{
+    if (ibit >= GAL_N_SYM_PAGE) {  // :497-506: next page
+        ibit = 0;
+        nx = 1;
+    }
+    int nib = ibit + 1, nnx = nx;
+    if (nib >= GAL_N_SYM_PAGE) {
+        nib = 0;
+        nnx = 1;
+    }
+    const uint32_t sg = sym_signs(Pd, idx, ibit, nx);
+    const uint32_t sgn = sym_signs(Pd, idx, nib, nnx);
+    return (uint32_t)ibit | ((uint32_t)nx << 9) | (sg << 10) | (sgn << 12);
+}
+
 struct ChanState {
     double x;     // code phase, chips (pre wrap-check)
     double p;     // carrier phase, cycles
-    uint32_t wB;  // cached 32 chips of E1-B  ^ data-symbol mask
-    uint32_t wC;  // cached 32 chips of E1-C  ^ secondary-code mask
-    uint32_t st;  // ibit | use_next<<9 | cached word index<<16
+    uint32_t st;  // packed symbol state, see above (ibit may read 500 until the group epilogue fixes it)
 };
 
-// One sample of one channel: src/galileo-sdr.cpp:491-532.  J = channel position in the launch
-// (LDS code bank, fmask bit pair).  Returns the packed contribution (ip + (qp << 16)).
+struct ChanGroup {  // live only inside one 16-sample group
+    // 32-chip windows in NATURAL bit positions (chip c at bit c & 31), already XORed with the symbol signs:
+    // bits >= (chip0 & 31) come from the word holding chip0, the bits below from the following word (word 0
+    // of the next code period -- with the NEXT symbol's signs -- when chip0 sits in the last word).
+    uint32_t wD, wC;
+    uint32_t st0;  // st at group start, to notice a wrap in the epilogue
+};
+
 template <int J>
-__device__ __forceinline__ int chan_step(ChanState &c, const double cs, const double ds, const int sidx,
-                                         uint32_t &fmask, const DevPlan &P, const uint32_t *s_code,
+__device__ __forceinline__ void group_begin(const ChanState &c, ChanGroup &g, const uint2 *s_win)
+{
+    const bool pend = c.x >= 4092.0;  // wrap pending: the first sample of the group takes it (:491-507)
+    const double xe = pend ? c.x - 4092.0 : c.x;
+    const int chip0 = ((int)(xe * 2.0)) >> 1;
+    const int w0 = chip0 >> 5;
+    const uint32_t hi = ~0u << (chip0 & 31);
+    const uint32_t sg_cur = (c.st >> (pend ? 12 : 10)) & 3u;
+    const uint32_t sg_nxt = (w0 == 127) ? ((c.st >> 12) & 3u) : sg_cur;
+    const uint2 a = s_win[J * WIN_WORDS + w0];
+    const uint2 b = s_win[J * WIN_WORDS + ((w0 + 1) & 127)];
+    const uint32_t d0 = a.x ^ (0u - (sg_cur & 1u)), d1 = b.x ^ (0u - (sg_nxt & 1u));
+    const uint32_t c0 = a.y ^ (0u - (sg_cur >> 1)), c1 = b.y ^ (0u - (sg_nxt >> 1));
+    g.wD = (d0 & hi) | (d1 & ~hi);
+    g.wC = (c0 & hi) | (c1 & ~hi);
+    g.st0 = c.st;
+}
+
+// One sample of one channel, src/galileo-sdr.cpp:491-532, branch-free.  Returns ip + (qp << 16).
+__device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs, const double ds,
                                          const int *s_lut)
 {
-    // --- symbol / page advance, :491-507 (rare: once per 4 ms of signal)
-    if (__builtin_expect(c.x >= 4092.0, 0)) {
-        int idx = sidx;
-        asm volatile("" : "+s"(idx));  // keep the address math inside the rare path
-        c.x -= 4092.0;
-        int ibit = (int)(c.st & 0x1ffu) + 1;
-        int nx = (int)((c.st >> 9) & 1u);
-        if (ibit >= GAL_N_SYM_PAGE) {
-            ibit = 0;
-            nx = 1;
-        }
-        c.st = (uint32_t)ibit | ((uint32_t)nx << 9) | ST_WI_INVALID;  // sign masks change: drop the cached words
-        fmask = (fmask & ~(3u << (2 * J))) | (sym_bits(P, idx, ibit, nx) << (2 * J));
-    }
+    // --- symbol advance, :491-507: x -= 4092 and ibit++ when x >= 4092 (subtracting +0.0 otherwise is exact)
+    const bool ge = c.x >= 4092.0;
+    c.x = c.x - (ge ? 4092.0 : 0.0);
+    c.st += ge ? 1u : 0u;
     // --- chip lookup, :512-515.  boc[2c] = -chip, boc[2c+1] = +chip (src/gal-sig.cpp:198-213)
     const int ic = (int)(c.x * 2.0);
-    const uint32_t w = (uint32_t)ic >> 6;  // 32-chip word index
-    if (__builtin_expect(w != (c.st >> 16), 0)) {
-        c.st = (c.st & 0xffffu) | (w << 16);
-        const uint32_t dm = 0u - ((fmask >> (2 * J)) & 1u);
-        const uint32_t sm = 0u - ((fmask >> (2 * J + 1)) & 1u);
-        c.wB = s_code[J * 256 + w] ^ dm;
-        c.wC = s_code[J * 256 + 128 + w] ^ sm;
-    }
     const uint32_t sh = ((uint32_t)ic >> 1) & 31u;
-    const uint32_t eb = c.wB >> sh;  // bit0: E1B chip * data symbol is -1
-    const uint32_t ec = c.wC >> sh;  // bit0: E1C chip * secondary chip is -1
-    // v = E1B*d - E1C*s in {-2,0,+2}, times the BOC half-chip sign (:517-521)
-    const uint32_t nz = (eb ^ ec) & 1u;
-    const uint32_t neg = (ec ^ (uint32_t)ic) & 1u;
+    // v = E1B*d - E1C*s in {-2,0,+2}, times the BOC half-chip sign (:517-521); signs are in the windows
+    const int nzm = __builtin_amdgcn_sbfe((int)(g.wD >> sh), 0, 1);               // -1 where v != 0
+    const int ngm = __builtin_amdgcn_sbfe((int)((g.wC >> sh) ^ (uint32_t)ic), 0, 1);  // -1 where v < 0
     // --- carrier LUT, :509-510: trunc toward zero, then two's-complement mask
     const int k = ((int)(511.0 * c.p)) & 511;
     const int t = s_lut[k];  // 2*(sin<<16 + cos)
-    const int m = 0 - (int)neg;
     // --- NCO updates, :528-532
     c.x = c.x + cs;
     c.p = carr_step(c.p, ds);
-    return ((t ^ m) - m) & (0 - (int)nz);
+    return ((t ^ ngm) - ngm) & nzm;
+}
+
+template <int J>
+__device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, const DevPlan *Pd, const uint8_t *act,
+                                          int e)
+{
+    if (__builtin_expect(c.st != g.st0, 0)) {  // the code wrapped inside this group (once per 4 ms of signal)
+        const int idx = e * Pd->S + (int)act[J];
+        c.st = sym_state(Pd, idx, (int)(c.st & 0x1ffu), (int)((c.st >> 9) & 1u));
+    }
 }
 
 #define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define GAL_MAX_NCH 12
+// acc = Q*65536 + I with |I|,|Q| < 32768  ->  little-endian int16 pair I,Q (:536-537)
+#define GAL_PACK(acc) ((((uint32_t)(acc) + 0x8000u) & 0xffff0000u) | ((uint32_t)(acc) & 0xffffu))
+#define GAL_UNPACK(w) ((int)((w) & 0xffff0000u) + (int)(short)((w) & 0xffffu))
 
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
 template <int NCH, bool ACC>
-__global__ __launch_bounds__(SYN_BLOCK) void k_synth(DevPlan P, const uint8_t *__restrict__ act_all,
+__global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
+                                                     const uint8_t *__restrict__ act_all,
                                                      const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
 {
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
-    __shared__ uint32_t s_code[NCH * 2 * 128];
+    __shared__ uint2 s_win[NCH * WIN_WORDS];
     __shared__ int s_lut[512];
 
-    const int bpe = P.blocks_per_epoch;
-    const int e = blockIdx.x / bpe;
-    const int tg = blockIdx.x - e * bpe;
+    const int e = blockIdx.x / G.blocks_per_epoch;
+    const int tg = blockIdx.x - e * G.blocks_per_epoch;
     const int tid = threadIdx.x;
     const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
-    const uint8_t *act = act_all + (size_t)e * P.S;
+    const uint8_t *act = act_all + (size_t)e * G.S;
 
-    for (int i = tid; i < 512; i += SYN_BLOCK) s_lut[i] = P.lut[i];
+    for (int i = tid; i < 512; i += SYN_BLOCK) s_lut[i] = Pd->lut[i];
     for (int j = 0; j < nact; ++j) {
-        const int prn = P.prn[e * P.S + act[j]];
-        for (int i = tid; i < 256; i += SYN_BLOCK) {
-            const uint32_t *src = (i < 128) ? (P.e1b + (prn - 1) * 128 + i) : (P.e1c + (prn - 1) * 128 + (i - 128));
-            s_code[j * 256 + i] = *src;
-        }
+        const int prn = Pd->prn[e * G.S + act[j]];
+        const uint2 *src = Pd->win + (size_t)(prn - 1) * WIN_WORDS;
+        for (int i = tid; i < WIN_WORDS; i += SYN_BLOCK) s_win[j * WIN_WORDS + i] = src[i];
     }
     __syncthreads();
 
     const int c = (tg * (SYN_BLOCK / 64) + (tid >> 6)) * 64 + (tid & 63);  // chunk index within the epoch
-    if (c >= P.nchunks) return;
-    const int n0 = c * P.R;
-    int nsteps = P.N - n0;
-    if (nsteps > P.R) nsteps = P.R;
+    if (c >= G.nchunks) return;
+    const int n0 = c * G.R;
+    int nsteps = G.N - n0;
+    if (nsteps > G.R) nsteps = G.R;
 
-    uint32_t fmask = 0;  // bit 2j: data symbol, bit 2j+1: secondary chip (1 => sign -1)
-
+    // Per-channel state as individually named scalars (macro-expanded), NOT arrays: hipcc turns small
+    // per-thread arrays into wide vector registers and copies whole tuples around every conditional update.
 #define GAL_DECL(j)                                                                         \
-    ChanState ch##j = {0.0, 0.0, 0u, 0u, ST_WI_INVALID};                                    \
+    ChanState ch##j = {0.0, 0.0, 0u};                                                       \
+    ChanGroup gr##j = {0u, 0u, 0u};                                                         \
     double cs##j = 0.0, ds##j = 0.0;                                                        \
-    int sidx##j = 0;                                                                        \
     if (j < NCH && j < nact) {                                                              \
-        const int idx = __builtin_amdgcn_readfirstlane(e * P.S + (int)act[j]);              \
-        sidx##j = idx;                                                                      \
-        const size_t cp = (size_t)idx * P.CP1 + c;                                          \
-        ch##j.x = P.cp_x[cp];                                                               \
-        ch##j.p = P.cp_p[cp];                                                               \
-        const uint32_t v = P.cp_ib[cp]; /* ibit | flipped<<16 */                            \
-        cs##j = uniform_f64(P.cstep[idx]);                                                  \
-        ds##j = uniform_f64(P.dstep[idx]);                                                  \
-        const int ibit = (int)(v & 0xffffu);                                                \
-        const int nx = (int)(v >> 16);                                                      \
-        ch##j.st = (uint32_t)ibit | ((uint32_t)nx << 9) | ST_WI_INVALID;                    \
-        fmask |= sym_bits(P, idx, ibit, nx) << (2 * j);                                     \
+        const int idx = __builtin_amdgcn_readfirstlane(e * G.S + (int)act[j]);              \
+        const size_t cp = (size_t)idx * G.CP1 + c;                                          \
+        ch##j.x = Pd->cp_x[cp];                                                             \
+        ch##j.p = Pd->cp_p[cp];                                                             \
+        const uint32_t v = Pd->cp_ib[cp]; /* ibit | flipped<<16 */                          \
+        cs##j = uniform_f64(Pd->cstep[idx]);                                                \
+        ds##j = uniform_f64(Pd->dstep[idx]);                                                \
+        ch##j.st = sym_state(Pd, idx, (int)(v & 0xffffu), (int)(v >> 16));                  \
     }
     GAL_CH_LIST(GAL_DECL)
 #undef GAL_DECL
 
-    uint32_t *out = iq + (size_t)e * P.N + n0;
+    uint32_t *out = iq + (size_t)e * G.N + n0;
     // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
     // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
     // bursts at 1.2x: tools/wrcal.hip).
-    const bool vec_ok = ((((size_t)e * P.N + n0) & 15) == 0);
+    const bool vec_ok = ((((size_t)e * G.N + n0) & 15) == 0);
 
-#define GAL_STEP(j) \
-    if (j < NCH && j < nact) acc += chan_step<j>(ch##j, cs##j, ds##j, sidx##j, fmask, P, s_code, s_lut);
-    // acc = Q*65536 + I with |I|,|Q| < 32768  ->  little-endian int16 pair I,Q (:536-537)
-#define GAL_PACK(acc) ((((uint32_t)(acc) + 0x8000u) & 0xffff0000u) | ((uint32_t)(acc) & 0xffffu))
-#define GAL_UNPACK(w) ((int)((w) & 0xffff0000u) + (int)(short)((w) & 0xffffu))
+#define GAL_BEGIN(j) if (j < NCH && j < nact) group_begin<j>(ch##j, gr##j, s_win);
+// idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 and signs 0 give a
+// zero contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
+#define GAL_STEP(j) if (j < NCH) acc += chan_step(ch##j, gr##j, cs##j, ds##j, s_lut);
+#define GAL_END(j) if (j < NCH && j < nact) group_end<j>(ch##j, gr##j, Pd, act, e);
+// The channels are replayed four at a time over the whole group (accumulating into o[]): four independent
+// dependency chains give the scheduler enough ILP to cover FP64 and LDS latency, while only four channels'
+// group temporaries are live at once (<= 128 VGPRs -> 4 waves/SIMD).  sched_barrier keeps the parts apart.
+#define GAL_PART(a, b, c, d)                         \
+    if (a < NCH) {                                   \
+        GAL_BEGIN(a) GAL_BEGIN(b) GAL_BEGIN(c) GAL_BEGIN(d) \
+        _Pragma("unroll") for (int u = 0; u < GSZ; ++u) \
+        {                                            \
+            int acc = o[u];                          \
+            GAL_STEP(a) GAL_STEP(b) GAL_STEP(c) GAL_STEP(d) \
+            /* pin the step: without this the instruction selector floats the pure-arithmetic parts of all  \
+               16 steps apart (all NCO chains first, all accumulates last) and spills hundreds of values */ \
+            asm volatile("" : "+v"(acc), "+v"(ch##a.x), "+v"(ch##a.p), "+v"(ch##b.x), "+v"(ch##b.p),        \
+                              "+v"(ch##c.x), "+v"(ch##c.p), "+v"(ch##d.x), "+v"(ch##d.p));                   \
+            o[u] = acc;                              \
+        }                                            \
+        GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)  \
+        __builtin_amdgcn_sched_barrier(0);           \
+    }
 
     int s0 = 0;
-    for (; s0 + 16 <= nsteps; s0 += 16) {
-        uint32_t o[16];
+    for (; s0 + SYN_GROUP <= nsteps; s0 += SYN_GROUP) {
+        constexpr int GSZ = SYN_GROUP;
+        int o[SYN_GROUP];
         if (ACC) {
             if (vec_ok) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < SYN_GROUP / 4; ++q) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(out + s0 + 4 * q);
-                    o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+                    o[4 * q] = GAL_UNPACK(v.x); o[4 * q + 1] = GAL_UNPACK(v.y);
+                    o[4 * q + 2] = GAL_UNPACK(v.z); o[4 * q + 3] = GAL_UNPACK(v.w);
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) o[u] = out[s0 + u];
+                for (int u = 0; u < SYN_GROUP; ++u) o[u] = GAL_UNPACK(out[s0 + u]);
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            int acc = ACC ? GAL_UNPACK(o[u]) : 0;
-            GAL_CH_LIST(GAL_STEP)
-            o[u] = GAL_PACK(acc);
-        }
-        if (vec_ok) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint4 *>(out + s0 + 4 * q) = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
         } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) out[s0 + u] = o[u];
+            for (int u = 0; u < SYN_GROUP; ++u) o[u] = 0;
+        }
+        GAL_PART(0, 1, 2, 3)
+        GAL_PART(4, 5, 6, 7)
+        GAL_PART(8, 9, 10, 11)
+        if (vec_ok) {
+#pragma unroll
+            for (int q = 0; q < SYN_GROUP / 4; ++q)
+                *reinterpret_cast<uint4 *>(out + s0 + 4 * q) =
+                    make_uint4(GAL_PACK(o[4 * q]), GAL_PACK(o[4 * q + 1]), GAL_PACK(o[4 * q + 2]), GAL_PACK(o[4 * q + 3]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < SYN_GROUP; ++u) out[s0 + u] = GAL_PACK(o[u]);
         }
     }
-    for (; s0 < nsteps; ++s0) {  // ragged tail: one sample at a time, no overrun
-        int acc = ACC ? GAL_UNPACK(out[s0]) : 0;
-        GAL_CH_LIST(GAL_STEP)
-        out[s0] = GAL_PACK(acc);
+    for (; s0 < nsteps; ++s0) {  // ragged tail: groups of one sample
+        constexpr int GSZ = 1;
+        int o[1];
+        o[0] = ACC ? GAL_UNPACK(out[s0]) : 0;
+        GAL_PART(0, 1, 2, 3)
+        GAL_PART(4, 5, 6, 7)
+        GAL_PART(8, 9, 10, 11)
+        out[s0] = GAL_PACK(o[0]);
     }
+#undef GAL_PART
+#undef GAL_BEGIN
 #undef GAL_STEP
+#undef GAL_END
 
     // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit.
     {
         int bad = 0;
 #define GAL_CHECK(j)                                                                  \
     if (j < NCH && j < nact) {                                                        \
-        const size_t cp = (size_t)sidx##j * P.CP1 + c + 1;                            \
-        const uint32_t v = P.cp_ib[cp];                                               \
-        bad += d2u(ch##j.x) != d2u(P.cp_x[cp]);                                       \
-        bad += d2u(ch##j.p) != d2u(P.cp_p[cp]);                                       \
+        const int idx = e * G.S + (int)act[j];                                        \
+        const size_t cp = (size_t)idx * G.CP1 + c + 1;                                \
+        const uint32_t v = Pd->cp_ib[cp];                                             \
+        bad += d2u(ch##j.x) != d2u(Pd->cp_x[cp]);                                     \
+        bad += d2u(ch##j.p) != d2u(Pd->cp_p[cp]);                                     \
         bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
     }
         GAL_CH_LIST(GAL_CHECK)
@@ -517,15 +579,18 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(DevPlan P, const uint8_t *_
         // ... and the carrier must enter this epoch exactly where it left the previous one (:531-532)
         if (c == 0 && e > 0) {
 #define GAL_LINK(j)                                                                                  \
-    if (j < NCH && j < nact && !(P.flags[sidx##j] & GAL_CH_RESTART)) {                               \
-        const double p_in = P.cp_p[(size_t)sidx##j * P.CP1];                                         \
-        const double p_prev = P.cp_p[(size_t)(sidx##j - P.S) * P.CP1 + P.nchunks];                   \
-        bad += d2u(p_in) != d2u(p_prev);                                                             \
+    if (j < NCH && j < nact) {                                                                       \
+        const int idx = e * G.S + (int)act[j];                                                       \
+        if (!(Pd->flags[idx] & GAL_CH_RESTART)) {                                                    \
+            const double p_in = Pd->cp_p[(size_t)idx * G.CP1];                                       \
+            const double p_prev = Pd->cp_p[(size_t)(idx - G.S) * G.CP1 + G.nchunks];                 \
+            bad += d2u(p_in) != d2u(p_prev);                                                         \
+        }                                                                                            \
     }
             GAL_CH_LIST(GAL_LINK)
 #undef GAL_LINK
         }
-        if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
+        if (bad) atomicAdd(&Pd->ctr[CTR_MISMATCH], bad);
     }
 }
 
@@ -566,20 +631,22 @@ extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
 }
 
 template <bool ACC>
-static int launch_synth_t(const DevPlan *P, int nch, const uint8_t *act, const int *nact, uint32_t *iq,
-                          hipStream_t st)
+static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact,
+                          uint32_t *iq, hipStream_t st)
 {
     const dim3 grid(P->E * P->blocks_per_epoch), block(SYN_BLOCK);
-    if (nch <= 4) hipLaunchKernelGGL((k_synth<4, ACC>), grid, block, 0, st, *P, act, nact, iq);
-    else if (nch <= 8) hipLaunchKernelGGL((k_synth<8, ACC>), grid, block, 0, st, *P, act, nact, iq);
-    else if (nch <= 12) hipLaunchKernelGGL((k_synth<12, ACC>), grid, block, 0, st, *P, act, nact, iq);
+    SynGeom G;
+    G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1; G.blocks_per_epoch = P->blocks_per_epoch;
+    if (nch <= 4) hipLaunchKernelGGL((k_synth<4, ACC>), grid, block, 0, st, Pd, G, act, nact, iq);
+    else if (nch <= 8) hipLaunchKernelGGL((k_synth<8, ACC>), grid, block, 0, st, Pd, G, act, nact, iq);
+    else if (nch <= 12) hipLaunchKernelGGL((k_synth<12, ACC>), grid, block, 0, st, Pd, G, act, nact, iq);
     else return -1;
     return 0;
 }
 
-extern "C" int galk_launch_synth(const DevPlan *P, int nch, int accumulate, const uint8_t *act, const int *nact,
-                                 uint32_t *iq, hipStream_t st)
+extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
+                                 const int *nact, uint32_t *iq, hipStream_t st)
 {
-    return accumulate ? launch_synth_t<true>(P, nch, act, nact, iq, st)
-                      : launch_synth_t<false>(P, nch, act, nact, iq, st);
+    return accumulate ? launch_synth_t<true>(P, Pd, nch, act, nact, iq, st)
+                      : launch_synth_t<false>(P, Pd, nch, act, nact, iq, st);
 }

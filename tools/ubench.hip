@@ -1,0 +1,84 @@
+// ubench -- issue cost of the VALU instructions on k_synth's critical path (gfx950), relative to v_add_u32.
+// 8 independent chains per lane, 4 waves per SIMD, every SIMD busy; prints ns per wave-instruction per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define ITER 4096
+#define CHAINS 8
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(double *out, double seed, int iters)
+{
+    double a[CHAINS];
+    int ia[CHAINS];
+#pragma unroll
+    for (int j = 0; j < CHAINS; ++j) {
+        a[j] = seed + j * 0.125 + threadIdx.x * 1e-6;
+        ia[j] = threadIdx.x + j;
+    }
+    const double c = seed * 1e-3;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < CHAINS; ++j) {
+            if (OP == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 1) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[j]) : "v"(c));
+            if (OP == 2) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[j]) : "v"(c));
+            if (OP == 3) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(ia[j]) : "v"(a[j]));
+            if (OP == 4) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(a[j]) : "v"(ia[j]));
+            if (OP == 5) asm volatile("v_cmp_le_f64 vcc, %0, %1" : : "v"(a[j]), "v"(c) : "vcc");
+            if (OP == 6) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(ia[j]) : "v"(i) : "vcc");
+            if (OP == 7) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(ia[j]) : "v"(i));
+            if (OP == 8) asm volatile("v_trunc_f64 %0, %1" : "=v"(a[j]) : "v"(a[j]));
+            if (OP == 9) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a[j]) : "v"(c));
+            if (OP == 10) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 11) asm volatile("v_fract_f64 %0, %1" : "=v"(a[j]) : "v"(a[j]));
+            if (OP == 12) asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(ia[j]) : "v"(a[j]));
+            if (OP == 13) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(a[j]) : "v"(i));
+            if (OP == 14) asm volatile("v_cmp_le_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a[j]) : "v"(c), "v"(ia[j]), "v"(i) : "vcc");
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < CHAINS; ++j) s += a[j] + ia[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int OP>
+double run(const char *name, double *d)
+{
+    const int blocks = 256 * 4;  // 4 blocks of 4 waves per CU -> 4 waves per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5, 16);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5, ITER);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double wave_instr_per_simd = (double)ITER * CHAINS * 4;  // 4 waves per SIMD
+    const double ns = ms * 1e6 / wave_instr_per_simd;
+    printf("%-16s %8.3f ms  %6.2f ns per wave-instruction per SIMD\n", name, ms, ns);
+    return ns;
+}
+
+int main()
+{
+    double *d;
+    hipMalloc(&d, 256 * 4 * 256 * sizeof(double));
+    const double ref = run<0>("v_add_u32", d);
+    run<0>("v_add_u32", d);
+    const char *names[] = {"v_add_u32", "v_add_f64", "v_mul_f64", "v_cvt_i32_f64", "v_cvt_f64_i32", "v_cmp_le_f64",
+                           "v_cndmask_b32", "v_lshrrev_b32", "v_trunc_f64", "v_fma_f64", "v_xad_u32", "v_fract_f64",
+                           "v_cvt_u32_f64", "v_lshrrev_b64", "cmp_f64+cndmask"};
+    double r[15];
+    r[1] = run<1>(names[1], d); r[2] = run<2>(names[2], d); r[3] = run<3>(names[3], d); r[4] = run<4>(names[4], d);
+    r[5] = run<5>(names[5], d); r[6] = run<6>(names[6], d); r[7] = run<7>(names[7], d); r[8] = run<8>(names[8], d);
+    r[9] = run<9>(names[9], d); r[10] = run<10>(names[10], d); r[11] = run<11>(names[11], d);
+    r[12] = run<12>(names[12], d); r[13] = run<13>(names[13], d); r[14] = run<14>(names[14], d);
+    printf("\nrelative to v_add_u32 (= 1 issue slot):\n");
+    for (int i = 1; i < 15; ++i) printf("  %-16s %.2f\n", names[i], r[i] / ref);
+    return 0;
+}
