@@ -145,7 +145,7 @@ __global__ void k_walk_carr(DevPlan P, int first)
     P.dirty[li] = 0;
 }
 
-// k_carr_scan: one wave per slot stitches the legs, 64 at a time.
+// k_carr_scan: one 256-thread block per slot stitches the legs.
 //   link_ok[i]  : the start leg i was walked from is BITWISE its predecessor's end (or the given phase at
 //                 a root: restart / batch start)
 //   verified[i] : every link from the segment's root up to i holds  (segmented AND scan)
@@ -156,99 +156,145 @@ __global__ void k_walk_carr(DevPlan P, int first)
 //   the shifted start exact in all but ~1e-5 of the legs; those are caught by link_ok on the next pass.
 //   jacobi != 0 (first scan, starts came from ideal arithmetic): no shift, which puts every start on the
 //   right sub-2^-52 residue (fixed by the itinerary since the last wrap).
-__global__ __launch_bounds__(64) void k_carr_scan(DevPlan P, int jacobi)
+// Three-phase block scan: every thread folds its K consecutive legs, the 256 partial results are scanned
+// through LDS, then every thread replays its legs with the incoming carry.
+struct ScanAgg {
+    int f;     // a segment head lies inside
+    int v;     // AND of link_ok since the last head (or since the start if f == 0)
+    double D;  // SUM of gaps since the last head
+};
+
+__device__ __forceinline__ ScanAgg scan_combine(const ScanAgg &a, const ScanAgg &b)  // a then b
+{
+    ScanAgg r;
+    r.f = a.f | b.f;
+    r.v = b.f ? b.v : (a.v & b.v);
+    r.D = b.f ? b.D : a.D + b.D;
+    return r;
+}
+
+struct LegView {
+    bool act, root, head, link_ok;
+    double cur, pprev, known, G;
+};
+
+__device__ __forceinline__ LegView leg_view(const DevPlan &P, int s, int i, const double *pst, const double *pend,
+                                            const uint8_t *dirty, double start0)
+{
+    LegView L;
+    const int e = i / P.W, w = i - e * P.W;
+    const int idx = e * P.S + s;
+    L.act = P.prn[idx] > 0;
+    const uint32_t fl = P.flags[idx];
+    L.root = L.act && w == 0 && (e == 0 || (fl & GAL_CH_RESTART));
+    L.known = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
+    bool prev_act = false;
+    if (i > 0) {
+        const int ep = (i - 1) / P.W;
+        prev_act = P.prn[ep * P.S + s] > 0;
+    }
+    L.cur = L.act ? pst[i] : 0.0;
+    L.pprev = (L.act && i > 0) ? pend[i - 1] : 0.0;
+    // segment heads: roots, idle legs, and (malformed) active legs without an active predecessor
+    L.head = L.root || !L.act || !prev_act;
+    const bool was_dirty = L.act && dirty[i] != 0;
+    L.link_ok = L.act && !was_dirty &&
+                (L.root ? d2u(L.cur) == d2u(L.known) : (prev_act && d2u(L.cur) == d2u(L.pprev)));
+    L.G = !L.act ? 0.0 : (L.root ? L.known - L.cur : (prev_act ? L.pprev - L.cur : 0.0));
+    if (!prev_act && !L.root) L.pprev = L.cur;  // malformed: keep the start
+    return L;
+}
+
+#define SCAN_THREADS 256
+__global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacobi)
 {
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
+    __shared__ int s_f[SCAN_THREADS], s_v[SCAN_THREADS];
+    __shared__ double s_D[SCAN_THREADS];
+    __shared__ int s_unver;
     const int s = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x;
+    if (t == 0) s_unver = 0;
     const double start0 = P.state_in[s].carr_phase;
     double *pst = P.pst + (size_t)s * P.LEGS;
     const double *pend = P.pend + (size_t)s * P.LEGS;
     uint8_t *verified = P.verified + (size_t)s * P.LEGS;
     uint8_t *dirty = P.dirty + (size_t)s * P.LEGS;
+    const int K = (P.LEGS + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int i0 = t * K;
+    const int i1 = i0 + K < P.LEGS ? i0 + K : P.LEGS;
 
+    // phase 1: fold my legs
+    ScanAgg mine = {0, 1, 0.0};
+    for (int i = i0; i < i1; ++i) {
+        const LegView L = leg_view(P, s, i, pst, pend, dirty, start0);
+        ScanAgg el = {L.head ? 1 : 0, L.link_ok ? 1 : 0, L.G};
+        mine = scan_combine(mine, el);
+        if (jacobi) mine.D = L.G;
+    }
+    s_f[t] = mine.f;
+    s_v[t] = mine.v;
+    s_D[t] = mine.D;
+    __syncthreads();
+    // phase 2: inclusive Hillis-Steele scan over the 256 partials
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        ScanAgg a = {0, 1, 0.0}, b = {s_f[t], s_v[t], s_D[t]};
+        const bool has = t >= off;
+        if (has) {
+            a.f = s_f[t - off];
+            a.v = s_v[t - off];
+            a.D = s_D[t - off];
+        }
+        __syncthreads();
+        if (has) {
+            const ScanAgg r = scan_combine(a, b);
+            s_f[t] = r.f;
+            s_v[t] = r.v;
+            s_D[t] = r.D;
+        }
+        __syncthreads();
+    }
+    // carry into my first leg = inclusive result of the previous thread (nothing before leg 0: it is a head)
+    ScanAgg run = {0, 0, 0.0};
+    if (t > 0) {
+        run.f = s_f[t - 1];
+        run.v = s_v[t - 1];
+        run.D = s_D[t - 1];
+    }
+    // phase 3: replay my legs with the carry
     int unver = 0;
-    // carries from the previous batch of 64 legs
-    bool c_act = false;   // last leg active
-    bool c_ver = false;   // last leg verified
-    double c_D = 0.0;     // last leg's start correction
-    for (int base = 0; base < P.LEGS; base += 64) {
-        const int i = base + lane;
-        const bool in = i < P.LEGS;
-        const int e = in ? i / P.W : 0;
-        const int w = i - e * P.W;
-        const int idx = e * P.S + s;
-        const bool act = in && P.prn[idx] > 0;
-        const bool root = act && w == 0 && (e == 0 || (P.flags[idx] & GAL_CH_RESTART));
-        const double known = (P.flags[idx] & GAL_CH_RESTART) ? P.p0[idx] : start0;
-        const double cur = act ? pst[i] : 0.0;
-        const double pprev = (act && i > 0) ? pend[i - 1] : 0.0;
-        bool prev_act = __shfl_up((int)act, 1) != 0;
-        if (lane == 0) prev_act = c_act;
-        const bool was_dirty = act && dirty[i] != 0;
-        // segment heads: roots, idle legs, and (malformed) active legs without an active predecessor
-        const bool head = root || !act || !prev_act;
-        const bool link_ok = act && !was_dirty &&
-                             (root ? d2u(cur) == d2u(known) : (prev_act && d2u(cur) == d2u(pprev)));
-        const double G = !act ? 0.0 : (root ? known - cur : (prev_act ? pprev - cur : 0.0));
-
-        // segmented inclusive scans (Hillis-Steele over the 64 lanes)
-        int f = head ? 1 : 0;
-        int v = link_ok ? 1 : 0;
-        double D = G;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int f_up = __shfl_up(f, off);
-            const int v_up = __shfl_up(v, off);
-            const double D_up = __shfl_up(D, off);
-            if (lane >= off && !f) {
-                v &= v_up;
-                D += D_up;
-                f |= f_up;
-            }
-        }
-        // lanes whose segment began before this batch continue the carries
-        if (!f) {
-            v &= c_ver ? 1 : 0;
-            D += c_D;
-        }
-        if (jacobi) D = G;
-        const bool ver = act && v != 0;
-        // start correction of the predecessor (0 at heads: a root's start is given).  Applied on the grid
-        // the predecessor's END lives on: phase differences survive a wrap only as multiples of 2^-52
-        // (the ulp of [1,2)), and only as multiples of 2^-51 when the step is an odd multiple of 2^-53
-        // ("tie epoch": every wrap rounds a tie to even).
-        double D_prev = __shfl_up(D, 1);
-        if (lane == 0) D_prev = c_D;
+    for (int i = i0; i < i1; ++i) {
+        const LegView L = leg_view(P, s, i, pst, pend, dirty, start0);
+        // start correction of the predecessor, applied on the grid its END lives on: phase differences survive
+        // a wrap only as multiples of 2^-52 (the ulp of [1,2)), and only as multiples of 2^-51 when the step is
+        // an odd multiple of 2^-53 ("tie epoch": every wrap rounds a tie to even)
+        double D_prev = L.head ? 0.0 : run.D;
         {
             const int ep = (i > 0 ? i - 1 : 0) / P.W;
-            const double dp = P.dstep[(in ? ep : 0) * P.S + s];
+            const double dp = P.dstep[ep * P.S + s];
             const double t53 = dp * 9007199254740992.0;  // * 2^53, exact
             const bool tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
             D_prev = tie ? (D_prev + 3.0) - 3.0 : (D_prev + 1.5) - 1.5;
         }
-        if (act) {
-            if (ver) {
+        ScanAgg el = {L.head ? 1 : 0, L.link_ok ? 1 : 0, L.G};
+        run = scan_combine(run, el);
+        if (jacobi) run.D = L.G;
+        if (L.act) {
+            if (run.v) {
                 verified[i] = 1;
             } else {
                 ++unver;
-                const double nstart = root ? known : (prev_act ? pprev + (jacobi ? 0.0 : D_prev) : cur);
-                if (d2u(nstart) != d2u(cur)) {
+                const double nstart = L.root ? L.known : L.pprev + (jacobi ? 0.0 : D_prev);
+                if (d2u(nstart) != d2u(L.cur)) {
                     pst[i] = nstart;
                     dirty[i] = 1;
                 }
             }
         }
-        // carries = lane 63's values
-        c_act = __shfl((int)act, 63) != 0;
-        c_ver = __shfl((int)ver, 63) != 0;
-        c_D = __shfl(D, 63);
-        if (!c_act) c_D = 0.0;
     }
-    // wave-reduce the unverified count
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) unver += __shfl_down(unver, off);
-    if (lane == 0 && unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], unver);
+    if (unver) atomicAdd(&s_unver, unver);
+    __syncthreads();
+    if (t == 0 && s_unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], s_unver);
 }
 
 // after every slot's scan: publish the count the next pass looks at
@@ -621,7 +667,7 @@ extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t s
 
 extern "C" void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(64), 0, st, *P, jacobi);
+    hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P, jacobi);
     hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
 }
 
