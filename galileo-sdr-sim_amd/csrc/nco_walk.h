@@ -56,47 +56,42 @@ struct Batch {
 // fewer steps than possible, never more.
 GAL_HD Batch nco_batch(double x, double d, int n_max, double cap, double inv_ad)
 {
-    Batch b;
-    b.n = 0;
-    b.inc = 0.0;
+    // Straight-line on purpose: on the GPU 64 lanes walk 64 different chains, so every early return
+    // would be executed by somebody; everything is computed and the verdict is a select at the end.
     const uint64_t xb = d2u(x), db = d2u(d);
     const uint64_t xa = xb & ~kSign, da = db & ~kSign;
     const int ex = (int)(xa >> 52), ed = (int)(da >> 52);
-    if (n_max <= 0) return b;
-    if (ex <= ed || ex < 54 || ex >= 0x7ff) return b;  // x not above d's binade (or grid not normal)
-    const double pk = u2d(xa & kExpMask);               // 2^k
-    const double g = u2d((uint64_t)(ex - 52) << 52);    // ulp of the binade
-    const double ad = u2d(da), ax = u2d(xa);
+    // x must sit above d's binade and on a normal grid
+    bool ok = (n_max > 0) & (ex > ed) & (ex >= 54) & (ex < 0x7ff);
+    const int exs = ok ? ex : 1023;                     // keep the arithmetic below finite when !ok
+    const double pk = u2d((uint64_t)exs << 52);         // 2^k
+    const double g = u2d((uint64_t)(exs - 52) << 52);   // ulp of the binade
+    const double ad = u2d(da), ax = ok ? u2d(xa) : 1.0;
     const double dk = (ad + pk) - pk;                   // RN_g(|d|), ties to even
     const double rem = ad - dk;                         // exact
-    const bool tie = (rem + rem == g) || (rem + rem == -g);
-    if (tie && (xa & 1ull)) return b;                   // need x/g even first: caller takes a genuine step
+    const bool tie = (rem + rem == g) | (rem + rem == -g);
+    ok &= !(tie & ((xa & 1ull) != 0));                  // tie: x/g must be even (one genuine step makes it so)
     const bool asc = ((xb ^ db) & kSign) == 0;
-    double t;
-    if (asc) {
-        double lim = pk + pk;
-        if (lim > cap) lim = cap;
-        t = (lim - g) - ax;                             // exact: multiples of g below 2^(k+1)
-    } else {
-        t = ax - (pk + g);                              // stay strictly above the binade floor
-    }
-    if (dk == 0.0) {                                    // |d| <= g/2: x is a fixed point of the rounded add
-        if (t >= 0.0) b.n = n_max;                      // (not at the binade floor, where the grid below is finer)
-        return b;
-    }
-    if (!(t >= dk)) return b;
+    double lim = pk + pk;
+    lim = lim > cap ? cap : lim;
+    // room left: up to the binade ceiling (or the wrap cap) when |x| grows, down to the floor when it shrinks
+    const double t = asc ? (lim - g) - ax : ax - (pk + g);
+    const bool fixed = dk == 0.0;                       // |d| <= g/2: x is a fixed point of the rounded add
     // t / dk through the caller's reciprocal of |d| (one division per walk instead of one per batch):
     // |dk - |d|| <= g/2 and n < 2^20 keep the estimate within 2^-20 of the true quotient, so it can only
     // overshoot floor(t/dk) by one, which the exact remainder test below catches (n*dk is a multiple of
     // g below 2^(k+1), hence exactly representable); an undershoot is merely conservative.
     double q = t * inv_ad;
-    if (q > (double)n_max) q = (double)n_max;
+    q = q > (double)n_max ? (double)n_max : q;
+    q = (ok & !fixed & (t >= dk)) ? q : 0.0;
     int n = (int)q;
-    if (fma_exact(-(double)n, dk, t) < 0.0) n -= 1;
-    if (n <= 0) return b;
+    n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
+    n = n < 0 ? 0 : n;
+    n = (ok & fixed & (t >= 0.0)) ? n_max : n;          // not at the binade floor, where the grid below is finer
+    Batch b;
     b.n = n;
     const double sdk = asc ? dk : -dk;
-    b.inc = (xb & kSign) ? -sdk : sdk;
+    b.inc = (n == 0 || fixed) ? 0.0 : ((xb & kSign) ? -sdk : sdk);
     return b;
 }
 
@@ -104,6 +99,8 @@ GAL_HD Batch nco_batch(double x, double d, int n_max, double cap, double inv_ad)
 // Carrier chain: N samples with constant step d.  `emit(c, p)` receives the phase BEFORE sample
 // c*R for c = 0 .. ceil(N/R)-1; the return value is the phase after sample N-1 (what the next epoch
 // starts from).  inv_ad = 1.0 / fabs(d) (any value if d == 0).
+// Loop shape (uniform across lanes): [checkpoint?] [closed-form batch, capped at the next checkpoint]
+// [one genuine step unless the batch ended on the checkpoint].
 template <class Emit>
 GAL_HD double carr_walk(double p, double d, double inv_ad, int N, int R, Emit emit)
 {
@@ -115,16 +112,11 @@ GAL_HD double carr_walk(double p, double d, double inv_ad, int N, int R, Emit em
             ++c;
             next_cp += R;
         }
-        const Batch b = nco_batch(p, d, N - i, 1.0, inv_ad);
-        const int iend = i + b.n;
-        while (next_cp <= iend && next_cp < N) {
-            emit(c, fma_exact((double)(next_cp - i), b.inc, p));
-            ++c;
-            next_cp += R;
-        }
-        if (b.n) p = fma_exact((double)b.n, b.inc, p);
-        i = iend;
-        if (i < N) {
+        const int stop = next_cp < N ? next_cp : N;     // never run past a checkpoint or the end
+        const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
+        p = fma_exact((double)b.n, b.inc, p);
+        i += b.n;
+        if (i < stop) {
             p = carr_step(p, d);
             ++i;
         }
@@ -153,24 +145,17 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
             ++c;
             next_cp += R;
         }
-        if (x >= 4092.0) {
-            x -= 4092.0;
-            ++ibit;
-            if (ibit >= 500) {
-                ibit = 0;
-                flipped = 1;
-            }
-        }
-        const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
-        const int iend = i + b.n;
-        while (next_cp <= iend && next_cp < N) {
-            emit(c, fma_exact((double)(next_cp - i), b.inc, x), ibit, flipped);
-            ++c;
-            next_cp += R;
-        }
-        if (b.n) x = fma_exact((double)b.n, b.inc, x);
-        i = iend;
-        if (i < N) {
+        const bool ge = x >= 4092.0;
+        x = x - (ge ? 4092.0 : 0.0);
+        ibit += ge ? 1 : 0;
+        const bool flip = ibit >= 500;
+        ibit = flip ? 0 : ibit;
+        flipped |= flip ? 1 : 0;
+        const int stop = next_cp < N ? next_cp : N;
+        const Batch b = nco_batch(x, cstep, stop - i, 4092.0, inv_c);
+        x = fma_exact((double)b.n, b.inc, x);
+        i += b.n;
+        if (i < stop) {
             x = x + cstep;
             ++i;
         }

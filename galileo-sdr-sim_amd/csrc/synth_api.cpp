@@ -297,7 +297,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const int nchunks = (N + R - 1) / R;
     const int tiles = (nchunks + 63) / 64;
     // carrier-walk legs: ~8 per epoch so that (legs x channels) fills the chip
-    int Lc = (nchunks + 7) / 8;
+    int legs = 8;
+    if (const char *env = getenv("GAL_WALK_LEGS")) legs = atoi(env) > 0 ? atoi(env) : legs;
+    int Lc = (nchunks + legs - 1) / legs;
     if (Lc < 1) Lc = 1;
     const int W = (nchunks + Lc - 1) / Lc;
     const size_t LEGS = (size_t)E * W;

@@ -76,6 +76,14 @@ __global__ void k_walk_code(DevPlan P)
 // i = e*W + w of slot s covers samples [w*L, (w+1)*L) of epoch e (L = Lc*R).  Leg arrays are slot-major,
 // [s][i], so one wave can stitch a slot with coalesced loads.
 //
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const uint64_t u = d2u(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), lane);
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+
 // k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start.  One wave per slot: 64 epochs are
 // loaded at once (one memory round trip), then the short sequential recurrence runs out of registers.
 __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
@@ -94,13 +102,14 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
         const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
         const double adv = (double)P.N * P.dstep[idx];
         double mine = 0.0;
-        for (int k = 0; k < 64; ++k) {
-            const int prn_k = __shfl(prn, k);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {  // v_readlane with a literal lane: no LDS permute on the serial path
+            const int prn_k = __builtin_amdgcn_readlane(prn, k);
             if (prn_k > 0) {  // wave-uniform branch
-                if (__shfl((int)reset, k)) p = __shfl(p0, k);
+                if (__builtin_amdgcn_readlane((int)reset, k)) p = readlane_f64(p0, k);
                 if (k == lane) mine = p;
-                p = p + __shfl(adv, k);
-                p = p - (double)(long long)p;
+                p = p + readlane_f64(adv, k);
+                p = p - __builtin_trunc(p);
             }
         }
         if (in && prn > 0) P.pguess[(size_t)s * P.E + e] = mine;
@@ -323,11 +332,12 @@ __global__ __launch_bounds__(64) void k_pages(DevPlan P)
         const int restart = (P.flags[idx] & GAL_CH_RESTART) ? 1 : 0;
         const int flip = P.flip_in[idx];
         int mine = -1;
+#pragma unroll
         for (int k = 0; k < 64; ++k) {
-            if (__shfl(prn, k) > 0) {  // wave-uniform
-                if (__shfl(restart, k)) cur = 2 * (base + k) + 1;
+            if (__builtin_amdgcn_readlane(prn, k) > 0) {  // wave-uniform
+                if (__builtin_amdgcn_readlane(restart, k)) cur = 2 * (base + k) + 1;
                 if (k == lane) mine = cur;
-                if (__shfl(flip, k)) cur = 2 * (base + k);
+                if (__builtin_amdgcn_readlane(flip, k)) cur = 2 * (base + k);
             }
         }
         if (in && prn > 0) {
