@@ -124,6 +124,52 @@ GAL_HD double carr_walk(double p, double d, double inv_ad, int N, int R, Emit em
     return p;
 }
 
+
+
+// carr_walk with wrap tracking: additionally reports the LAST wrap inside the walk -- the local sample
+// index right after the wrapping step and the residual phase there -- which is what the speculative
+// stitcher (synth_kernels.hip: k_walk_carr / k_carr_scan) uses as a leg's hand-over state: right after a
+// wrap every phase is a multiple of 2^-52, so differences between neighbouring trajectories survive all
+// later roundings (binade crossings coarsen the grid only up to 2^-53).
+struct WalkOut {
+    double p;       // phase after the last sample
+    int last_w;     // local index after the last wrapping step, -1 if the walk never wrapped
+    double last_r;  // phase at last_w
+};
+
+template <class Emit>
+GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, int cp0, Emit emit)
+{
+    // cp0: local index of the first checkpoint (checkpoints at cp0, cp0+R, ...); pass cp0 >= N for none
+    int i = 0;
+    int next_cp = cp0, c = 0;
+    WalkOut o;
+    o.last_w = -1;
+    o.last_r = 0.0;
+    while (i < N) {
+        if (next_cp == i) {
+            emit(c, p);
+            ++c;
+            next_cp += R;
+        }
+        const int stop = next_cp < N ? next_cp : N;  // never run past a checkpoint or the end
+        const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
+        p = fma_exact((double)b.n, b.inc, p);
+        i += b.n;
+        if (i < stop) {
+            const double q = p + d;
+            const double t = __builtin_trunc(q);
+            p = q - t;  // == carr_step(p, d)
+            ++i;
+            const bool wrapped = t != 0.0;
+            o.last_w = wrapped ? i : o.last_w;
+            o.last_r = wrapped ? p : o.last_r;
+        }
+    }
+    o.p = p;
+    return o;
+}
+
 // Code chain: N samples, step c > 0, wrap at 4092 checked BEFORE each sample's use
 // (src/galileo-sdr.cpp:491-507).  `emit(cidx, x, ibit, flipped)` receives the PRE-check state before
 // sample cidx*R.  Returns the pre-check state after sample N-1 through the reference parameters.

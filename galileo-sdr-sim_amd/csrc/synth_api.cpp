@@ -343,9 +343,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_flip = take(ES);
     const size_t o_act = take((size_t)n_groups * ES), o_nact = take((size_t)n_groups * E * 4);
     const size_t o_pguess = take(ES * 8);
-    const size_t o_pst = take(LEGS * S * 8), o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
+    const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmw = take(LEGS * S * 8),
+                 o_clmr = take(LEGS * S * 8);
+    const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ctr = take(CTR_COUNT * 4);
+
     const size_t total = off;
     if (total > h->arena_bytes) {
         if (h->arena) hipFree(h->arena);
@@ -373,10 +376,13 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.act = nullptr; P.nact = nullptr;  // per group, set at launch
     h->d_act = (uint8_t *)(base + o_act); h->d_nact = (int *)(base + o_nact);
     P.pguess = (double *)(base + o_pguess);
-    P.pst = (double *)(base + o_pst); P.pend = (double *)(base + o_pend);
+    P.anc_w = (long long *)(base + o_ancw); P.anc_r = (double *)(base + o_ancr);
+    P.clm_w = (long long *)(base + o_clmw); P.clm_r = (double *)(base + o_clmr);
+    P.pend = (double *)(base + o_pend);
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
+
     P.e1b = h->d_e1b; P.e1c = h->d_e1c; P.lut = h->d_lut; P.win = h->d_win;
 
     // ---- upload (synchronous: after plan() the batch is resident in HBM).  A start phase of -0.0 is
@@ -399,7 +405,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     HIP_TRY(hipMemset(base + o_cpp, 0, ES * CP1 * 8));
     HIP_TRY(hipMemset(base + o_cpi, 0, ES * CP1 * 4));
     HIP_TRY(hipMemset(base + o_pguess, 0, ES * 8));
-    HIP_TRY(hipMemset(base + o_pst, 0, LEGS * S * 8));
+    HIP_TRY(hipMemset(base + o_ancw, 0, LEGS * S * 8));
+    HIP_TRY(hipMemset(base + o_ancr, 0, LEGS * S * 8));
+    HIP_TRY(hipMemset(base + o_clmw, 0xff, LEGS * S * 8));
+    HIP_TRY(hipMemset(base + o_clmr, 0, LEGS * S * 8));
     HIP_TRY(hipMemset(base + o_pend, 0, LEGS * S * 8));
     HIP_TRY(hipMemset(base + o_ver, 0, LEGS * S));
     HIP_TRY(hipMemset(base + o_dirty, 0, LEGS * S));
@@ -454,7 +463,7 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
         if (h->h_ctr[CTR_PASSES] >= max_passes)
             return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes (%d legs unverified)",
                         h->h_ctr[CTR_PASSES], h->h_ctr[CTR_UNVERIFIED]);
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             galk_launch_walk_carr(P, 0, st);
             galk_launch_carr_scan(P, 0, st);
         }

@@ -45,12 +45,15 @@ struct DevPlan {
     const uint8_t *act;  // [E][S] slots with prn > 0, first nact[e] entries valid
     const int *nact;     // [E]
 
-    // carrier speculation (leg arrays are slot-major)
-    double *pguess;     // [S][E] ideal-arithmetic phase at epoch start
-    double *pst;        // [S][LEGS] start phase the last walk of the leg used
-    double *pend;       // [S][LEGS] end phase of that walk
-    uint8_t *verified;  // [S][LEGS]
-    uint8_t *dirty;     // [S][LEGS]
+    // carrier speculation (leg arrays are slot-major, [S][LEGS])
+    double *pguess;      // [S][E] ideal-arithmetic phase at epoch start
+    long long *anc_w;    // anchor of the leg: global sample index ...
+    double *anc_r;       // ... and the phase before that sample (a wrap residual, or the chain root)
+    long long *clm_w;    // claim: last wrap seen by the leg's last walk (-1: none)
+    double *clm_r;
+    double *pend;        // phase after the leg's last sample (that walk)
+    uint8_t *verified;
+    uint8_t *dirty;
 
     // checkpoints, one per chunk + end state
     double *cp_x;     // [E][S][CP1]

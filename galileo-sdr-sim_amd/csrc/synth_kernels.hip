@@ -120,8 +120,14 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
     }
 }
 
-// k_walk_carr: one lane per (leg, slot) walks its leg in closed form from pst and records pend and the
-// chunk checkpoints.  first != 0: derive pst from the epoch guess.
+// k_walk_carr: one lane per (leg, slot).  A leg is walked from its ANCHOR -- the last wrap event at or before
+// its first sample, (omega, r): "the phase before global sample omega is r", or the chain root -- first up to
+// the leg start (no output, epoch by epoch because the step changes), then through the leg itself, emitting
+// the chunk checkpoints.  It reports the last wrap it saw (its CLAIM) or none.  Anchoring at wraps is what
+// makes the speculation robust: right after a wrap every phase is a multiple of 2^-52, so the difference
+// between a guessed and the true trajectory survives every later rounding unchanged, whereas a mid-cycle
+// phase (finer grid) would be re-rounded at each binade crossing.  first != 0: pseudo anchor = the ideal
+// phase at the leg start (only its claims are used afterwards).
 __global__ void k_walk_carr(DevPlan P, int first)
 {
     if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
@@ -133,175 +139,279 @@ __global__ void k_walk_carr(DevPlan P, int first)
     const int idx = e * P.S + s;
     if (P.prn[idx] <= 0) return;
     const size_t li = (size_t)s * P.LEGS + i;
-    const double d = P.dstep[idx];
     const int L = P.Lc * P.R;
+    const long long A = (long long)e * P.N + (long long)w * L;  // global index of the leg's first sample
+    long long cur;
     double p;
     if (first) {
-        const double x = P.pguess[(size_t)s * P.E + e] + (double)(w * L) * d;
-        p = x - (double)(long long)x;
-        P.pst[li] = p;
+        const double x = P.pguess[(size_t)s * P.E + e] + (double)(w * L) * P.dstep[idx];
+        cur = A;
+        p = x - __builtin_trunc(x);
+        P.anc_w[li] = cur;
+        P.anc_r[li] = p;
         P.verified[li] = 0;
     } else {
         if (!P.dirty[li]) return;
-        p = P.pst[li];
+        cur = P.anc_w[li];
+        p = P.anc_r[li];
+    }
+    long long lw = -1;
+    double lr = 0.0;
+    while (cur < A) {  // anchor -> leg start
+        const int ec = (int)(cur / P.N);
+        long long seg_end = (long long)(ec + 1) * P.N;
+        seg_end = seg_end > A ? A : seg_end;
+        const int n = (int)(seg_end - cur);
+        const double d = P.dstep[ec * P.S + s];
+        const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
+        if (o.last_w >= 0) {
+            lw = cur + o.last_w;
+            lr = o.last_r;
+        }
+        p = o.p;
+        cur = seg_end;
     }
     int n = P.N - w * L;
-    if (n > L) n = L;
+    n = n > L ? L : n;
+    const double d = P.dstep[idx];
     double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-    const double pe = carr_walk(p, d, 1.0 / __builtin_fabs(d), n, P.R, [&](int c, double v) { cpp[c] = v; });
-    if (w == P.W - 1) P.cp_p[(size_t)idx * P.CP1 + P.nchunks] = pe;
-    P.pend[li] = pe;
+    const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { cpp[c] = v; });
+    if (o.last_w >= 0) {
+        lw = A + o.last_w;
+        lr = o.last_r;
+    }
+    if (w == P.W - 1) P.cp_p[(size_t)idx * P.CP1 + P.nchunks] = o.p;
+    P.pend[li] = o.p;
+    P.clm_w[li] = lw;  // -1: no wrap between the anchor and the end of the leg
+    P.clm_r[li] = lr;
     P.dirty[li] = 0;
 }
 
-// k_carr_scan: one 256-thread block per slot stitches the legs.
-//   link_ok[i]  : the start leg i was walked from is BITWISE its predecessor's end (or the given phase at
-//                 a root: restart / batch start)
-//   verified[i] : every link from the segment's root up to i holds  (segmented AND scan)
-//   otherwise a new start: predecessor's end, shifted by the predecessor's own start correction
-//   D[i-1] = sum of the gaps G[j] = pend[j-1] - pst[j] since the root (segmented SUM scan; the gaps
-//   are tiny exact multiples of the phase grid, so the order of summation is irrelevant).  Rounded-add
-//   chains commute with shifts that are multiples of 2^-52 while the itinerary is unchanged, which makes
-//   the shifted start exact in all but ~1e-5 of the legs; those are caught by link_ok on the next pass.
-//   jacobi != 0 (first scan, starts came from ideal arithmetic): no shift, which puts every start on the
-//   right sub-2^-52 residue (fixed by the itinerary since the last wrap).
-// Three-phase block scan: every thread folds its K consecutive legs, the 256 partial results are scanned
-// through LDS, then every thread replays its legs with the incoming carry.
-struct ScanAgg {
-    int f;     // a segment head lies inside
-    int v;     // AND of link_ok since the last head (or since the start if f == 0)
-    double D;  // SUM of gaps since the last head
+// k_carr_scan: one 256-thread block per slot stitches the legs.  Sequential statement (what the three
+// block-wide sweeps below compute; walk_host.cpp::galwalk_spec_wrap runs the same statement on the host):
+//     chain state: last claim (lc_w, lc_r), its pending correction D, allok
+//     for each leg i:   root      -> (lc_w, lc_r) = (first sample, given phase), D = 0, allok = true
+//                       link_ok   =  anchor_i bitwise == (lc_w, lc_r)  and the leg was walked from it
+//                       allok    &=  link_ok ;   verified_i = allok
+//                       new anchor = (lc_w, lc_r + D)            (predicted true value of that claim)
+//                       D_leg     =  new anchor - old anchor      (0 if it is a different wrap event)
+//                       leg saw a wrap -> (lc_w, lc_r) = its claim, D = D_leg   (else the state is inherited)
+// A leg is accepted only through bitwise equality with the verified chain, so the shift heuristic (rounded-
+// add chains commute with shifts by multiples of 2^-52 while the itinerary is unchanged; 2^-51 in "tie
+// epochs" whose step is an odd multiple of 2^-53) affects the number of passes, never the result.
+struct ClaimState {
+    int kind;  // 0 nothing yet, 1 defined, 2 chain broken (idle epoch)
+    long long w;
+    double r;
 };
 
-__device__ __forceinline__ ScanAgg scan_combine(const ScanAgg &a, const ScanAgg &b)  // a then b
-{
-    ScanAgg r;
-    r.f = a.f | b.f;
-    r.v = b.f ? b.v : (a.v & b.v);
-    r.D = b.f ? b.D : a.D + b.D;
-    return r;
-}
-
-struct LegView {
-    bool act, root, head, link_ok;
-    double cur, pprev, known, G;
+struct LegRec {
+    bool act, root, dirty, hw;
+    long long A, aw, cw;
+    double ar, cr, known;
 };
 
-__device__ __forceinline__ LegView leg_view(const DevPlan &P, int s, int i, const double *pst, const double *pend,
-                                            const uint8_t *dirty, double start0)
+__device__ __forceinline__ LegRec leg_load(const DevPlan &P, int s, int i, double start0)
 {
-    LegView L;
+    LegRec L;
     const int e = i / P.W, w = i - e * P.W;
     const int idx = e * P.S + s;
+    const size_t li = (size_t)s * P.LEGS + i;
     L.act = P.prn[idx] > 0;
     const uint32_t fl = P.flags[idx];
     L.root = L.act && w == 0 && (e == 0 || (fl & GAL_CH_RESTART));
     L.known = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
-    bool prev_act = false;
-    if (i > 0) {
-        const int ep = (i - 1) / P.W;
-        prev_act = P.prn[ep * P.S + s] > 0;
-    }
-    L.cur = L.act ? pst[i] : 0.0;
-    L.pprev = (L.act && i > 0) ? pend[i - 1] : 0.0;
-    // segment heads: roots, idle legs, and (malformed) active legs without an active predecessor
-    L.head = L.root || !L.act || !prev_act;
-    const bool was_dirty = L.act && dirty[i] != 0;
-    L.link_ok = L.act && !was_dirty &&
-                (L.root ? d2u(L.cur) == d2u(L.known) : (prev_act && d2u(L.cur) == d2u(L.pprev)));
-    L.G = !L.act ? 0.0 : (L.root ? L.known - L.cur : (prev_act ? L.pprev - L.cur : 0.0));
-    if (!prev_act && !L.root) L.pprev = L.cur;  // malformed: keep the start
+    L.A = (long long)e * P.N + (long long)w * (P.Lc * P.R);
+    L.aw = P.anc_w[li];
+    L.ar = P.anc_r[li];
+    L.cw = P.clm_w[li];
+    L.cr = P.clm_r[li];
+    L.hw = L.act && L.cw >= 0;
+    L.dirty = L.act && P.dirty[li] != 0;
     return L;
+}
+
+// Effect of one leg on (allok, D) given the claim state `lc` in front of it.  `fv` / `fd` report that the
+// leg restarted allok / D (root, idle epoch, or an anchor that is a different wrap event than the claim),
+// which is what makes the fold of many legs associative for the block scan.
+__device__ __forceinline__ void leg_advance(const DevPlan &P, int s, int i, const LegRec &L, ClaimState &lc,
+                                            double &D, int &allok, int &fv, int &fd, bool apply, int &unver)
+{
+    if (!L.act) {
+        lc.kind = 2;
+        allok = 0;
+        D = 0.0;
+        fv = 1;
+        fd = 1;
+        return;
+    }
+    if (L.root) {
+        lc.kind = 1;
+        lc.w = L.A;
+        lc.r = L.known;
+        D = 0.0;
+        allok = 1;
+        fv = 1;
+        fd = 1;
+    }
+    const bool have = lc.kind == 1;
+    const bool link_ok = have && !L.dirty && L.aw == lc.w && d2u(L.ar) == d2u(lc.r);
+    allok &= link_ok ? 1 : 0;
+    double Du = D;
+    {  // tie epochs quantise phase differences to multiples of 2^-51 at every wrap
+        long long ea = lc.w > 0 ? (lc.w - 1) / P.N : 0;
+        ea = ea < P.E ? ea : P.E - 1;
+        const double dp = P.dstep[(int)ea * P.S + s];
+        const double t53 = dp * 9007199254740992.0;  // * 2^53, exact
+        const bool tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
+        Du = tie ? (Du + 3.0) - 3.0 : Du;
+    }
+    const long long nw = lc.w;
+    const double nr = lc.r + Du;
+    const bool same_event = have && L.aw == nw;
+    const double Dleg = same_event ? nr - L.ar : 0.0;
+    if (apply) {
+        const size_t li = (size_t)s * P.LEGS + i;
+        if (allok) {
+            P.verified[li] = 1;
+        } else {
+            ++unver;
+            if (have && (L.aw != nw || d2u(L.ar) != d2u(nr))) {
+                P.anc_w[li] = nw;
+                P.anc_r[li] = nr;
+                P.dirty[li] = 1;
+            }
+        }
+    }
+    if (L.hw) {
+        lc.w = L.cw;
+        lc.r = L.cr;
+        // D_out = (lc.r_in - anchor) + D_in for the same event (a sum: associative), else restart at 0
+        D = Dleg;
+        if (!same_event) fd = 1;
+    }
 }
 
 #define SCAN_THREADS 256
 __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacobi)
 {
+    (void)jacobi;  // pseudo anchors never match a claim's wrap index, so the first scan resets D by itself
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    __shared__ int s_f[SCAN_THREADS], s_v[SCAN_THREADS];
+    __shared__ int s_kind[SCAN_THREADS];
+    __shared__ long long s_w[SCAN_THREADS];
+    __shared__ double s_r[SCAN_THREADS];
+    __shared__ int s_fv[SCAN_THREADS], s_v[SCAN_THREADS], s_fd[SCAN_THREADS];
     __shared__ double s_D[SCAN_THREADS];
     __shared__ int s_unver;
     const int s = blockIdx.x;
     const int t = threadIdx.x;
     if (t == 0) s_unver = 0;
     const double start0 = P.state_in[s].carr_phase;
-    double *pst = P.pst + (size_t)s * P.LEGS;
-    const double *pend = P.pend + (size_t)s * P.LEGS;
-    uint8_t *verified = P.verified + (size_t)s * P.LEGS;
-    uint8_t *dirty = P.dirty + (size_t)s * P.LEGS;
     const int K = (P.LEGS + SCAN_THREADS - 1) / SCAN_THREADS;
     const int i0 = t * K;
     const int i1 = i0 + K < P.LEGS ? i0 + K : P.LEGS;
 
-    // phase 1: fold my legs
-    ScanAgg mine = {0, 1, 0.0};
+    // ---- sweep 1: where does the claim chain stand after my legs (if they say anything at all)?
+    ClaimState mine = {0, 0, 0.0};
     for (int i = i0; i < i1; ++i) {
-        const LegView L = leg_view(P, s, i, pst, pend, dirty, start0);
-        ScanAgg el = {L.head ? 1 : 0, L.link_ok ? 1 : 0, L.G};
-        mine = scan_combine(mine, el);
-        if (jacobi) mine.D = L.G;
-    }
-    s_f[t] = mine.f;
-    s_v[t] = mine.v;
-    s_D[t] = mine.D;
-    __syncthreads();
-    // phase 2: inclusive Hillis-Steele scan over the 256 partials
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-        ScanAgg a = {0, 1, 0.0}, b = {s_f[t], s_v[t], s_D[t]};
-        const bool has = t >= off;
-        if (has) {
-            a.f = s_f[t - off];
-            a.v = s_v[t - off];
-            a.D = s_D[t - off];
-        }
-        __syncthreads();
-        if (has) {
-            const ScanAgg r = scan_combine(a, b);
-            s_f[t] = r.f;
-            s_v[t] = r.v;
-            s_D[t] = r.D;
-        }
-        __syncthreads();
-    }
-    // carry into my first leg = inclusive result of the previous thread (nothing before leg 0: it is a head)
-    ScanAgg run = {0, 0, 0.0};
-    if (t > 0) {
-        run.f = s_f[t - 1];
-        run.v = s_v[t - 1];
-        run.D = s_D[t - 1];
-    }
-    // phase 3: replay my legs with the carry
-    int unver = 0;
-    for (int i = i0; i < i1; ++i) {
-        const LegView L = leg_view(P, s, i, pst, pend, dirty, start0);
-        // start correction of the predecessor, applied on the grid its END lives on: phase differences survive
-        // a wrap only as multiples of 2^-52 (the ulp of [1,2)), and only as multiples of 2^-51 when the step is
-        // an odd multiple of 2^-53 ("tie epoch": every wrap rounds a tie to even)
-        double D_prev = L.head ? 0.0 : run.D;
-        {
-            const int ep = (i > 0 ? i - 1 : 0) / P.W;
-            const double dp = P.dstep[ep * P.S + s];
-            const double t53 = dp * 9007199254740992.0;  // * 2^53, exact
-            const bool tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
-            D_prev = tie ? (D_prev + 3.0) - 3.0 : (D_prev + 1.5) - 1.5;
-        }
-        ScanAgg el = {L.head ? 1 : 0, L.link_ok ? 1 : 0, L.G};
-        run = scan_combine(run, el);
-        if (jacobi) run.D = L.G;
-        if (L.act) {
-            if (run.v) {
-                verified[i] = 1;
-            } else {
-                ++unver;
-                const double nstart = L.root ? L.known : L.pprev + (jacobi ? 0.0 : D_prev);
-                if (d2u(nstart) != d2u(L.cur)) {
-                    pst[i] = nstart;
-                    dirty[i] = 1;
-                }
+        const LegRec L = leg_load(P, s, i, start0);
+        if (!L.act) {
+            mine.kind = 2;
+        } else {
+            if (L.root) {
+                mine.kind = 1;
+                mine.w = L.A;
+                mine.r = L.known;
+            }
+            if (L.hw) {
+                mine.kind = 1;
+                mine.w = L.cw;
+                mine.r = L.cr;
             }
         }
     }
-    if (unver) atomicAdd(&s_unver, unver);
+    s_kind[t] = mine.kind;
+    s_w[t] = mine.w;
+    s_r[t] = mine.r;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // inclusive "last one that speaks" scan
+        int k2 = 0;
+        long long w2 = 0;
+        double r2 = 0.0;
+        const bool take = t >= off && s_kind[t] == 0;
+        if (take) {
+            k2 = s_kind[t - off];
+            w2 = s_w[t - off];
+            r2 = s_r[t - off];
+        }
+        __syncthreads();
+        if (take) {
+            s_kind[t] = k2;
+            s_w[t] = w2;
+            s_r[t] = r2;
+        }
+        __syncthreads();
+    }
+    ClaimState lc0 = {0, 0, 0.0};
+    if (t > 0) {
+        lc0.kind = s_kind[t - 1];
+        lc0.w = s_w[t - 1];
+        lc0.r = s_r[t - 1];
+    }
+
+    // ---- sweep 2: fold my legs' effect on (allok, D) from neutral carries
+    {
+        ClaimState lc = lc0;
+        int allok = 1, fv = 0, fd = 0, dummy = 0;
+        double D = 0.0;
+        for (int i = i0; i < i1; ++i) {
+            const LegRec L = leg_load(P, s, i, start0);
+            leg_advance(P, s, i, L, lc, D, allok, fv, fd, false, dummy);
+        }
+        s_fv[t] = fv;
+        s_v[t] = allok;
+        s_fd[t] = fd;
+        s_D[t] = D;
+    }
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // inclusive segmented AND / SUM scan
+        int afv = 0, av = 1, afd = 0;
+        double aD = 0.0;
+        const bool has = t >= off;
+        if (has) {
+            afv = s_fv[t - off];
+            av = s_v[t - off];
+            afd = s_fd[t - off];
+            aD = s_D[t - off];
+        }
+        const int bfv = s_fv[t], bv = s_v[t], bfd = s_fd[t];
+        const double bD = s_D[t];
+        __syncthreads();
+        if (has) {
+            s_fv[t] = afv | bfv;
+            s_v[t] = bfv ? bv : (av & bv);
+            s_fd[t] = afd | bfd;
+            s_D[t] = bfd ? bD : aD + bD;
+        }
+        __syncthreads();
+    }
+
+    // ---- sweep 3: replay my legs with the true carries and apply
+    {
+        ClaimState lc = lc0;
+        int allok = 0, fv = 0, fd = 0;  // nothing is verified before the first root
+        double D = 0.0;
+        if (t > 0) {
+            allok = s_fv[t - 1] ? s_v[t - 1] : 0;
+            D = s_D[t - 1];
+        }
+        int unver = 0;
+        for (int i = i0; i < i1; ++i) {
+            const LegRec L = leg_load(P, s, i, start0);
+            leg_advance(P, s, i, L, lc, D, allok, fv, fd, true, unver);
+        }
+        if (unver) atomicAdd(&s_unver, unver);
+    }
     __syncthreads();
     if (t == 0 && s_unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], s_unver);
 }
@@ -693,10 +803,13 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     const dim3 grid(P->E * P->blocks_per_epoch), block(SYN_BLOCK);
     SynGeom G;
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1; G.blocks_per_epoch = P->blocks_per_epoch;
-    if (nch <= 4) hipLaunchKernelGGL((k_synth<4, ACC>), grid, block, 0, st, Pd, G, act, nact, iq);
-    else if (nch <= 8) hipLaunchKernelGGL((k_synth<8, ACC>), grid, block, 0, st, Pd, G, act, nact, iq);
-    else if (nch <= 12) hipLaunchKernelGGL((k_synth<12, ACC>), grid, block, 0, st, Pd, G, act, nact, iq);
-    else return -1;
+    switch (nch) {
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq); break;
+        GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
+        GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
+#undef GAL_CASE
+    default: return -1;
+    }
     return 0;
 }
 

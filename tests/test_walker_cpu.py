@@ -30,6 +30,8 @@ def W(pkg):
     lib.galwalk_spec_chain.argtypes = [i, i, vp, vp, vp, vp, d, i, vp, vp, vp]
     lib.galwalk_spec_legs.restype = i
     lib.galwalk_spec_legs.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i]
+    lib.galwalk_spec_wrap.restype = i
+    lib.galwalk_spec_wrap.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i]
     return lib
 
 
@@ -173,3 +175,34 @@ def test_speculative_legs_emulation(W):
         assert r > 0
         truth = _chain_truth(W, p0[0], d, N)
         assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), truth.view(np.uint64))
+
+
+def test_wrap_anchored_stitching_as_on_gpu(W):
+    """The scheme the GPU runs (k_walk_carr / k_carr_scan): legs anchored at the last wrap, claims stitched by
+    the sequential statement (nthreads=0) and by the block-parallel three-sweep form (nthreads=256).  Both must
+    reproduce the sequential chain exactly and converge in a handful of passes -- also for channels sweeping
+    through zero Doppler, where leg-boundary speculation needed hundreds of passes."""
+    rng = np.random.default_rng(7)
+    E, N, Wl, L = 80, 26000, 8, 3264
+    cases = []
+    for t in range(4):
+        f0 = rng.uniform(-3000, 3000)
+        cases.append((f0 - 0.05 * np.arange(E)) * DELT)
+    cases.append(np.linspace(40.0, -35.0, E) * DELT)      # zero crossing
+    cases.append(np.full(E, 0.7) * DELT)                   # practically no wraps at all
+    for d in cases:
+        d = np.ascontiguousarray(d)
+        prn = np.full(E, 3, dtype=np.int32)
+        flags = np.zeros(E, dtype=np.uint32)
+        p0 = np.zeros(E)
+        flags[0] = 1
+        p0[0] = rng.uniform(0, 1)
+        truth = _chain_truth(W, p0[0], d, N)
+        for nthreads in (0, 256):
+            pend = np.zeros(E * Wl)
+            hist = np.zeros(64, dtype=np.int32)
+            walks = ctypes.c_long()
+            r = W.galwalk_spec_wrap(E, Wl, L, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data,
+                                    0.0, 64, pend.ctypes.data, ctypes.byref(walks), hist.ctypes.data, nthreads)
+            assert 0 < r <= 10, (r, nthreads, hist[:12])
+            assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), truth.view(np.uint64))
