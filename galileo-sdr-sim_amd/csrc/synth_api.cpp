@@ -21,6 +21,7 @@ void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
+void galk_launch_state_phase(const DevPlan *P, hipStream_t st);
 int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
                       const int *nact, uint32_t *iq, hipStream_t st);
 }
@@ -75,7 +76,9 @@ struct gal_synth {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // code-chain walk + page resolution run beside the carrier passes
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
     // tables in HBM
     uint32_t *d_e1b = nullptr, *d_e1c = nullptr;
@@ -161,8 +164,13 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
     h->stream = h->own_stream;
+    if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
+    if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
+        return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     if (hipHostMalloc((void **)&h->h_ctr, CTR_COUNT * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->h_state, sizeof(gal_chan_state_t) * GAL_ENGINE_MAX_CHAN,
                       hipHostMallocDefault) != hipSuccess)
@@ -209,6 +217,9 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->h_state) hipHostFree(h->h_state);
     for (auto &e : h->ev)
         if (e) hipEventDestroy(e);
+    if (h->ev_prep) hipEventDestroy(h->ev_prep);
+    if (h->ev_aux) hipEventDestroy(h->ev_aux);
+    if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return GAL_OK;
@@ -447,7 +458,13 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), st));
     HIP_TRY(hipEventRecord(h->ev[0], st));
     galk_launch_prep(P, st);
-    galk_launch_walk_code(P, st);
+    // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the
+    // carrier chain: they run on a second stream beside the carrier passes and join before k_synth
+    HIP_TRY(hipEventRecord(h->ev_prep, st));
+    HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
+    galk_launch_walk_code(P, h->aux_stream);
+    galk_launch_pages(P, h->aux_stream);
+    HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     galk_launch_carr_guess(P, st);
     // Speculative carrier walk: a few passes are enqueued back to back (each is a no-op once the chain
     // is verified), then the host looks at the counter once; stragglers (itinerary mismatches, low-Doppler
@@ -471,7 +488,8 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
         HIP_TRY(hipStreamSynchronize(st));
     }
     h->stats.walk_passes = h->h_ctr[CTR_PASSES];
-    galk_launch_pages(P, st);
+    galk_launch_state_phase(P, st);
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
     HIP_TRY(hipEventRecord(h->ev[1], st));
     int rc = enqueue_synth(h, (uint32_t *)iq_dev);
     if (rc) return rc;

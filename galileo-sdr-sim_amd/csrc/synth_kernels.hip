@@ -469,9 +469,17 @@ __global__ __launch_bounds__(64) void k_pages(DevPlan P)
     if (lane == 0) {
         const int prn = P.prn[(P.E - 1) * P.S + s];
         P.state_out[s].prn = prn > 0 ? prn : 0;
-        P.state_out[s].carr_phase = prn > 0 ? P.pend[(size_t)s * P.LEGS + (P.LEGS - 1)] : 0.0;
         P.state_out[s].reserved = 0;
     }
+}
+
+// end-of-batch carrier phase per slot (after the carrier chain is verified)
+__global__ void k_state_phase(DevPlan P)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P.S) return;
+    const int prn = P.prn[(P.E - 1) * P.S + s];
+    P.state_out[s].carr_phase = prn > 0 ? P.pend[(size_t)s * P.LEGS + (P.LEGS - 1)] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(64) void k_pages(DevPlan P)
 //     the NEXT symbol are kept ready in `st`, the group epilogue refills them (and flips the page).
 // Per-lane persistent state per channel: x, p (FP64) and one packed word
 //     st = ibit[8:0] | use_next_page[9] | sg[11:10] | sg_next[13:12],  sg = (data^sec) | sec<<1.
-// LDS: [NCH][128]{D,C} code words + 512-entry LUT.
+// LDS: [NCH][128]{D,C} code words + 4 x 1024-entry LUT (zero / plus / zero / minus).
 #define SYN_BLOCK 256
 #define SYN_GROUP 16
 #define WIN_WORDS 128
@@ -530,9 +538,11 @@ __device__ __forceinline__ uint32_t sym_state(const DevPlan *Pd, int idx, int ib
 }
 
 struct ChanState {
-    double x;     // code phase, chips (pre wrap-check)
+    double y;     // TWICE the code phase, i.e. in BOC half chips (pre wrap-check).  Doubling is exact in binary
+                  // floating point and commutes with rounding, so y_n == 2*x_n bit for bit when the step is
+                  // doubled too; (int)y is then the reference's icode = (int)(code_phase*2) (:512) for free.
     double p;     // carrier phase, cycles
-    uint32_t st;  // packed symbol state, see above (ibit may read 500 until the group epilogue fixes it)
+    uint32_t st;  // packed symbol state, see above
 };
 
 struct ChanGroup {  // live only inside one 16-sample group
@@ -540,15 +550,15 @@ struct ChanGroup {  // live only inside one 16-sample group
     // bits >= (chip0 & 31) come from the word holding chip0, the bits below from the following word (word 0
     // of the next code period -- with the NEXT symbol's signs -- when chip0 sits in the last word).
     uint32_t wD, wC;
-    uint32_t st0;  // st at group start, to notice a wrap in the epilogue
+    double y0;  // y at group start: the code wrapped inside the group iff y ends below it
 };
 
 template <int J>
 __device__ __forceinline__ void group_begin(const ChanState &c, ChanGroup &g, const uint2 *s_win)
 {
-    const bool pend = c.x >= 4092.0;  // wrap pending: the first sample of the group takes it (:491-507)
-    const double xe = pend ? c.x - 4092.0 : c.x;
-    const int chip0 = ((int)(xe * 2.0)) >> 1;
+    const bool pend = c.y >= 8184.0;  // wrap pending: the first sample of the group takes it (:491-507)
+    const double ye = pend ? c.y - 8184.0 : c.y;
+    const int chip0 = ((int)ye) >> 1;
     const int w0 = chip0 >> 5;
     const uint32_t hi = ~0u << (chip0 & 31);
     const uint32_t sg_cur = (c.st >> (pend ? 12 : 10)) & 3u;
@@ -559,39 +569,46 @@ __device__ __forceinline__ void group_begin(const ChanState &c, ChanGroup &g, co
     const uint32_t c0 = a.y ^ (0u - (sg_cur >> 1)), c1 = b.y ^ (0u - (sg_nxt >> 1));
     g.wD = (d0 & hi) | (d1 & ~hi);
     g.wC = (c0 & hi) | (c1 & ~hi);
-    g.st0 = c.st;
+    g.y0 = c.y;
 }
 
 // One sample of one channel, src/galileo-sdr.cpp:491-532, branch-free.  Returns ip + (qp << 16).
-__device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs, const double ds,
-                                         const int *s_lut)
+// cs2 = 2 * f_code * delt.  s_lut2 points at entry k = 0 of the first of FOUR 1024-entry tables indexed by
+// k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0, -LUT[k & 511].  The two's-complement
+// mask of :509-510, the sign and the zero case of v are all folded into the LDS address.
+__device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
+                                         const int *s_lut2)
 {
-    // --- symbol advance, :491-507: x -= 4092 and ibit++ when x >= 4092 (subtracting +0.0 otherwise is exact)
-    const bool ge = c.x >= 4092.0;
-    c.x = c.x - (ge ? 4092.0 : 0.0);
-    c.st += ge ? 1u : 0u;
+    // --- symbol advance, :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact); the
+    //     symbol counter is advanced in the group epilogue
+    const bool ge = c.y >= 8184.0;
+    c.y = c.y - (ge ? 8184.0 : 0.0);
     // --- chip lookup, :512-515.  boc[2c] = -chip, boc[2c+1] = +chip (src/gal-sig.cpp:198-213)
-    const int ic = (int)(c.x * 2.0);
+    const int ic = (int)c.y;
     const uint32_t sh = ((uint32_t)ic >> 1) & 31u;
     // v = E1B*d - E1C*s in {-2,0,+2}, times the BOC half-chip sign (:517-521); signs are in the windows
-    const int nzm = __builtin_amdgcn_sbfe((int)(g.wD >> sh), 0, 1);               // -1 where v != 0
-    const int ngm = __builtin_amdgcn_sbfe((int)((g.wC >> sh) ^ (uint32_t)ic), 0, 1);  // -1 where v < 0
-    // --- carrier LUT, :509-510: trunc toward zero, then two's-complement mask
-    const int k = ((int)(511.0 * c.p)) & 511;
-    const int t = s_lut[k];  // 2*(sin<<16 + cos)
+    const uint32_t nz = __builtin_amdgcn_ubfe(g.wD, sh, 1);     // v != 0   (v_bfe_u32: shift and mask in one)
+    const uint32_t neg = ((g.wC >> sh) ^ (uint32_t)ic) & 1u;    // v < 0
+    // --- carrier LUT, :509-510: trunc toward zero (mask, sign and zero folded into the table choice)
+    int a4 = (int)(511.0 * c.p) << 2;                           // byte offset of entry k in table 0
+    // two fused shift-adds pick the table (spelled in asm: the combiner otherwise re-associates them into
+    // three shifts, two masks and a three-way add)
+    asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(nz), "v"(a4));
+    asm("v_lshl_add_u32 %0, %1, 13, %2" : "=v"(a4) : "v"(neg), "v"(a4));
+    const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_lut2) + a4);
     // --- NCO updates, :528-532
-    c.x = c.x + cs;
+    c.y = c.y + cs2;
     c.p = carr_step(c.p, ds);
-    return ((t ^ ngm) - ngm) & nzm;
+    return t;
 }
 
 template <int J>
 __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, const DevPlan *Pd, const uint8_t *act,
                                           int e)
 {
-    if (__builtin_expect(c.st != g.st0, 0)) {  // the code wrapped inside this group (once per 4 ms of signal)
+    if (__builtin_expect(c.y < g.y0, 0)) {  // the code wrapped inside this group (once per 4 ms of signal)
         const int idx = e * Pd->S + (int)act[J];
-        c.st = sym_state(Pd, idx, (int)(c.st & 0x1ffu), (int)((c.st >> 9) & 1u));
+        c.st = sym_state(Pd, idx, (int)(c.st & 0x1ffu) + 1, (int)((c.st >> 9) & 1u));
     }
 }
 
@@ -609,7 +626,8 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
 {
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
     __shared__ uint2 s_win[NCH * WIN_WORDS];
-    __shared__ int s_lut[512];
+    __shared__ int s_lut[4 * 1024];  // table q = nz | neg<<1, entry k + 512: {0, +LUT, 0, -LUT}[q][k & 511]
+    const int *s_lut2 = s_lut + 512;
 
     const int e = blockIdx.x / G.blocks_per_epoch;
     const int tg = blockIdx.x - e * G.blocks_per_epoch;
@@ -617,7 +635,10 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
     const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
     const uint8_t *act = act_all + (size_t)e * G.S;
 
-    for (int i = tid; i < 512; i += SYN_BLOCK) s_lut[i] = Pd->lut[i];
+    for (int i = tid; i < 4 * 1024; i += SYN_BLOCK) {
+        const int q = i >> 10, v = Pd->lut[i & 511];
+        s_lut[i] = (q & 1) ? ((q & 2) ? -v : v) : 0;
+    }
     for (int j = 0; j < nact; ++j) {
         const int prn = Pd->prn[e * G.S + act[j]];
         const uint2 *src = Pd->win + (size_t)(prn - 1) * WIN_WORDS;
@@ -635,15 +656,15 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
     // per-thread arrays into wide vector registers and copies whole tuples around every conditional update.
 #define GAL_DECL(j)                                                                         \
     ChanState ch##j = {0.0, 0.0, 0u};                                                       \
-    ChanGroup gr##j = {0u, 0u, 0u};                                                         \
+    ChanGroup gr##j = {0u, 0u, 0.0};                                                        \
     double cs##j = 0.0, ds##j = 0.0;                                                        \
     if (j < NCH && j < nact) {                                                              \
         const int idx = __builtin_amdgcn_readfirstlane(e * G.S + (int)act[j]);              \
         const size_t cp = (size_t)idx * G.CP1 + c;                                          \
-        ch##j.x = Pd->cp_x[cp];                                                             \
+        ch##j.y = 2.0 * Pd->cp_x[cp];                                                       \
         ch##j.p = Pd->cp_p[cp];                                                             \
         const uint32_t v = Pd->cp_ib[cp]; /* ibit | flipped<<16 */                          \
-        cs##j = uniform_f64(Pd->cstep[idx]);                                                \
+        cs##j = uniform_f64(2.0 * Pd->cstep[idx]);                                          \
         ds##j = uniform_f64(Pd->dstep[idx]);                                                \
         ch##j.st = sym_state(Pd, idx, (int)(v & 0xffffu), (int)(v >> 16));                  \
     }
@@ -659,7 +680,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
 #define GAL_BEGIN(j) if (j < NCH && j < nact) group_begin<j>(ch##j, gr##j, s_win);
 // idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 and signs 0 give a
 // zero contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
-#define GAL_STEP(j) if (j < NCH) acc += chan_step(ch##j, gr##j, cs##j, ds##j, s_lut);
+#define GAL_STEP(j) if (j < NCH) acc += chan_step(ch##j, gr##j, cs##j, ds##j, s_lut2);
 #define GAL_END(j) if (j < NCH && j < nact) group_end<j>(ch##j, gr##j, Pd, act, e);
 // The channels are replayed four at a time over the whole group (accumulating into o[]): four independent
 // dependency chains give the scheduler enough ILP to cover FP64 and LDS latency, while only four channels'
@@ -673,8 +694,8 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
             GAL_STEP(a) GAL_STEP(b) GAL_STEP(c) GAL_STEP(d) \
             /* pin the step: without this the instruction selector floats the pure-arithmetic parts of all  \
                16 steps apart (all NCO chains first, all accumulates last) and spills hundreds of values */ \
-            asm volatile("" : "+v"(acc), "+v"(ch##a.x), "+v"(ch##a.p), "+v"(ch##b.x), "+v"(ch##b.p),        \
-                              "+v"(ch##c.x), "+v"(ch##c.p), "+v"(ch##d.x), "+v"(ch##d.p));                   \
+            asm volatile("" : "+v"(acc), "+v"(ch##a.y), "+v"(ch##a.p), "+v"(ch##b.y), "+v"(ch##b.p),        \
+                              "+v"(ch##c.y), "+v"(ch##c.p), "+v"(ch##d.y), "+v"(ch##d.p));                   \
             o[u] = acc;                              \
         }                                            \
         GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)  \
@@ -736,7 +757,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
         const int idx = e * G.S + (int)act[j];                                        \
         const size_t cp = (size_t)idx * G.CP1 + c + 1;                                \
         const uint32_t v = Pd->cp_ib[cp];                                             \
-        bad += d2u(ch##j.x) != d2u(Pd->cp_x[cp]);                                     \
+        bad += d2u(ch##j.y) != d2u(2.0 * Pd->cp_x[cp]);                               \
         bad += d2u(ch##j.p) != d2u(Pd->cp_p[cp]);                                     \
         bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
     }
@@ -789,6 +810,11 @@ extern "C" void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t 
 {
     hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P, jacobi);
     hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
+}
+
+extern "C" void galk_launch_state_phase(const DevPlan *P, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_state_phase, dim3(1), dim3(64), 0, st, *P);
 }
 
 extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
