@@ -353,7 +353,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4), o_pcur = take(ES * GAL_PAGE_WORDS * 4);
     const size_t o_flip = take(ES);
     const size_t o_act = take((size_t)n_groups * ES), o_nact = take((size_t)n_groups * E * 4);
-    const size_t o_pguess = take(ES * 8);
+    const size_t o_pguess = take(ES * 8), o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmw = take(LEGS * S * 8),
                  o_clmr = take(LEGS * S * 8);
     const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
@@ -387,6 +387,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.act = nullptr; P.nact = nullptr;  // per group, set at launch
     h->d_act = (uint8_t *)(base + o_act); h->d_nact = (int *)(base + o_nact);
     P.pguess = (double *)(base + o_pguess);
+    P.gss_w = (long long *)(base + o_gssw); P.gss_r = (double *)(base + o_gssr);
     P.anc_w = (long long *)(base + o_ancw); P.anc_r = (double *)(base + o_ancr);
     P.clm_w = (long long *)(base + o_clmw); P.clm_r = (double *)(base + o_clmr);
     P.pend = (double *)(base + o_pend);

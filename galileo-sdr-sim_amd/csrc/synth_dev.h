@@ -47,6 +47,8 @@ struct DevPlan {
 
     // carrier speculation (leg arrays are slot-major, [S][LEGS])
     double *pguess;      // [S][E] ideal-arithmetic phase at epoch start
+    long long *gss_w;    // [S][E] ideal last wrap (or root) at or before the epoch start: global sample index
+    double *gss_r;       // [S][E] ... and its residual
     long long *anc_w;    // anchor of the leg: global sample index ...
     double *anc_r;       // ... and the phase before that sample (a wrap residual, or the chain root)
     long long *clm_w;    // claim: last wrap seen by the leg's last walk (-1: none)

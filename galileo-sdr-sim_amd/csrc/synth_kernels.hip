@@ -84,13 +84,34 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return u2d(((uint64_t)hi << 32) | lo);
 }
 
-// k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start.  One wave per slot: 64 epochs are
-// loaded at once (one memory round trip), then the short sequential recurrence runs out of registers.
+// Ideal-arithmetic prediction of the last wrap at or before local sample `a` of an epoch that starts at
+// phase p (|p| < 1) with step d: the unreduced phase p + n*d crosses the k-th integer at
+// omega_k = ceil((k - p) / d); the wrap residual is snapped to the 2^-52 grid every true residual lives on.
+// Returns false if there is no wrap in [1, a].  Only a GUESS: the stitcher verifies everything.
+__device__ __forceinline__ bool ideal_last_wrap(double p, double d, int a, int *omega, double *r)
+{
+    const double xa = p + (double)a * d;
+    const double ka = __builtin_trunc(xa);
+    if (ka == 0.0 || d == 0.0) return false;
+    double w = __builtin_ceil((ka - p) / d);
+    w = w > (double)a ? (double)a : w;
+    w = w < 1.0 ? 1.0 : w;
+    const double res = (p + w * d) - ka;
+    *omega = (int)w;
+    *r = (res + 1.5) - 1.5;
+    return true;
+}
+
+// k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start and the ideal last wrap before it.
+// One wave per slot: 64 epochs are loaded at once (one memory round trip), then the short sequential
+// recurrence runs out of registers (v_readlane with literal lanes, no LDS permutes on the serial path).
 __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
 {
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
-    double p = 0.0;  // wave-uniform running phase
+    double p = 0.0;        // wave-uniform running phase
+    long long lw = 0;      // wave-uniform: last wrap (or root) before the current epoch ...
+    double lr = 0.0;       // ... and its residual
     const double start0 = P.state_in[s].carr_phase;
     for (int base = 0; base < P.E; base += 64) {
         const int e = base + lane;
@@ -100,19 +121,39 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
         const uint32_t fl = P.flags[idx];
         const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
         const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
-        const double adv = (double)P.N * P.dstep[idx];
-        double mine = 0.0;
+        const double d = P.dstep[idx];
+        double mine = 0.0, mine_r = 0.0;
+        long long mine_w = 0;
 #pragma unroll
-        for (int k = 0; k < 64; ++k) {  // v_readlane with a literal lane: no LDS permute on the serial path
+        for (int k = 0; k < 64; ++k) {
             const int prn_k = __builtin_amdgcn_readlane(prn, k);
             if (prn_k > 0) {  // wave-uniform branch
-                if (__builtin_amdgcn_readlane((int)reset, k)) p = readlane_f64(p0, k);
-                if (k == lane) mine = p;
-                p = p + readlane_f64(adv, k);
+                if (__builtin_amdgcn_readlane((int)reset, k)) {
+                    p = readlane_f64(p0, k);
+                    lw = (long long)(base + k) * P.N;
+                    lr = p;
+                }
+                if (k == lane) {
+                    mine = p;
+                    mine_w = lw;
+                    mine_r = lr;
+                }
+                const double dk = readlane_f64(d, k);
+                int om;
+                double rr;
+                if (ideal_last_wrap(p, dk, P.N, &om, &rr)) {
+                    lw = (long long)(base + k) * P.N + om;
+                    lr = rr;
+                }
+                p = p + (double)P.N * dk;
                 p = p - __builtin_trunc(p);
             }
         }
-        if (in && prn > 0) P.pguess[(size_t)s * P.E + e] = mine;
+        if (in && prn > 0) {
+            P.pguess[(size_t)s * P.E + e] = mine;
+            P.gss_w[(size_t)s * P.E + e] = mine_w;
+            P.gss_r[(size_t)s * P.E + e] = mine_r;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk
@@ -126,8 +167,8 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
 // the chunk checkpoints.  It reports the last wrap it saw (its CLAIM) or none.  Anchoring at wraps is what
 // makes the speculation robust: right after a wrap every phase is a multiple of 2^-52, so the difference
 // between a guessed and the true trajectory survives every later rounding unchanged, whereas a mid-cycle
-// phase (finer grid) would be re-rounded at each binade crossing.  first != 0: pseudo anchor = the ideal
-// phase at the leg start (only its claims are used afterwards).
+// phase (finer grid) would be re-rounded at each binade crossing.  first != 0: the anchor is the last wrap
+// predicted by ideal arithmetic (k_carr_guess / ideal_last_wrap).
 __global__ void k_walk_carr(DevPlan P, int first)
 {
     if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
@@ -144,9 +185,16 @@ __global__ void k_walk_carr(DevPlan P, int first)
     long long cur;
     double p;
     if (first) {
-        const double x = P.pguess[(size_t)s * P.E + e] + (double)(w * L) * P.dstep[idx];
-        cur = A;
-        p = x - __builtin_trunc(x);
+        // first pass: anchor from ideal arithmetic (predicted last wrap at or before the leg start)
+        int om;
+        double rr;
+        if (ideal_last_wrap(P.pguess[(size_t)s * P.E + e], P.dstep[idx], w * L, &om, &rr)) {
+            cur = (long long)e * P.N + om;
+            p = rr;
+        } else {
+            cur = P.gss_w[(size_t)s * P.E + e];
+            p = P.gss_r[(size_t)s * P.E + e];
+        }
         P.anc_w[li] = cur;
         P.anc_r[li] = p;
         P.verified[li] = 0;
@@ -292,7 +340,7 @@ __device__ __forceinline__ void leg_advance(const DevPlan &P, int s, int i, cons
     }
 }
 
-#define SCAN_THREADS 256
+#define SCAN_THREADS 1024
 __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacobi)
 {
     (void)jacobi;  // pseudo anchors never match a claim's wrap index, so the first scan resets D by itself
