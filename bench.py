@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--epochs", type=int, default=1199, help="epochs per step (default: the 120 s scenario)")
     ap.add_argument("--channels", type=int, default=12)
     ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = auto)")
+    ap.add_argument("--workload", default="syn12", choices=["syn12", "syn24", "dyn"],
+                    help="syn12 = headline M-SYN12 (BASELINE configs[1] size); syn24 = config 4 geometry (24 SVs, "
+                    "25 MS/s); dyn = config 3 (12 SVs, Doppler from a 10 Hz circular track)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,9 +114,12 @@ def main():
 
     pkg = load_pkg()
     n_samp, rate, n_slots = 260000, 2.6e6, 16
+    if args.workload == "syn24":
+        n_samp, rate, n_slots = 2500000, 25e6, 24
+        args.channels = 24
     # each rank: an independent scenario of identical size (different seed)
     params = pkg.shard.rank_workload(rank, args.epochs, n_chan=args.channels, n_slots=n_slots,
-                                     samples_per_epoch=n_samp, sample_rate=rate)
+                                     samples_per_epoch=n_samp, sample_rate=rate, dyn_track=(args.workload == "dyn"))
     eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
                           chunk_samples=args.chunk)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -151,7 +157,7 @@ def main():
 
     if rank == 0:
         avg_synth_ms = ms_synth / args.steps
-        traffic, traffic_src = measured_traffic() if (args.epochs == 1199 and args.channels == 12) else (None, None)
+        traffic, traffic_src = measured_traffic() if (args.epochs == 1199 and args.workload == "syn12" and args.channels == 12) else (None, None)
         achieved = 4.0 * samples_per_step / (avg_synth_ms * 1e-3) / 1e9 if avg_synth_ms > 0 else 0.0
         line = {
             "metric": METRIC,
@@ -168,8 +174,10 @@ def main():
             "dtype": "f64 phase NCO -> int32 accumulate -> int16 IQ",
             "data": "synthetic",
             "config": {
-                "workload": "M-SYN12: static-geometry 12-SV E1B/C, %d epochs x %d samples @%.1f MS/s per GPU "
-                "(BASELINE configs[1] size; one independent scenario per rank)" % (args.epochs, n_samp, rate / 1e6),
+                "workload": {"syn12": "M-SYN12: static-geometry 12-SV E1B/C", "syn24": "M-SYN24: 24-SV E1B/C",
+                             "dyn": "M-DYN: 12-SV E1B/C, 10 Hz circular user motion"}[args.workload]
+                + ", %d epochs x %d samples @%.1f MS/s per GPU (one independent scenario per rank)" % (
+                    args.epochs, n_samp, rate / 1e6),
                 "channels": args.channels,
                 "chunk_samples": stats["chunk_samples"],
                 "walk_passes": stats["walk_passes"],
@@ -178,7 +186,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_synth<12,false>",
+                "kernel": "k_synth<%d,false>%s" % (min(args.channels, 12), " (+ accumulate launch)" if args.channels > 12 else ""),
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -192,6 +200,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
+        line["x_realtime"] = round(value * 1e6 / rate, 2)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -215,99 +215,23 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
 
 
 // ---------------------------------------------------------------------------------------------
-// Speculative evaluation of the carrier chain across epochs (one slot).  The chain is sequential over
-// the whole run, but rounded-add chains commute with shifts that are multiples of 2^-52 as long as the
-// itinerary (binade crossings, wraps) is unchanged, so epochs are walked in parallel from guessed start
-// phases and stitched by these two routines.  All [E][S] arrays are indexed e * S + s.
-//
-// carr_guess_slot: ideal-arithmetic guesses for every epoch start.
-GAL_HD void carr_guess_slot(int s, int E, int S, int N, const int *prn, const uint32_t *flags, const double *p0,
-                            const double *dstep, double start0, double *pst, uint8_t *verified, uint8_t *dirty)
+// Ideal-arithmetic prediction of the last wrap at or before local sample `a` of an epoch that starts at
+// phase p (|p| < 1) with step d: the unreduced phase p + n*d crosses the k-th integer at
+// omega_k = ceil((k - p) / d); the wrap residual is snapped to the 2^-52 grid every true residual lives on.
+// Returns false if there is no wrap in [1, a].  Only a GUESS for the speculative stitcher
+// (synth_kernels.hip: k_carr_guess / k_walk_carr), which verifies everything bitwise.
+GAL_HD bool ideal_last_wrap(double p, double d, int a, int *omega, double *r)
 {
-    double p = 0.0;
-    bool have = false;
-    for (int e = 0; e < E; ++e) {
-        const int idx = e * S + s;
-        if (prn[idx] <= 0) {
-            have = false;
-            continue;
-        }
-        if (flags[idx] & 1u) {  // GAL_CH_RESTART
-            p = p0[idx];
-            have = true;
-        } else if (e == 0) {
-            p = start0;
-            have = true;
-        } else if (!have) {
-            p = 0.0;  // malformed batch (rejected on the host); keep the routine total
-            have = true;
-        }
-        pst[idx] = p;
-        dirty[idx] = 1;
-        verified[idx] = 0;
-        p = p + (double)N * dstep[idx];
-        p = p - (double)(long long)p;
-    }
-}
-
-// carr_scan_slot: walk the epochs in order.  A chunk is VERIFIED only if the start phase its last walk
-// used is bitwise the true one (given at a restart / batch start, or the end of a verified predecessor).
-// Unverified chunks get a new start: jacobi != 0 -> the predecessor's last end as is (this puts the
-// guess on the right sub-2^-52 residue: after one wrap every phase is a multiple of 2^-52 plus a
-// residue fixed by the itinerary); else that end shifted by the predecessor's own start correction.
-// Returns the number of still unverified chunks.
-GAL_HD int carr_scan_slot(int s, int E, int S, const int *prn, const uint32_t *flags, const double *p0,
-                          double start0, double *pst, const double *pend, uint8_t *verified, uint8_t *dirty,
-                          int jacobi)
-{
-    int unver = 0;
-    bool prev_true = false;  // previous chunk verified -> its pend is the true start of this one
-    bool have_prev = false;  // previous chunk active
-    double prev_end_true = 0.0, prev_end_guess = 0.0;
-    for (int e = 0; e < E; ++e) {
-        const int idx = e * S + s;
-        if (prn[idx] <= 0) {
-            prev_true = false;
-            have_prev = false;
-            continue;
-        }
-        const double cur = pst[idx];
-        bool known = false;
-        double tstart = 0.0;
-        if (flags[idx] & 1u) {
-            known = true;
-            tstart = p0[idx];
-        } else if (e == 0) {
-            known = true;
-            tstart = start0;
-        } else if (prev_true) {
-            known = true;
-            tstart = prev_end_true;
-        }
-        double nstart = cur;
-        if (known) nstart = tstart;
-        else if (have_prev) nstart = prev_end_guess;
-        const bool same = d2u(nstart) == d2u(cur);
-        const double pend_old = pend[idx];
-        if (known && same && !dirty[idx]) {
-            verified[idx] = 1;
-            prev_true = true;
-            prev_end_true = pend_old;
-            prev_end_guess = pend_old;
-        } else {
-            ++unver;
-            prev_true = false;
-            if (!same) {
-                pst[idx] = nstart;
-                dirty[idx] = 1;
-                prev_end_guess = jacobi ? pend_old : pend_old + (nstart - cur);
-            } else {
-                prev_end_guess = pend_old;
-            }
-        }
-        have_prev = true;
-    }
-    return unver;
+    const double xa = p + (double)a * d;
+    const double ka = __builtin_trunc(xa);
+    if (ka == 0.0 || d == 0.0) return false;
+    double w = __builtin_ceil((ka - p) / d);
+    w = w > (double)a ? (double)a : w;
+    w = w < 1.0 ? 1.0 : w;
+    const double res = (p + w * d) - ka;
+    *omega = (int)w;
+    *r = (res + 1.5) - 1.5;
+    return true;
 }
 
 }  // namespace galnco

@@ -84,34 +84,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return u2d(((uint64_t)hi << 32) | lo);
 }
 
-// Ideal-arithmetic prediction of the last wrap at or before local sample `a` of an epoch that starts at
-// phase p (|p| < 1) with step d: the unreduced phase p + n*d crosses the k-th integer at
-// omega_k = ceil((k - p) / d); the wrap residual is snapped to the 2^-52 grid every true residual lives on.
-// Returns false if there is no wrap in [1, a].  Only a GUESS: the stitcher verifies everything.
-__device__ __forceinline__ bool ideal_last_wrap(double p, double d, int a, int *omega, double *r)
-{
-    const double xa = p + (double)a * d;
-    const double ka = __builtin_trunc(xa);
-    if (ka == 0.0 || d == 0.0) return false;
-    double w = __builtin_ceil((ka - p) / d);
-    w = w > (double)a ? (double)a : w;
-    w = w < 1.0 ? 1.0 : w;
-    const double res = (p + w * d) - ka;
-    *omega = (int)w;
-    *r = (res + 1.5) - 1.5;
-    return true;
-}
-
 // k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start and the ideal last wrap before it.
-// One wave per slot: 64 epochs are loaded at once (one memory round trip), then the short sequential
-// recurrence runs out of registers (v_readlane with literal lanes, no LDS permutes on the serial path).
+// One wave per slot, 64 epochs per round trip: (1) the short sequential phase recurrence runs out of
+// registers (v_readlane with literal lanes, no LDS permutes on the serial path); (2) every lane predicts the
+// last wrap inside its own epoch in closed form; (3) a wave-wide "last one that speaks" scan turns those into
+// the last wrap (or chain root) at or before every epoch start.
 __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
 {
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
-    double p = 0.0;        // wave-uniform running phase
-    long long lw = 0;      // wave-uniform: last wrap (or root) before the current epoch ...
-    double lr = 0.0;       // ... and its residual
+    double p = 0.0;  // wave-uniform running phase
+    // carry of the event scan: kind 0 nothing yet, 1 defined, 2 chain broken
+    int c_kind = 0;
+    long long c_w = 0;
+    double c_r = 0.0;
     const double start0 = P.state_in[s].carr_phase;
     for (int base = 0; base < P.E; base += 64) {
         const int e = base + lane;
@@ -122,38 +108,70 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
         const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
         const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
         const double d = P.dstep[idx];
-        double mine = 0.0, mine_r = 0.0;
-        long long mine_w = 0;
+        const double adv = (double)P.N * d;
+        double mine = 0.0;
 #pragma unroll
         for (int k = 0; k < 64; ++k) {
             const int prn_k = __builtin_amdgcn_readlane(prn, k);
             if (prn_k > 0) {  // wave-uniform branch
-                if (__builtin_amdgcn_readlane((int)reset, k)) {
-                    p = readlane_f64(p0, k);
-                    lw = (long long)(base + k) * P.N;
-                    lr = p;
-                }
-                if (k == lane) {
-                    mine = p;
-                    mine_w = lw;
-                    mine_r = lr;
-                }
-                const double dk = readlane_f64(d, k);
-                int om;
-                double rr;
-                if (ideal_last_wrap(p, dk, P.N, &om, &rr)) {
-                    lw = (long long)(base + k) * P.N + om;
-                    lr = rr;
-                }
-                p = p + (double)P.N * dk;
+                if (__builtin_amdgcn_readlane((int)reset, k)) p = readlane_f64(p0, k);
+                if (k == lane) mine = p;
+                p = p + readlane_f64(adv, k);
                 p = p - __builtin_trunc(p);
             }
         }
+        // the last event up to the END of my epoch: a wrap inside it, else its root, else nothing
+        int kind = 0;
+        long long w = 0;
+        double r = 0.0;
+        if (in && prn <= 0) kind = 2;
+        if (prn > 0) {
+            int om;
+            double rr;
+            if (ideal_last_wrap(mine, d, P.N, &om, &rr)) {
+                kind = 1;
+                w = (long long)e * P.N + om;
+                r = rr;
+            } else if (reset) {
+                kind = 1;
+                w = (long long)e * P.N;
+                r = mine;
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {  // inclusive "last one that speaks"
+            const int k2 = __shfl_up(kind, off);
+            const long long w2 = __shfl_up(w, off);
+            const double r2 = __shfl_up(r, off);
+            if (lane >= off && kind == 0) {
+                kind = k2;
+                w = w2;
+                r = r2;
+            }
+        }
+        if (kind == 0) {
+            kind = c_kind;
+            w = c_w;
+            r = c_r;
+        }
+        // exclusive value = what stands before my epoch
+        int xk = __shfl_up(kind, 1);
+        long long xw = __shfl_up(w, 1);
+        double xr = __shfl_up(r, 1);
+        if (lane == 0) {
+            xk = c_kind;
+            xw = c_w;
+            xr = c_r;
+        }
         if (in && prn > 0) {
             P.pguess[(size_t)s * P.E + e] = mine;
-            P.gss_w[(size_t)s * P.E + e] = mine_w;
-            P.gss_r[(size_t)s * P.E + e] = mine_r;
+            const bool use_root = reset || xk != 1;  // (a chain without a root is rejected on the host)
+            P.gss_w[(size_t)s * P.E + e] = use_root ? (long long)e * P.N : xw;
+            P.gss_r[(size_t)s * P.E + e] = use_root ? mine : xr;
         }
+        c_kind = __shfl(kind, 63);
+        c_w = __shfl(w, 63);
+        c_r = __shfl(r, 63);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk

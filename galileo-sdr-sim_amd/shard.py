@@ -11,11 +11,11 @@ def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def rank_workload(rank, n_epochs, n_chan=12, n_slots=16, samples_per_epoch=260000, sample_rate=2.6e6):
+def rank_workload(rank, n_epochs, n_chan=12, n_slots=16, samples_per_epoch=260000, sample_rate=2.6e6, dyn_track=False):
     """The scenario rank `rank` owns: same size on every rank (weak scaling), different seed."""
     return workloads.make_synthetic(n_epochs=n_epochs, n_chan=n_chan, n_slots=n_slots,
                                     samples_per_epoch=samples_per_epoch, sample_rate=sample_rate,
-                                    seed=workloads.SEED + rank)
+                                    seed=workloads.SEED + rank, dyn_track=dyn_track)
 
 
 def reduce_report(dist, device, elapsed_s, n_samples, checksum):

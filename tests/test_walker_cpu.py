@@ -26,10 +26,6 @@ def W(pkg):
     lib.galwalk_carr_iters.argtypes = [d, d, i]
     lib.galwalk_code.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
     lib.galwalk_code_brute.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
-    lib.galwalk_spec_chain.restype = i
-    lib.galwalk_spec_chain.argtypes = [i, i, vp, vp, vp, vp, d, i, vp, vp, vp]
-    lib.galwalk_spec_legs.restype = i
-    lib.galwalk_spec_legs.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i]
     lib.galwalk_spec_wrap.restype = i
     lib.galwalk_spec_wrap.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i]
     return lib
@@ -125,58 +121,6 @@ def _chain_truth(W, p, d, N):
     return ends
 
 
-def test_speculative_chain_sequential_spec(W):
-    """Epoch-level speculation (carr_guess_slot / carr_scan_slot) reproduces the sequential chain exactly."""
-    rng = np.random.default_rng(5)
-    E, N = 60, 26000
-    for t in range(6):
-        f0 = rng.uniform(-3000, 3000)
-        d = (f0 - 0.05 * np.arange(E)) * DELT
-        prn = np.full(E, 7, dtype=np.int32)
-        flags = np.zeros(E, dtype=np.uint32)
-        p0 = np.zeros(E)
-        flags[0] = 1
-        p0[0] = rng.uniform(0, 1)
-        if t % 2:  # a re-allocation in the middle and an idle gap
-            prn[20:23] = 0
-            flags[23] = 1
-            p0[23] = rng.uniform(0, 1)
-        pst, pend = np.zeros(E), np.zeros(E)
-        walks = ctypes.c_long()
-        r = W.galwalk_spec_chain(E, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data, 0.0, 80,
-                                 pst.ctypes.data, pend.ctypes.data, ctypes.byref(walks))
-        assert r > 0, r
-        if t % 2:
-            truth = np.concatenate([_chain_truth(W, p0[0], d[:20], N), np.zeros(3), _chain_truth(W, p0[23], d[23:], N)])
-            act = prn > 0
-            assert np.array_equal(pend[act].view(np.uint64), truth[act].view(np.uint64))
-        else:
-            assert np.array_equal(pend.view(np.uint64), _chain_truth(W, p0[0], d, N).view(np.uint64))
-
-
-def test_speculative_legs_emulation(W):
-    """Leg-level speculation as the GPU runs it (k_walk_carr / k_carr_scan): whatever the number of passes,
-    only bitwise-verified legs are accepted, so the stitched chain equals the sequential one."""
-    rng = np.random.default_rng(6)
-    E, N, Wl, L = 40, 26000, 8, 3252
-    for t in range(5):
-        f0 = rng.uniform(-3000, 3000) if t else 35.0
-        d = (f0 - 0.05 * np.arange(E)) * DELT
-        prn = np.full(E, 3, dtype=np.int32)
-        flags = np.zeros(E, dtype=np.uint32)
-        p0 = np.zeros(E)
-        flags[0] = 1
-        p0[0] = rng.uniform(0, 1)
-        pend = np.zeros(E * Wl)
-        hist = np.zeros(400, dtype=np.int32)
-        walks = ctypes.c_long()
-        r = W.galwalk_spec_legs(E, Wl, L, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data, 0.0,
-                                400, pend.ctypes.data, ctypes.byref(walks), hist.ctypes.data, 3)
-        assert r > 0
-        truth = _chain_truth(W, p0[0], d, N)
-        assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), truth.view(np.uint64))
-
-
 def test_wrap_anchored_stitching_as_on_gpu(W):
     """The scheme the GPU runs (k_walk_carr / k_carr_scan): legs anchored at the last wrap, claims stitched by
     the sequential statement (nthreads=0) and by the block-parallel three-sweep form (nthreads=256).  Both must
@@ -190,6 +134,7 @@ def test_wrap_anchored_stitching_as_on_gpu(W):
         cases.append((f0 - 0.05 * np.arange(E)) * DELT)
     cases.append(np.linspace(40.0, -35.0, E) * DELT)      # zero crossing
     cases.append(np.full(E, 0.7) * DELT)                   # practically no wraps at all
+    cases.append(-(1500.0 + 0.5 * np.arange(E)) * DELT)    # negative Doppler
     for d in cases:
         d = np.ascontiguousarray(d)
         prn = np.full(E, 3, dtype=np.int32)
@@ -198,7 +143,7 @@ def test_wrap_anchored_stitching_as_on_gpu(W):
         flags[0] = 1
         p0[0] = rng.uniform(0, 1)
         truth = _chain_truth(W, p0[0], d, N)
-        for nthreads in (0, 256):
+        for nthreads in (0, 256, 1024):
             pend = np.zeros(E * Wl)
             hist = np.zeros(64, dtype=np.int32)
             walks = ctypes.c_long()
