@@ -297,77 +297,113 @@ __device__ __forceinline__ LegRec leg_load(const DevPlan &P, int s, int i, doubl
     return L;
 }
 
-// Effect of one leg on (allok, D) given the claim state `lc` in front of it.  `fv` / `fd` report that the
-// leg restarted allok / D (root, idle epoch, or an anchor that is a different wrap event than the claim),
-// which is what makes the fold of many legs associative for the block scan.
-__device__ __forceinline__ void leg_advance(const DevPlan &P, int s, int i, const LegRec &L, ClaimState &lc,
-                                            double &D, int &allok, int &fv, int &fd, bool apply, int &unver)
+// The pending correction D travels along the chain as   D <- D + c[(D / 2^-52) mod 4]   per wrap-bearing leg:
+// normally c = G (the gap between the claim and the anchor that was walked, a multiple of 2^-52); in a tie
+// epoch D is first rounded to a multiple of 2^-51, ties to even, which depends on D only through
+// D mod 2^-50.  Such maps (plus "reset to a constant") are closed under composition, so the fold over many
+// legs is a 4-entry table and the block scan reproduces the sequential statement exactly.
+#define GAL_U52 2.220446049250313e-16  // 2^-52
+
+__device__ __forceinline__ int d_residue(double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); }
+
+__device__ __forceinline__ double tie_round(double D)  // to a multiple of 2^-51, ties to even (exact)
 {
+    return (D + 3.0) - 3.0;
+}
+
+struct DMap {
+    int isconst;  // the legs reset D: result = K whatever came in
+    double K;
+    double c[4];  // else result = D + c[residue(D)]
+};
+
+__device__ __forceinline__ double dmap_apply(const DMap &f, double D) { return f.isconst ? f.K : D + f.c[d_residue(D)]; }
+
+__device__ __forceinline__ DMap dmap_combine(const DMap &a, const DMap &b)  // a then b
+{
+    if (b.isconst) return b;
+    DMap r;
+    if (a.isconst) {
+        r.isconst = 1;
+        r.K = dmap_apply(b, a.K);
+        r.c[0] = r.c[1] = r.c[2] = r.c[3] = 0.0;
+        return r;
+    }
+    r.isconst = 0;
+    r.K = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const double mid = (double)m * GAL_U52 + a.c[m];
+        r.c[m] = a.c[m] + b.c[d_residue(mid)];
+    }
+    return r;
+}
+
+// What one leg does to the chain, given the claim state `lc` in front of it (exact, from sweep 1).
+struct LegOp {
+    bool act, root, have, link_ok, hw, same, tie;
+    long long nw;  // event the leg should be anchored at
+    double base;   // its residual before the pending correction is added
+    double G;      // gap: claim residual minus the anchor residual that was walked (same event only)
+};
+
+__device__ __forceinline__ LegOp leg_op(const DevPlan &P, int s, const LegRec &L, ClaimState &lc)
+{
+    LegOp o;
+    o.act = L.act;
+    o.root = L.root;
+    o.have = false; o.link_ok = false; o.hw = false; o.same = false; o.tie = false;
+    o.nw = 0; o.base = 0.0; o.G = 0.0;
     if (!L.act) {
         lc.kind = 2;
-        allok = 0;
-        D = 0.0;
-        fv = 1;
-        fd = 1;
-        return;
+        return o;
     }
     if (L.root) {
         lc.kind = 1;
         lc.w = L.A;
         lc.r = L.known;
-        D = 0.0;
-        allok = 1;
-        fv = 1;
-        fd = 1;
     }
-    const bool have = lc.kind == 1;
-    const bool link_ok = have && !L.dirty && L.aw == lc.w && d2u(L.ar) == d2u(lc.r);
-    allok &= link_ok ? 1 : 0;
-    double Du = D;
+    o.have = lc.kind == 1;
+    o.link_ok = o.have && !L.dirty && L.aw == lc.w && d2u(L.ar) == d2u(lc.r);
     {  // tie epochs quantise phase differences to multiples of 2^-51 at every wrap
         long long ea = lc.w > 0 ? (lc.w - 1) / P.N : 0;
         ea = ea < P.E ? ea : P.E - 1;
         const double dp = P.dstep[(int)ea * P.S + s];
         const double t53 = dp * 9007199254740992.0;  // * 2^53, exact
-        const bool tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
-        Du = tie ? (Du + 3.0) - 3.0 : Du;
+        o.tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
     }
-    const long long nw = lc.w;
-    const double nr = lc.r + Du;
-    const bool same_event = have && L.aw == nw;
-    const double Dleg = same_event ? nr - L.ar : 0.0;
-    if (apply) {
-        const size_t li = (size_t)s * P.LEGS + i;
-        if (allok) {
-            P.verified[li] = 1;
-        } else {
-            ++unver;
-            if (have && (L.aw != nw || d2u(L.ar) != d2u(nr))) {
-                P.anc_w[li] = nw;
-                P.anc_r[li] = nr;
-                P.dirty[li] = 1;
-            }
-        }
-    }
+    o.nw = lc.w;
+    o.base = lc.r;
+    o.same = o.have && L.aw == lc.w;
+    o.G = o.same ? lc.r - L.ar : 0.0;
+    o.hw = L.hw;
     if (L.hw) {
         lc.w = L.cw;
         lc.r = L.cr;
-        // D_out = (lc.r_in - anchor) + D_in for the same event (a sum: associative), else restart at 0
-        D = Dleg;
-        if (!same_event) fd = 1;
     }
+    return o;
+}
+
+// D after the leg, given D before it (the sequential statement's "D = D_leg" / inheritance / resets)
+__device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
+{
+    if (!o.act || o.root) D = o.act ? 0.0 : 0.0;
+    if (!o.act) return 0.0;
+    if (!o.hw) return D;
+    if (!o.same) return 0.0;
+    return o.G + (o.tie ? tie_round(D) : D);
 }
 
 #define SCAN_THREADS 1024
 __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacobi)
 {
-    (void)jacobi;  // pseudo anchors never match a claim's wrap index, so the first scan resets D by itself
+    (void)jacobi;
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_kind[SCAN_THREADS];
     __shared__ long long s_w[SCAN_THREADS];
     __shared__ double s_r[SCAN_THREADS];
-    __shared__ int s_fv[SCAN_THREADS], s_v[SCAN_THREADS], s_fd[SCAN_THREADS];
-    __shared__ double s_D[SCAN_THREADS];
+    __shared__ int s_fv[SCAN_THREADS], s_v[SCAN_THREADS], s_ic[SCAN_THREADS];
+    __shared__ double s_K[SCAN_THREADS], s_c[4][SCAN_THREADS];
     __shared__ int s_unver;
     const int s = blockIdx.x;
     const int t = threadIdx.x;
@@ -425,39 +461,63 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacob
         lc0.r = s_r[t - 1];
     }
 
-    // ---- sweep 2: fold my legs' effect on (allok, D) from neutral carries
+    // ---- sweep 2: fold my legs: allok (segmented AND) and the D map (evaluated on the four residues)
     {
         ClaimState lc = lc0;
-        int allok = 1, fv = 0, fd = 0, dummy = 0;
-        double D = 0.0;
+        int allok = 1, fv = 0, isconst = 0;
+        double D4[4] = {0.0, GAL_U52, 2.0 * GAL_U52, 3.0 * GAL_U52};
         for (int i = i0; i < i1; ++i) {
             const LegRec L = leg_load(P, s, i, start0);
-            leg_advance(P, s, i, L, lc, D, allok, fv, fd, false, dummy);
+            const LegOp o = leg_op(P, s, L, lc);
+            if (!o.act) {
+                allok = 0;
+                fv = 1;
+            } else {
+                if (o.root) {
+                    allok = 1;
+                    fv = 1;
+                }
+                allok &= o.link_ok ? 1 : 0;
+            }
+            if (!o.act || o.root || (o.hw && !o.same)) isconst = 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, (o.act && o.root) ? 0.0 : D4[m]);
         }
         s_fv[t] = fv;
         s_v[t] = allok;
-        s_fd[t] = fd;
-        s_D[t] = D;
+        s_ic[t] = isconst;
+        s_K[t] = D4[0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s_c[m][t] = D4[m] - (double)m * GAL_U52;
     }
     __syncthreads();
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // inclusive segmented AND / SUM scan
-        int afv = 0, av = 1, afd = 0;
-        double aD = 0.0;
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // inclusive scan: segmented AND + D-map composition
         const bool has = t >= off;
+        int afv = 0, av = 1;
+        DMap a, b;
+        a.isconst = 0; a.K = 0.0; a.c[0] = a.c[1] = a.c[2] = a.c[3] = 0.0;
         if (has) {
             afv = s_fv[t - off];
             av = s_v[t - off];
-            afd = s_fd[t - off];
-            aD = s_D[t - off];
+            a.isconst = s_ic[t - off];
+            a.K = s_K[t - off];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a.c[m] = s_c[m][t - off];
         }
-        const int bfv = s_fv[t], bv = s_v[t], bfd = s_fd[t];
-        const double bD = s_D[t];
+        const int bfv = s_fv[t], bv = s_v[t];
+        b.isconst = s_ic[t];
+        b.K = s_K[t];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b.c[m] = s_c[m][t];
         __syncthreads();
         if (has) {
+            const DMap r = dmap_combine(a, b);
             s_fv[t] = afv | bfv;
             s_v[t] = bfv ? bv : (av & bv);
-            s_fd[t] = afd | bfd;
-            s_D[t] = bfd ? bD : aD + bD;
+            s_ic[t] = r.isconst;
+            s_K[t] = r.K;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) s_c[m][t] = r.c[m];
         }
         __syncthreads();
     }
@@ -465,16 +525,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacob
     // ---- sweep 3: replay my legs with the true carries and apply
     {
         ClaimState lc = lc0;
-        int allok = 0, fv = 0, fd = 0;  // nothing is verified before the first root
+        int allok = 0;  // nothing is verified before the first root
         double D = 0.0;
         if (t > 0) {
             allok = s_fv[t - 1] ? s_v[t - 1] : 0;
-            D = s_D[t - 1];
+            D = s_ic[t - 1] ? s_K[t - 1] : s_c[0][t - 1];  // the prefix map applied to D = 0
         }
         int unver = 0;
         for (int i = i0; i < i1; ++i) {
             const LegRec L = leg_load(P, s, i, start0);
-            leg_advance(P, s, i, L, lc, D, allok, fv, fd, true, unver);
+            const LegOp o = leg_op(P, s, L, lc);
+            if (!o.act) {
+                allok = 0;
+                D = 0.0;
+                continue;
+            }
+            if (o.root) {
+                allok = 1;
+                D = 0.0;
+            }
+            allok &= o.link_ok ? 1 : 0;
+            const double nr = o.base + (o.tie ? tie_round(D) : D);
+            const size_t li = (size_t)s * P.LEGS + i;
+            if (allok) {
+                P.verified[li] = 1;
+            } else {
+                ++unver;
+                if (o.have && (L.aw != o.nw || d2u(L.ar) != d2u(nr))) {
+                    P.anc_w[li] = o.nw;
+                    P.anc_r[li] = nr;
+                    P.dirty[li] = 1;
+                }
+            }
+            D = leg_d_out(o, D);
         }
         if (unver) atomicAdd(&s_unver, unver);
     }
