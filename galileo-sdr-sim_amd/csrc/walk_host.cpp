@@ -167,80 +167,115 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             ++nwalk;
         }
         int unver = 0;
-        // one leg of the stitcher's sequential statement (== leg_advance in synth_kernels.hip)
-        struct Chain { int kind; long long w; double r; double D; int allok; int fv, fd; };
-        auto advance = [&](int i, Chain &c, bool apply) {
+        // ---- stitcher (== leg_op / leg_d_out / DMap of synth_kernels.hip)
+        struct Lc { int kind; long long w; double r; };
+        struct Op { bool act, root, have, link_ok, hw, same, tie; long long nw; double base, G; };
+        auto leg_op = [&](int i, Lc &lc) {
+            Op o = {false, false, false, false, false, false, false, 0, 0.0, 0.0};
             const int e = i / W, w = i % W;
-            if (prn[e] <= 0) { c.kind = 2; c.allok = 0; c.D = 0.0; c.fv = 1; c.fd = 1; return; }
-            const bool root = w == 0 && (e == 0 || (flags[e] & 1u));
-            if (root) { c.kind = 1; c.w = leg_start(i); c.r = (flags[e] & 1u) ? p0[e] : start0; c.D = 0.0; c.allok = 1; c.fv = 1; c.fd = 1; }
-            const bool have = c.kind == 1;
-            const bool link_ok = have && !dirty[i] && ws[i] == c.w && d2u(rs[i]) == d2u(c.r);
-            c.allok &= link_ok ? 1 : 0;
-            double Du = c.D;
-            {   // tie epochs quantise phase differences to multiples of 2^-51 at every wrap
-                long long ea = c.w > 0 ? (c.w - 1) / N : 0;
-                ea = ea < E ? ea : E - 1;
-                const double dp = dstep[ea];
-                const double t53 = dp * 9007199254740992.0;
-                const bool tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
-                if (tie) Du = (Du + 3.0) - 3.0;
+            o.act = prn[e] > 0;
+            if (!o.act) { lc.kind = 2; return o; }
+            o.root = w == 0 && (e == 0 || (flags[e] & 1u));
+            if (o.root) { lc.kind = 1; lc.w = leg_start(i); lc.r = (flags[e] & 1u) ? p0[e] : start0; }
+            o.have = lc.kind == 1;
+            o.link_ok = o.have && !dirty[i] && ws[i] == lc.w && d2u(rs[i]) == d2u(lc.r);
+            long long ea = lc.w > 0 ? (lc.w - 1) / N : 0;
+            ea = ea < E ? ea : E - 1;
+            const double t53 = dstep[ea] * 9007199254740992.0;
+            o.tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
+            o.nw = lc.w;
+            o.base = lc.r;
+            o.same = o.have && ws[i] == lc.w;
+            o.G = o.same ? lc.r - rs[i] : 0.0;
+            o.hw = hw[i] != 0;
+            if (o.hw) { lc.w = wc[i]; lc.r = rc[i]; }
+            return o;
+        };
+        auto tie_round = [](double D) { return (D + 3.0) - 3.0; };
+        auto d_out = [&](const Op &o, double D) {
+            if (!o.act) return 0.0;
+            if (o.root) D = 0.0;
+            if (!o.hw) return D;
+            if (!o.same) return 0.0;
+            return o.G + (o.tie ? tie_round(D) : D);
+        };
+        auto apply_leg = [&](int i, const Op &o, int &allok, double &D) {
+            if (!o.act) { allok = 0; D = 0.0; return; }
+            if (o.root) { allok = 1; D = 0.0; }
+            allok &= o.link_ok ? 1 : 0;
+            const double nr = o.base + (o.tie ? tie_round(D) : D);
+            if (allok) ver[i] = 1;
+            else {
+                ++unver;
+                if (o.have && (ws[i] != o.nw || d2u(rs[i]) != d2u(nr))) { ws[i] = o.nw; rs[i] = nr; dirty[i] = 1; }
             }
-            const long long nw = c.w;
-            const double nr = c.r + Du;
-            const bool same = have && ws[i] == nw;
-            const double Dleg = same ? nr - rs[i] : 0.0;
-            if (apply) {
-                if (c.allok) ver[i] = 1;
-                else {
-                    ++unver;
-                    if (have && (ws[i] != nw || d2u(rs[i]) != d2u(nr))) { ws[i] = nw; rs[i] = nr; dirty[i] = 1; }
-                }
-            }
-            if (hw[i]) { c.w = wc[i]; c.r = rc[i]; c.D = Dleg; if (!same) c.fd = 1; }
+            D = d_out(o, D);
         };
         if (nthreads <= 0) {
-            Chain c = {0, 0, 0.0, 0.0, 0, 0, 0};
-            for (int i = 0; i < LEGS; ++i) advance(i, c, true);
+            Lc lc = {0, 0, 0.0};
+            int allok = 0;
+            double D = 0.0;
+            for (int i = 0; i < LEGS; ++i) {
+                // leg_op reads the OLD anchors; apply_leg overwrites them afterwards
+                const Op o = leg_op(i, lc);
+                apply_leg(i, o, allok, D);
+            }
         } else {
-            // the kernel's three sweeps: K consecutive legs per thread, block scans of the partial results
+            const double U = 2.220446049250313e-16;  // 2^-52
+            auto resid = [&](double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); };
+            struct Agg { int kind; long long w; double r; int fv, v, ic; double K, c[4]; };
             const int T = nthreads, K = (LEGS + T - 1) / T;
-            std::vector<Chain> agg1(T), agg2(T);
-            for (int t = 0; t < T; ++t) {  // sweep 1: last claim
-                Chain m = {0, 0, 0.0, 0.0, 0, 0, 0};
+            std::vector<Agg> ag(T);
+            for (int t = 0; t < T; ++t) {  // sweep 1
+                Agg m = {0, 0, 0.0, 0, 1, 0, 0.0, {0, 0, 0, 0}};
                 for (int i = t * K; i < std::min(LEGS, (t + 1) * K); ++i) {
                     const int e = i / W, w = i % W;
                     if (prn[e] <= 0) { m.kind = 2; continue; }
                     if (w == 0 && (e == 0 || (flags[e] & 1u))) { m.kind = 1; m.w = leg_start(i); m.r = (flags[e] & 1u) ? p0[e] : start0; }
                     if (hw[i]) { m.kind = 1; m.w = wc[i]; m.r = rc[i]; }
                 }
-                agg1[t] = m;
+                ag[t] = m;
             }
-            for (int t = 1; t < T; ++t)
-                if (agg1[t].kind == 0) agg1[t] = agg1[t - 1];  // inclusive "last one that speaks"
-            for (int t = 0; t < T; ++t) {  // sweep 2: fold from neutral carries
-                Chain c = {0, 0, 0.0, 0.0, 1, 0, 0};
-                if (t > 0) { c.kind = agg1[t - 1].kind; c.w = agg1[t - 1].w; c.r = agg1[t - 1].r; }
-                for (int i = t * K; i < std::min(LEGS, (t + 1) * K); ++i) advance(i, c, false);
-                agg2[t] = c;
-            }
-            for (int t = 1; t < T; ++t) {  // inclusive segmented AND / SUM
-                Chain a = agg2[t - 1], b = agg2[t];
-                Chain r = b;
-                r.fv = a.fv | b.fv;
-                r.allok = b.fv ? b.allok : (a.allok & b.allok);
-                r.fd = a.fd | b.fd;
-                r.D = b.fd ? b.D : a.D + b.D;
-                agg2[t] = r;
-            }
-            for (int t = 0; t < T; ++t) {  // sweep 3: apply with the true carries
-                Chain c = {0, 0, 0.0, 0.0, 0, 0, 0};
-                if (t > 0) {
-                    c.kind = agg1[t - 1].kind; c.w = agg1[t - 1].w; c.r = agg1[t - 1].r;
-                    c.allok = agg2[t - 1].fv ? agg2[t - 1].allok : 0;
-                    c.D = agg2[t - 1].D;
+            std::vector<Lc> lcin(T);
+            {
+                Lc run = {0, 0, 0.0};
+                for (int t = 0; t < T; ++t) {
+                    lcin[t] = run;
+                    if (ag[t].kind != 0) run = {ag[t].kind, ag[t].w, ag[t].r};
                 }
-                for (int i = t * K; i < std::min(LEGS, (t + 1) * K); ++i) advance(i, c, true);
+            }
+            for (int t = 0; t < T; ++t) {  // sweep 2: fold allok and the D map on the four residues
+                Lc lc = lcin[t];
+                int allok = 1, fv = 0, ic = 0;
+                double D4[4] = {0.0, U, 2 * U, 3 * U};
+                for (int i = t * K; i < std::min(LEGS, (t + 1) * K); ++i) {
+                    const Op o = leg_op(i, lc);
+                    if (!o.act) { allok = 0; fv = 1; }
+                    else { if (o.root) { allok = 1; fv = 1; } allok &= o.link_ok ? 1 : 0; }
+                    if (!o.act || o.root || (o.hw && !o.same)) ic = 1;
+                    for (int m = 0; m < 4; ++m) D4[m] = d_out(o, D4[m]);
+                }
+                ag[t].fv = fv; ag[t].v = allok; ag[t].ic = ic; ag[t].K = D4[0];
+                for (int m = 0; m < 4; ++m) ag[t].c[m] = D4[m] - m * U;
+            }
+            // exclusive prefix of (allok, D map), then sweep 3
+            int pfv = 0, pv = 1, pic = 0;
+            double pK = 0.0, pc[4] = {0, 0, 0, 0};
+            for (int t = 0; t < T; ++t) {
+                Lc lc = lcin[t];
+                int allok = (t > 0 && pfv) ? pv : 0;
+                double D = t > 0 ? (pic ? pK : pc[0]) : 0.0;
+                for (int i = t * K; i < std::min(LEGS, (t + 1) * K); ++i) {
+                    const Op o = leg_op(i, lc);
+                    apply_leg(i, o, allok, D);
+                }
+                // fold thread t into the prefix: (p then ag[t])
+                const Agg &b = ag[t];
+                const int nfv = pfv | b.fv, nv = b.fv ? b.v : (pv & b.v);
+                if (b.ic) { pic = 1; pK = b.K; }
+                else if (pic) { pK = pK + b.c[resid(pK)]; }
+                else { double nc[4]; for (int m = 0; m < 4; ++m) { const double mid = m * U + pc[m]; nc[m] = pc[m] + b.c[resid(mid)]; } for (int m = 0; m < 4; ++m) pc[m] = nc[m]; }
+                pfv = nfv; pv = nv;
             }
         }
         if (unver_hist) unver_hist[pass] = unver;

@@ -143,11 +143,15 @@ def test_wrap_anchored_stitching_as_on_gpu(W):
         flags[0] = 1
         p0[0] = rng.uniform(0, 1)
         truth = _chain_truth(W, p0[0], d, N)
+        passes = []
         for nthreads in (0, 256, 1024):
             pend = np.zeros(E * Wl)
             hist = np.zeros(64, dtype=np.int32)
             walks = ctypes.c_long()
             r = W.galwalk_spec_wrap(E, Wl, L, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data,
                                     0.0, 64, pend.ctypes.data, ctypes.byref(walks), hist.ctypes.data, nthreads)
-            assert 0 < r <= 10, (r, nthreads, hist[:12])
+            assert 0 < r <= 6, (r, nthreads, hist[:12])
             assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), truth.view(np.uint64))
+            passes.append(r)
+        # the block-parallel form composes the pending-correction maps exactly: same pass count as sequential
+        assert passes[0] == passes[1] == passes[2], passes
