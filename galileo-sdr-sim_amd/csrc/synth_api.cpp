@@ -171,7 +171,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
-    if (hipHostMalloc((void **)&h->h_ctr, CTR_COUNT * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void **)&h->h_ctr, 2 * CTR_COUNT * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->h_state, sizeof(gal_chan_state_t) * GAL_ENGINE_MAX_CHAN,
                       hipHostMallocDefault) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
@@ -467,35 +467,25 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     galk_launch_pages(P, h->aux_stream);
     HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     galk_launch_carr_guess(P, st);
-    // Speculative carrier walk: a few passes are enqueued back to back (each is a no-op once the chain
-    // is verified), then the host looks at the counter once; stragglers (itinerary mismatches, low-Doppler
-    // legs) iterate from the host until every leg is verified.
-    const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
-    for (int pass = 0; pass < kDefaultPasses; ++pass) {
+    // Speculative carrier walk: kDefaultPasses passes are enqueued back to back (each is a no-op once the
+    // chain is verified -- 2-3 normally suffice), then the synthesis kernel, all asynchronously: the host does
+    // not wait here, so several handles can be kept in flight (the latency-bound walk of one batch then
+    // runs beside the issue-bound synthesis of another).  gal_synth_finish() looks at the counter; in the rare
+    // case that the chain was not verified by then it iterates further and repeats the synthesis.
+    int n_passes = kDefaultPasses;
+    if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;  // test hook
+    for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, st);
         galk_launch_carr_scan(P, pass == 0, st);
     }
     HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    while (h->h_ctr[CTR_UNVERIFIED] != 0) {
-        if (h->h_ctr[CTR_PASSES] >= max_passes)
-            return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes (%d legs unverified)",
-                        h->h_ctr[CTR_PASSES], h->h_ctr[CTR_UNVERIFIED]);
-        for (int k = 0; k < 2; ++k) {
-            galk_launch_walk_carr(P, 0, st);
-            galk_launch_carr_scan(P, 0, st);
-        }
-        HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    h->stats.walk_passes = h->h_ctr[CTR_PASSES];
     galk_launch_state_phase(P, st);
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
     HIP_TRY(hipEventRecord(h->ev[1], st));
     int rc = enqueue_synth(h, (uint32_t *)iq_dev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], st));
-    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->h_ctr + CTR_COUNT, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
     h->last_iq = (uint32_t *)iq_dev;
     h->executed = true;
     return GAL_OK;
@@ -512,7 +502,38 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     float ms_walk = 0, ms_synth = 0;
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
     hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[2]);
-
+    int *ctr_walk = h->h_ctr;              // counters after the enqueued walker passes
+    int *ctr_end = h->h_ctr + CTR_COUNT;   // counters after the synthesis kernel
+    if (ctr_walk[CTR_UNVERIFIED] != 0) {
+        // stragglers (itinerary mismatches / tie epochs beyond the enqueued passes): iterate from the host
+        // until every leg is verified, then redo the end state and the synthesis with the exact checkpoints
+        const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
+        while (ctr_walk[CTR_UNVERIFIED] != 0) {
+            if (ctr_walk[CTR_PASSES] >= max_passes)
+                return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes (%d legs unverified)",
+                            ctr_walk[CTR_PASSES], ctr_walk[CTR_UNVERIFIED]);
+            for (int k = 0; k < 2; ++k) {
+                galk_launch_walk_carr(P, 0, st);
+                galk_launch_carr_scan(P, 0, st);
+            }
+            HIP_TRY(hipMemcpyAsync(ctr_walk, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
+        galk_launch_state_phase(P, st);
+        HIP_TRY(hipEventRecord(h->ev[1], st));
+        int rc = enqueue_synth(h, h->last_iq);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(h->ev[2], st));
+        HIP_TRY(hipMemcpyAsync(ctr_end, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float extra = 0;
+        hipEventElapsedTime(&extra, h->ev[1], h->ev[2]);
+        ms_walk += ms_synth;  // the first, speculative synthesis was wasted work
+        ms_synth = extra;
+    }
+    h->stats.walk_passes = ctr_end[CTR_PASSES];
+    h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;

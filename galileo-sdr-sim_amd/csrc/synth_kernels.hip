@@ -53,6 +53,7 @@ __global__ void k_prep(DevPlan P)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_walk_code(DevPlan P)
 {
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P.E * P.S) return;
     if (P.prn[idx] <= 0) return;
@@ -91,6 +92,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // the last wrap (or chain root) at or before every epoch start.
 __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
 {
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
     double p = 0.0;  // wave-uniform running phase
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
 // predicted by ideal arithmetic (k_carr_guess / ideal_last_wrap).
 __global__ void k_walk_carr(DevPlan P, int first)
 {
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.LEGS * P.S) return;
@@ -397,6 +400,7 @@ __device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
 #define SCAN_THREADS 1024
 __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacobi)
 {
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     (void)jacobi;
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_kind[SCAN_THREADS];
@@ -580,6 +584,7 @@ __global__ void k_carr_publish(DevPlan P)
 //   -1: state_in,  2*e: page_next of epoch e,  2*e+1: page_init of epoch e.
 __global__ __launch_bounds__(64) void k_pages(DevPlan P)
 {
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     const int s = blockIdx.x;
     const int lane = threadIdx.x;
     int cur = -1;  // wave-uniform

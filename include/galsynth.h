@@ -122,7 +122,9 @@ size_t gal_synth_output_bytes(const gal_synth_t *h);
 /*
  * Run the hot path for the planned batch: NCO walk + per-sample synthesis, writing
  * interleaved int16 I,Q (little endian) to iq_dev (DEVICE memory, 16-byte aligned).  Asynchronous on
- * the handle's stream; may be called repeatedly for the same plan (bench loop).
+ * the handle's stream (plus two internal helper streams joined by events); may be called repeatedly for
+ * the same plan.  Several handles may be in flight on different streams: the latency-bound walk of one
+ * batch then overlaps the synthesis kernel of another (bench.py --pipeline).
  */
 int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
 

@@ -123,3 +123,40 @@ def test_invalid_batches_are_rejected(pkg):
         bad["ibit0"][0, 0] = 500
         with pytest.raises(pkg.GalSynthError):
             eng.run_host(bad)
+
+
+def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
+    """With a single enqueued walker pass the chain is never verified in time: gal_synth_finish() must iterate
+    from the host and redo the synthesis -- the result is still bit-exact."""
+    monkeypatch.setenv("GAL_WALK_PASSES", "1")
+    p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=77)
+    iq, st, stats = _compare(pkg, p, 52000)
+    assert stats["walk_passes"] >= 2
+
+
+def test_two_handles_in_flight(pkg):
+    """Software pipeline as bench.py runs it: two handles on two streams, executes interleaved."""
+    import torch
+
+    n = 52000
+    pa = pkg.workloads.make_synthetic(n_epochs=4, n_chan=6, n_slots=16, samples_per_epoch=n, seed=81)
+    pb = pkg.workloads.make_synthetic(n_epochs=4, n_chan=9, n_slots=16, samples_per_epoch=n, seed=82)
+    ea = pkg.SynthEngine(samples_per_epoch=n, device=0)
+    eb = pkg.SynthEngine(samples_per_epoch=n, device=0)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ea.set_stream(sa.cuda_stream)
+    eb.set_stream(sb.cuda_stream)
+    ea.plan(pa)
+    eb.plan(pb)
+    oa = torch.empty(ea.output_bytes() // 2, dtype=torch.int16, device="cuda")
+    ob = torch.empty(eb.output_bytes() // 2, dtype=torch.int16, device="cuda")
+    for _ in range(3):
+        ea.execute(oa.data_ptr())
+        eb.execute(ob.data_ptr())
+        ea.finish()
+        eb.finish()
+    ra, _ = oracle_run(pa, n, 2.6e6)
+    rb, _ = oracle_run(pb, n, 2.6e6)
+    assert np.array_equal(oa.cpu().numpy(), ra) and np.array_equal(ob.cpu().numpy(), rb)
+    ea.close()
+    eb.close()
