@@ -19,7 +19,7 @@ void galk_launch_prep(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
-void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st);
+void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_state_phase(const DevPlan *P, hipStream_t st);
 int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
@@ -81,7 +81,6 @@ struct gal_synth {
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
     // tables in HBM
-    uint32_t *d_e1b = nullptr, *d_e1c = nullptr;
     int *d_lut = nullptr;
     uint2 *d_win = nullptr;      // [50][130] periodic {B^C, C} windows
     DevPlan *d_plan = nullptr;   // device copy of P (the hot kernel reads rarely used fields through it)
@@ -176,10 +175,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
                       hipHostMallocDefault) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
 
-    const size_t code_bytes = sizeof(kE1B);
-    if (hipMalloc((void **)&h->d_e1b, code_bytes) != hipSuccess ||
-        hipMalloc((void **)&h->d_e1c, code_bytes) != hipSuccess ||
-        hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess ||
+    if (hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_win, 50 * 128 * sizeof(uint2)) != hipSuccess ||
         hipMalloc((void **)&h->d_plan, sizeof(DevPlan)) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "table allocation failed"));
@@ -193,9 +189,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     }
     int lut[512];
     for (int k = 0; k < 512; ++k) lut[k] = 2 * ((int)g_sin[k] * 65536 + (int)g_cos[k]);
-    if (hipMemcpy(h->d_e1b, kE1B, code_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_e1c, kE1C, code_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     *out = h;
     return GAL_OK;
@@ -208,8 +202,6 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->arena) hipFree(h->arena);
     if (h->own_iq) hipFree(h->own_iq);
-    if (h->d_e1b) hipFree(h->d_e1b);
-    if (h->d_e1c) hipFree(h->d_e1c);
     if (h->d_lut) hipFree(h->d_lut);
     if (h->d_win) hipFree(h->d_win);
     if (h->d_plan) hipFree(h->d_plan);
@@ -384,7 +376,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.cstep = (double *)(base + o_cstep); P.dstep = (double *)(base + o_dstep);
     P.page_next = (uint32_t *)(base + o_pnext); P.page_cur = (uint32_t *)(base + o_pcur);
     P.flip_in = (uint8_t *)(base + o_flip);
-    P.act = nullptr; P.nact = nullptr;  // per group, set at launch
     h->d_act = (uint8_t *)(base + o_act); h->d_nact = (int *)(base + o_nact);
     P.pguess = (double *)(base + o_pguess);
     P.gss_w = (long long *)(base + o_gssw); P.gss_r = (double *)(base + o_gssr);
@@ -395,7 +386,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
 
-    P.e1b = h->d_e1b; P.e1c = h->d_e1c; P.lut = h->d_lut; P.win = h->d_win;
+    P.lut = h->d_lut; P.win = h->d_win;
 
     // ---- upload (synchronous: after plan() the batch is resident in HBM).  A start phase of -0.0 is
     // canonicalised to +0.0 (see carr_step in nco_walk.h).
@@ -476,7 +467,7 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;  // test hook
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, st);
-        galk_launch_carr_scan(P, pass == 0, st);
+        galk_launch_carr_scan(P, st);
     }
     HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
     galk_launch_state_phase(P, st);
@@ -514,7 +505,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
                             ctr_walk[CTR_PASSES], ctr_walk[CTR_UNVERIFIED]);
             for (int k = 0; k < 2; ++k) {
                 galk_launch_walk_carr(P, 0, st);
-                galk_launch_carr_scan(P, 0, st);
+                galk_launch_carr_scan(P, st);
             }
             HIP_TRY(hipMemcpyAsync(ctr_walk, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

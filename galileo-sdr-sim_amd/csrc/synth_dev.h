@@ -41,10 +41,6 @@ struct DevPlan {
     uint32_t *page_cur;   // [E][S][16] page in force at epoch start (k_pages)
     uint8_t *flip_in;     // [E][S] symbol counter wrapped inside this epoch
 
-    // active-channel compaction (host built)
-    const uint8_t *act;  // [E][S] slots with prn > 0, first nact[e] entries valid
-    const int *nact;     // [E]
-
     // carrier speculation (leg arrays are slot-major, [S][LEGS])
     double *pguess;      // [S][E] ideal-arithmetic phase at epoch start
     long long *gss_w;    // [S][E] ideal last wrap (or root) at or before the epoch start: global sample index
@@ -65,8 +61,6 @@ struct DevPlan {
     int *ctr;  // [CTR_COUNT]
 
     // tables
-    const uint32_t *e1b;  // [50][128]
-    const uint32_t *e1c;  // [50][128]
     const int *lut;       // [512] 2 * (sin << 16 + cos)
     const uint2 *win;     // [50][130] {E1B^E1C, E1C} 32-chip words of the periodically extended codes
 };

@@ -1,25 +1,26 @@
 // synth_kernels.hip -- gfx950 (CDNA4) kernels of the Galileo E1B/C IQ synthesis engine.
 //
 // Replaces the per-sample loop of the reference, src/galileo-sdr.cpp:481-539.
-// Pipeline per batch of epochs (all on one HIP stream):
+// Pipeline per batch of epochs (handle stream + one helper stream, joined by events):
 //   k_prep         AoS epoch records -> SoA, NCO steps c = f_code*delt, d = f_carr*delt (one rounding each,
 //                  exactly the product the reference recomputes every sample, :528,:531)
 //   k_walk_code    one lane per (epoch, slot): exact closed-form walk of the code-phase chain, emitting a
 //                  checkpoint (phase, symbol index, page-flip flag) every R samples           [nco_walk.h]
-//   k_carr_guess / k_walk_carr / k_carr_scan
-//                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively:
-//                  every (epoch, slot) lane walks its epoch from a guessed start phase; a scan accepts
-//                  a chunk only when its start is BITWISE equal to the verified end of the previous one and
-//                  otherwise shifts the guess (rounded-add chains commute with shifts on the 2^-52 grid);
-//                  repeat until every chunk is verified -- typically 3 passes.
 //   k_pages        which page is in force at each epoch start (pages change only when a symbol counter
-//                  wraps inside the sample loop, :497-506)
+//                  wraps inside the sample loop, :497-506)                [both on the helper stream]
+//   k_carr_guess / k_walk_carr / k_carr_scan (+ k_carr_publish), 2-4 passes
+//                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively on LEGS
+//                  (8 per epoch): a leg is walked from its anchor = the last wrap event before it (first
+//                  guess: ideal arithmetic); the stitcher accepts a leg only when its anchor is BITWISE the
+//                  claim of the verified chain before it, otherwise re-anchors it at the predicted claim
+//                  (rounded-add chains commute with shifts on the 2^-52 grid every wrap residual lives on)
+//   k_state_phase  end-of-batch carrier phase per slot
 //   k_synth<NCH>   the hot kernel: one lane replays R consecutive samples for ALL active channels with the
 //                  reference's exact operation sequence from its checkpoint, accumulates packed
-//                  (Q<<16)+I in a register, and stores int16 I/Q with 16-byte stores.  PRN memory codes
-//                  (bit packed) and the sin/cos LUT live in LDS.  Each lane finally checks its end state
-//                  against the next checkpoint, so the closed-form walkers are verified against genuine
-//                  stepping on every run.
+//                  (Q<<16)+I in a register, and stores int16 I/Q in 64-byte bursts.  PRN memory codes (bit
+//                  planes) and the sin/cos LUT live in LDS.  Each lane finally checks its end state against
+//                  the next checkpoint, so the closed-form walkers are verified against genuine stepping
+//                  on every run.
 // No MFMA anywhere: this is FP64/integer ALU work bounded above by the 4 B/sample HBM write.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -390,18 +391,17 @@ __device__ __forceinline__ LegOp leg_op(const DevPlan &P, int s, const LegRec &L
 // D after the leg, given D before it (the sequential statement's "D = D_leg" / inheritance / resets)
 __device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
 {
-    if (!o.act || o.root) D = o.act ? 0.0 : 0.0;
     if (!o.act) return 0.0;
+    if (o.root) D = 0.0;
     if (!o.hw) return D;
     if (!o.same) return 0.0;
     return o.G + (o.tie ? tie_round(D) : D);
 }
 
 #define SCAN_THREADS 1024
-__global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacobi)
+__global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
-    (void)jacobi;
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_kind[SCAN_THREADS];
     __shared__ long long s_w[SCAN_THREADS];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P, int jacob
             }
             if (!o.act || o.root || (o.hw && !o.same)) isconst = 1;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, (o.act && o.root) ? 0.0 : D4[m]);
+            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, D4[m]);
         }
         s_fv[t] = fv;
         s_v[t] = allok;
@@ -960,9 +960,9 @@ extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t s
     hipLaunchKernelGGL(k_walk_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P, first);
 }
 
-extern "C" void galk_launch_carr_scan(const DevPlan *P, int jacobi, hipStream_t st)
+extern "C" void galk_launch_carr_scan(const DevPlan *P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P, jacobi);
+    hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P);
     hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
 }
 
