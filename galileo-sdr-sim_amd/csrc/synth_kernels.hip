@@ -55,8 +55,11 @@ __global__ void k_prep(DevPlan P)
 __global__ void k_walk_code(DevPlan P)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.E * P.S) return;
+    // a wave = 64 consecutive epochs of ONE slot (similar trip counts, idle slots leave as whole waves)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.E * P.S) return;
+    const int s = t / P.E;
+    const int idx = (t - s * P.E) * P.S + s;
     if (P.prn[idx] <= 0) return;
     double *cpx = P.cp_x + (size_t)idx * P.CP1;
     uint32_t *cpi = P.cp_ib + (size_t)idx * P.CP1;
@@ -194,10 +197,12 @@ __global__ void k_walk_carr(DevPlan P, int first)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
+    // a wave = 64 consecutive legs of ONE slot: similar Doppler, hence similar trip counts (a wave runs as long
+    // as its slowest lane), idle slots are whole waves that leave at once, and the leg arrays are read coalesced
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.LEGS * P.S) return;
-    const int s = t % P.S;
-    const int i = t / P.S;
+    const int s = t / P.LEGS;
+    const int i = t - s * P.LEGS;
     const int e = i / P.W, w = i - e * P.W;
     const int idx = e * P.S + s;
     if (P.prn[idx] <= 0) return;
