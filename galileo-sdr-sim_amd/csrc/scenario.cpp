@@ -40,6 +40,10 @@ struct Channel {  // the part of channel_t that outlives an epoch
     double carr_phase0 = 0.0;
     uint32_t page_init[GAL_PAGE_WORDS];
     bool fresh = false;  // allocated since the last emitted epoch
+    // page cache: the page depends on the receive time only through (int)sec (TOW and the word schedule,
+    // src/inav-msg.cpp:39-40,186), so it is regenerated once per second, not once per 0.1 s epoch
+    int page_key_sec = -1, page_key_week = -1, page_key_eph = -1;
+    uint32_t page_cached[GAL_PAGE_WORDS];
 };
 
 struct Vec3 {
@@ -88,6 +92,7 @@ void allocate_channels(gal_scen *s, const GalTime &grx, const double xyz[3])
                     Channel &c = s->chan[i];
                     if (c.prn != 0) continue;
                     c.prn = sv + 1;
+                    c.page_key_sec = -1;
                     int sym[kSymPerPage];
                     inav_page_symbols(grx, eph, s->nav.iono, sym);
                     pack_symbols(sym, c.page_init);
@@ -290,9 +295,15 @@ int32_t gal_scen_next(gal_scen_t *s, int32_t max_epochs, gal_chan_epoch_t *rows)
                 memcpy(r.page_init, c.page_init, sizeof(r.page_init));
                 c.fresh = false;
             }
-            int sym[kSymPerPage];
-            inav_page_symbols(s->grx, eph, s->nav.iono, sym);
-            pack_symbols(sym, r.page_next);
+            if (c.page_key_sec != (int)s->grx.sec || c.page_key_week != s->grx.week || c.page_key_eph != k) {
+                int sym[kSymPerPage];
+                inav_page_symbols(s->grx, eph, s->nav.iono, sym);
+                pack_symbols(sym, c.page_cached);
+                c.page_key_sec = (int)s->grx.sec;
+                c.page_key_week = s->grx.week;
+                c.page_key_eph = k;
+            }
+            memcpy(r.page_next, c.page_cached, sizeof(r.page_next));
         }
         // 30 s refresh, src/galileo-sdr.cpp:545-562
         const int igrx = (int)(s->grx.sec * 10.0 + 0.5);
