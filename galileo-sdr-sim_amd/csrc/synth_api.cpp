@@ -82,7 +82,7 @@ struct gal_synth {
 
     // tables in HBM
     int *d_lut = nullptr;
-    uint2 *d_win = nullptr;      // [50][130] periodic {B^C, C} windows
+    uint32_t *d_str = nullptr;   // [50][512] half-chip streams (2 bits per BOC half chip)
     DevPlan *d_plan = nullptr;   // device copy of P (the hot kernel reads rarely used fields through it)
 
     // arena for the planned batch
@@ -176,15 +176,21 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
 
     if (hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&h->d_win, 50 * 128 * sizeof(uint2)) != hipSuccess ||
+        hipMalloc((void **)&h->d_str, 50 * 512 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&h->d_plan, sizeof(DevPlan)) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "table allocation failed"));
     {
-        // bit planes D = E1B ^ E1C and C = E1C, 32 chips per word (bits 4092..4095 of the last word unused)
-        std::vector<uint2> win(50 * 128);
+        // per PRN 8184 BOC half chips x 2 bits: bit 2h = (E1B ^ E1C) chip, bit 2h+1 = E1C chip ^ (h & 1)
+        // (synth_kernels.hip, ChanGroup); the upper half of word 511 is unused
+        std::vector<uint32_t> str(50 * 512, 0u);
         for (int prn = 0; prn < 50; ++prn)
-            for (int w = 0; w < 128; ++w) win[prn * 128 + w] = make_uint2(kE1B[prn][w] ^ kE1C[prn][w], kE1C[prn][w]);
-        if (hipMemcpy(h->d_win, win.data(), win.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)
+            for (int hc = 0; hc < 2 * GAL_CODE_LEN; ++hc) {
+                const int chip = hc >> 1;
+                const uint32_t b = (kE1B[prn][chip >> 5] >> (chip & 31)) & 1u, c = (kE1C[prn][chip >> 5] >> (chip & 31)) & 1u;
+                const uint32_t two = (b ^ c) | ((c ^ (uint32_t)(hc & 1)) << 1);
+                str[prn * 512 + (hc >> 4)] |= two << (2 * (hc & 15));
+            }
+        if (hipMemcpy(h->d_str, str.data(), str.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(GAL_E_DEVICE, "table upload failed"));
     }
     int lut[512];
@@ -203,7 +209,7 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->arena) hipFree(h->arena);
     if (h->own_iq) hipFree(h->own_iq);
     if (h->d_lut) hipFree(h->d_lut);
-    if (h->d_win) hipFree(h->d_win);
+    if (h->d_str) hipFree(h->d_str);
     if (h->d_plan) hipFree(h->d_plan);
     if (h->h_ctr) hipHostFree(h->h_ctr);
     if (h->h_state) hipHostFree(h->h_state);
@@ -263,9 +269,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 return fail(GAL_E_INVAL, "epoch %d slot %d: bad phase/frequency", e, s);
             if (!(std::fabs(r.f_carr) < h->cfg.sample_rate) || !(r.f_code < h->cfg.sample_rate * 4000.0))
                 return fail(GAL_E_INVAL, "epoch %d slot %d: NCO step out of range", e, s);
-            // 16 samples must fit the 32-chip window of k_synth (28 in the code's last word)
-            if (!(r.f_code / h->cfg.sample_rate * 16.0 + 2.0 <= 28.0))
-                return fail(GAL_E_INVAL, "epoch %d slot %d: sample rate too low for the chip window (f_code/fs > 1.6)", e, s);
+            // 16 samples must fit the 16-half-chip window of k_synth: 15 * (2 f_code / fs) + 1 <= 16
+            if (!(r.f_code / h->cfg.sample_rate <= 0.5) || !(r.f_code / h->cfg.sample_rate >= 1.0 / 1048576.0))
+                return fail(GAL_E_INVAL, "epoch %d slot %d: f_code / sample_rate outside [2^-20, 0.5]", e, s);
             if (r.flags & GAL_CH_RESTART) {
                 if (!(std::fabs(r.carr_phase0) < 1.0))
                     return fail(GAL_E_INVAL, "epoch %d slot %d: carr_phase0 must be in (-1,1)", e, s);
@@ -295,6 +301,28 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         if (target < 64) target = 64;
         R = (N + target - 1) / target;
         R = (R + 15) / 16 * 16;  // 64-byte store bursts stay aligned
+        if (N >= 65536) {
+            // k_synth takes its slow group body whenever any lane of a wave is within 16 samples of a code
+            // wrap.  Lanes are consecutive chunks, so when the chunk length divides the code period (10400
+            // samples at 2.6 MS/s -> R = 1040) all wraps of a wave fall into the same group.  Pick the multiple
+            // of 16 near 1024 that minimises (slow groups + idle lanes).
+            const double period = (double)GAL_CODE_LEN * h->cfg.sample_rate / 1.023e6;
+            double best = 1e30;
+            for (int cand = 768; cand <= 1536; cand += 16) {
+                const double q = std::floor(period / cand + 0.5);
+                if (q < 1.0) continue;
+                const double spread = 64.0 / q * std::fabs(period - q * cand);  // samples, over one wave
+                double slow = 4.0 * (1.0 + spread / 16.0) * 16.0 / cand;        // 4 channels per part
+                if (slow > 1.0) slow = 1.0;
+                const int nck = (N + cand - 1) / cand;
+                const double waste = 1.0 - (double)N / ((double)((nck + 63) / 64 * 64) * cand);
+                const double cost = 0.3 * slow + waste + 0.02 * std::fabs(cand - 1024.0) / 1024.0;
+                if (cost < best) {
+                    best = cost;
+                    R = cand;
+                }
+            }
+        }
     }
     if (R < 4) R = 4;
     const int nchunks = (N + R - 1) / R;
@@ -386,7 +414,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
 
-    P.lut = h->d_lut; P.win = h->d_win;
+    P.lut = h->d_lut; P.str = h->d_str;
 
     // ---- upload (synchronous: after plan() the batch is resident in HBM).  A start phase of -0.0 is
     // canonicalised to +0.0 (see carr_step in nco_walk.h).

@@ -62,7 +62,7 @@ struct DevPlan {
 
     // tables
     const int *lut;       // [512] 2 * (sin << 16 + cos)
-    const uint2 *win;     // [50][130] {E1B^E1C, E1C} 32-chip words of the periodically extended codes
+    const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 
 // by-value geometry of the hot kernel (everything else it reaches through a device copy of DevPlan, so

@@ -646,20 +646,28 @@ __global__ void k_state_phase(DevPlan P)
 // constant (NCO steps, active PRNs) is wave-uniform and lives in SGPRs.
 //
 // A lane replays its chunk in GROUPS of 16 samples.  Inside a group the per-sample work of every channel
-// is BRANCH-FREE, so the 16 x NCH channel-steps form one basic block and the compiler interleaves the
-// channels' dependency chains (FP64 add/cvt latency and the LDS LUT read are hidden by ILP instead of by
-// occupancy).  What used to be rare branches is hoisted to the group boundaries:
-//   * chips: 16 samples advance the code by < 7 chips, so the group prologue builds a 32-chip window per
-//     channel from two LDS words (bit planes D = E1B^E1C and C = E1C), pre-XORed with the data/secondary
-//     signs; the window may straddle a word boundary and the code wrap (see ChanGroup).
-//   * code wrap (x >= 4092, src/galileo-sdr.cpp:491-507): `x -= ge ? 4092 : 0; ibit += ge`; the signs of
-//     the NEXT symbol are kept ready in `st`, the group epilogue refills them (and flips the page).
-// Per-lane persistent state per channel: x, p (FP64) and one packed word
+// is BRANCH-FREE, so the 16 x 4 channel-steps of a part form one basic block and the compiler interleaves
+// the channels' dependency chains (FP64 add/cvt latency and the LDS LUT read are hidden by ILP instead of
+// by occupancy).  What used to be rare branches is hoisted to the group boundaries:
+//   * chips: 16 samples advance the code by < 16 BOC half chips (plan() checks f_code/fs <= 0.5), so the
+//     group prologue cuts a 16-half-chip window W (2 bits per half chip: "v != 0" and "v < 0") out of the
+//     channel's half-chip stream in LDS and XORs the data/secondary signs of the current symbol onto it;
+//     a sample then needs one shift-add and one bit-field extract to get its table selector.
+//   * code wrap (x >= 4092, src/galileo-sdr.cpp:491-507): a wave-uniform test at the group start
+//     (any lane, any of the part's channels within 16 samples of the wrap?) picks between a FAST group body
+//     with no wrap handling at all and a SLOW one (`x -= ge ? 4092 : 0`, window spliced from the end of
+//     this code period and the start of the next with the next symbol's signs; the symbol counter is
+//     advanced in the group epilogue).  With the default chunk size (a divisor of the code period) the wraps
+//     of all 64 lanes fall into the same group, so ~9 of 10 groups are fast.
+// Per-lane persistent state per channel: y = 2x, p (FP64) and one packed word
 //     st = ibit[8:0] | use_next_page[9] | sg[11:10] | sg_next[13:12],  sg = (data^sec) | sec<<1.
-// LDS: [NCH][128]{D,C} code words + 4 x 1024-entry LUT (zero / plus / zero / minus).
+// LDS: [NCH][512] half-chip stream words + 4 x 1024-entry LUT (zero / plus / zero / minus).
 #define SYN_BLOCK 256
 #define SYN_GROUP 16
-#define WIN_WORDS 128
+#define STR_WORDS 512
+#ifndef SYN_WAVES
+#define SYN_WAVES 3  // waves per SIMD the register allocation aims at (LDS allows 4 blocks per CU)
+#endif
 
 __device__ __forceinline__ double uniform_f64(double v)
 {
@@ -705,55 +713,72 @@ struct ChanState {
 };
 
 struct ChanGroup {  // live only inside one 16-sample group
-    // 32-chip windows in NATURAL bit positions (chip c at bit c & 31), already XORed with the symbol signs:
-    // bits >= (chip0 & 31) come from the word holding chip0, the bits below from the following word (word 0
-    // of the next code period -- with the NEXT symbol's signs -- when chip0 sits in the last word).
-    uint32_t wD, wC;
-    double y0;  // y at group start: the code wrapped inside the group iff y ends below it
+    // 16-half-chip window, half chip ic0 + j at bits 2j (v != 0) and 2j+1 (v < 0), signs applied.  The
+    // stream (synth_api.cpp) stores bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1) for half chip h:
+    // v = E1B*d - E1C*s is non-zero iff B^C^d^s, negative iff C^s (given non-zero), and the BOC(1,1)
+    // sub-carrier boc[2c] = -chip, boc[2c+1] = +chip (src/gal-sig.cpp:198-213) flips the sign on odd h.
+    uint32_t W;
+    int m;       // bit offset of a sample's half chip in W = (2*icode + m) & 31; slow groups add 16 at the code
+                 // wrap (2 * 8184 = 16 mod 32) and start from an EVEN multiple of 16 ... see group_begin_slow
+    int mw;      // slow groups: value of m once the wrap has been taken (the epilogue compares)
 };
 
+// sg * 0x55555555: 0, 0x5555.., 0xAAAA.., 0xFFFF.. = the XOR mask of the sign pair on all 16 half chips
+#define GAL_SIGN_MASK(sg) ((sg) * 0x55555555u)
+
 template <int J>
-__device__ __forceinline__ void group_begin(const ChanState &c, ChanGroup &g, const uint2 *s_win)
+__device__ __forceinline__ void group_begin_fast(const ChanState &c, ChanGroup &g, const uint32_t *s_str)
+{
+    const int ic0 = (int)c.y;  // y < 8184 - 16*cs2: no wrap before the group ends
+    const int w = ic0 >> 4;
+    const uint32_t lo = s_str[J * STR_WORDS + w];
+    const uint32_t hi = s_str[J * STR_WORDS + ((w + 1) & (STR_WORDS - 1))];
+    g.W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(ic0 & 15) << 1) ^ GAL_SIGN_MASK((c.st >> 10) & 3u);
+    g.m = -2 * ic0;
+}
+
+template <int J>
+__device__ __forceinline__ void group_begin_slow(const ChanState &c, ChanGroup &g, const uint32_t *s_str)
 {
     const bool pend = c.y >= 8184.0;  // wrap pending: the first sample of the group takes it (:491-507)
     const double ye = pend ? c.y - 8184.0 : c.y;
-    const int chip0 = ((int)ye) >> 1;
-    const int w0 = chip0 >> 5;
-    const uint32_t hi = ~0u << (chip0 & 31);
-    const uint32_t sg_cur = (c.st >> (pend ? 12 : 10)) & 3u;
-    const uint32_t sg_nxt = (w0 == 127) ? ((c.st >> 12) & 3u) : sg_cur;
-    const uint2 a = s_win[J * WIN_WORDS + w0];
-    const uint2 b = s_win[J * WIN_WORDS + ((w0 + 1) & 127)];
-    const uint32_t d0 = a.x ^ (0u - (sg_cur & 1u)), d1 = b.x ^ (0u - (sg_nxt & 1u));
-    const uint32_t c0 = a.y ^ (0u - (sg_cur >> 1)), c1 = b.y ^ (0u - (sg_nxt >> 1));
-    g.wD = (d0 & hi) | (d1 & ~hi);
-    g.wC = (c0 & hi) | (c1 & ~hi);
-    g.y0 = c.y;
+    const int ic0 = (int)ye;
+    const int w = ic0 >> 4;
+    const uint32_t lo = s_str[J * STR_WORDS + w];
+    const uint32_t hi = s_str[J * STR_WORDS + ((w + 1) & (STR_WORDS - 1))];
+    const uint32_t head = s_str[J * STR_WORDS];
+    const uint32_t sg_nxt = (c.st >> 12) & 3u;
+    const uint32_t sg_cur = pend ? sg_nxt : ((c.st >> 10) & 3u);
+    uint32_t W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(ic0 & 15) << 1) ^ GAL_SIGN_MASK(sg_cur);
+    // half chips from jw on belong to the next code period: stream start, next symbol's signs
+    const int jw = 8184 - ic0;
+    const bool splice = jw < 16;
+    const uint32_t sh = (uint32_t)(2 * jw) & 31u;
+    const uint32_t keep = splice ? ((1u << sh) - 1u) : ~0u;
+    const uint32_t tail = splice ? ((head ^ GAL_SIGN_MASK(sg_nxt)) << sh) : 0u;
+    g.W = (W & keep) | tail;
+    // a pending wrap is taken by the first sample, which switches m to mw like any other wrap
+    g.mw = -2 * ic0 + (pend ? 0 : 16);
+    g.m = g.mw - 16;
 }
 
-// One sample of one channel, src/galileo-sdr.cpp:491-532, branch-free.  Returns ip + (qp << 16).
-// cs2 = 2 * f_code * delt.  s_lut2 points at entry k = 0 of the first of FOUR 1024-entry tables indexed by
-// k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0, -LUT[k & 511].  The two's-complement
-// mask of :509-510, the sign and the zero case of v are all folded into the LDS address.
+// One sample of one channel, src/galileo-sdr.cpp:509-532, branch-free, for a group without a code wrap.
+// Returns ip + (qp << 16).  cs2 = 2 * f_code * delt.  s_lut2 points at entry k = 0 of the first of FOUR
+// 1024-entry tables indexed by k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0,
+// -LUT[k & 511].  The two's-complement mask of :509-510, the sign and the zero case of v are all folded into
+// the LDS address.
 __device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
                                          const int *s_lut2)
 {
-    // --- symbol advance, :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact); the
-    //     symbol counter is advanced in the group epilogue
-    const bool ge = c.y >= 8184.0;
-    c.y = c.y - (ge ? 8184.0 : 0.0);
-    // --- chip lookup, :512-515.  boc[2c] = -chip, boc[2c+1] = +chip (src/gal-sig.cpp:198-213)
+    // --- chip lookup, :512-521: icode = (int)(2x); selector bits of that half chip
     const int ic = (int)c.y;
-    const uint32_t sh = ((uint32_t)ic >> 1) & 31u;
-    // v = E1B*d - E1C*s in {-2,0,+2}, times the BOC half-chip sign (:517-521); signs are in the windows
-    const uint32_t nz = __builtin_amdgcn_ubfe(g.wD, sh, 1);     // v != 0   (v_bfe_u32: shift and mask in one)
-    const uint32_t neg = ((g.wC >> sh) ^ (uint32_t)ic) & 1u;    // v < 0
+    int off;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(ic), "v"(g.m));
+    const uint32_t q = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);  // v_bfe_u32 uses offset[4:0]
     // --- carrier LUT, :509-510: trunc toward zero (mask, sign and zero folded into the table choice)
-    int a4 = (int)(511.0 * c.p) << 2;                           // byte offset of entry k in table 0
-    // two fused shift-adds pick the table (spelled in asm: the combiner otherwise re-associates them into
-    // three shifts, two masks and a three-way add)
-    asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(nz), "v"(a4));
-    asm("v_lshl_add_u32 %0, %1, 13, %2" : "=v"(a4) : "v"(neg), "v"(a4));
+    int a4 = (int)(511.0 * c.p) << 2;  // byte offset of entry k in table 0
+    // (spelled in asm: the combiner otherwise re-associates the shift-add into shifts, masks and an add3)
+    asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(q), "v"(a4));
     const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_lut2) + a4);
     // --- NCO updates, :528-532
     c.y = c.y + cs2;
@@ -761,11 +786,22 @@ __device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const
     return t;
 }
 
+// The same with the symbol advance of :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact);
+// the symbol counter is advanced in the group epilogue.
+__device__ __forceinline__ int chan_step_wrap(ChanState &c, ChanGroup &g, const double cs2, const double ds,
+                                              const int *s_lut2)
+{
+    const bool ge = c.y >= 8184.0;
+    c.y = c.y - (ge ? 8184.0 : 0.0);
+    g.m = ge ? g.mw : g.m;
+    return chan_step(c, g, cs2, ds, s_lut2);
+}
+
 template <int J>
 __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, const DevPlan *Pd, const uint8_t *act,
                                           int e)
 {
-    if (__builtin_expect(c.y < g.y0, 0)) {  // the code wrapped inside this group (once per 4 ms of signal)
+    if (__builtin_expect(g.m == g.mw, 0)) {  // the code wrapped inside this group (once per 4 ms of signal)
         const int idx = e * Pd->S + (int)act[J];
         c.st = sym_state(Pd, idx, (int)(c.st & 0x1ffu) + 1, (int)((c.st >> 9) & 1u));
     }
@@ -779,12 +815,12 @@ __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, cons
 
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
 template <int NCH, bool ACC>
-__global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
+__global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_WAVES))) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
                                                      const uint8_t *__restrict__ act_all,
                                                      const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
 {
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
-    __shared__ uint2 s_win[NCH * WIN_WORDS];
+    __shared__ uint32_t s_str[NCH * STR_WORDS];
     __shared__ int s_lut[4 * 1024];  // table q = nz | neg<<1, entry k + 512: {0, +LUT, 0, -LUT}[q][k & 511]
     const int *s_lut2 = s_lut + 512;
 
@@ -800,8 +836,8 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
     }
     for (int j = 0; j < nact; ++j) {
         const int prn = Pd->prn[e * G.S + act[j]];
-        const uint2 *src = Pd->win + (size_t)(prn - 1) * WIN_WORDS;
-        for (int i = tid; i < WIN_WORDS; i += SYN_BLOCK) s_win[j * WIN_WORDS + i] = src[i];
+        const uint32_t *src = Pd->str + (size_t)(prn - 1) * STR_WORDS;
+        for (int i = tid; i < STR_WORDS; i += SYN_BLOCK) s_str[j * STR_WORDS + i] = src[i];
     }
     __syncthreads();
 
@@ -815,7 +851,6 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
     // per-thread arrays into wide vector registers and copies whole tuples around every conditional update.
 #define GAL_DECL(j)                                                                         \
     ChanState ch##j = {0.0, 0.0, 0u};                                                       \
-    ChanGroup gr##j = {0u, 0u, 0.0};                                                        \
     double cs##j = 0.0, ds##j = 0.0;                                                        \
     if (j < NCH && j < nact) {                                                              \
         const int idx = __builtin_amdgcn_readfirstlane(e * G.S + (int)act[j]);              \
@@ -829,6 +864,13 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
     }
     GAL_CH_LIST(GAL_DECL)
 #undef GAL_DECL
+    // one threshold for all channels: y below it cannot reach the wrap within 16 samples (the code rates of
+    // the channels differ by parts per million, so the largest step serves all)
+    double csmax = 0.0;
+#define GAL_CSMAX(j) if (j < NCH) csmax = cs##j > csmax ? cs##j : csmax;
+    GAL_CH_LIST(GAL_CSMAX)
+#undef GAL_CSMAX
+    const double thr = uniform_f64(8184.0 - 16.0 * csmax);
 
     uint32_t *out = iq + (size_t)e * G.N + n0;
     // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
@@ -836,29 +878,50 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
     // bursts at 1.2x: tools/wrcal.hip).
     const bool vec_ok = ((((size_t)e * G.N + n0) & 15) == 0);
 
-#define GAL_BEGIN(j) if (j < NCH && j < nact) group_begin<j>(ch##j, gr##j, s_win);
-// idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 and signs 0 give a
-// zero contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
-#define GAL_STEP(j) if (j < NCH) acc += chan_step(ch##j, gr##j, cs##j, ds##j, s_lut2);
+// idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 gives a zero
+// contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
+#define GAL_NEAR(j) if (j < NCH && j < nact) near |= ch##j.y >= thr;
+#define GAL_BEGIN_F(j) if (j < NCH && j < nact) group_begin_fast<j>(ch##j, gr##j, s_str);
+#define GAL_BEGIN_S(j) if (j < NCH && j < nact) group_begin_slow<j>(ch##j, gr##j, s_str);
+#define GAL_STEP_F(j) if (j < NCH) acc += chan_step(ch##j, gr##j, cs##j, ds##j, s_lut2);
+#define GAL_STEP_S(j) if (j < NCH) acc += chan_step_wrap(ch##j, gr##j, cs##j, ds##j, s_lut2);
 #define GAL_END(j) if (j < NCH && j < nact) group_end<j>(ch##j, gr##j, Pd, act, e);
+// pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
+// (all NCO chains first, all accumulates last) and spills hundreds of values
+#define GAL_PIN(a, b, c, d)                                                                              \
+    asm volatile("" : "+v"(acc), "+v"(ch##a.y), "+v"(ch##a.p), "+v"(ch##b.y), "+v"(ch##b.p),             \
+                      "+v"(ch##c.y), "+v"(ch##c.p), "+v"(ch##d.y), "+v"(ch##d.p));
 // The channels are replayed four at a time over the whole group (accumulating into o[]): four independent
 // dependency chains give the scheduler enough ILP to cover FP64 and LDS latency, while only four channels'
-// group temporaries are live at once (<= 128 VGPRs -> 4 waves/SIMD).  sched_barrier keeps the parts apart.
-#define GAL_PART(a, b, c, d)                         \
-    if (a < NCH) {                                   \
-        GAL_BEGIN(a) GAL_BEGIN(b) GAL_BEGIN(c) GAL_BEGIN(d) \
-        _Pragma("unroll") for (int u = 0; u < GSZ; ++u) \
-        {                                            \
-            int acc = o[u];                          \
-            GAL_STEP(a) GAL_STEP(b) GAL_STEP(c) GAL_STEP(d) \
-            /* pin the step: without this the instruction selector floats the pure-arithmetic parts of all  \
-               16 steps apart (all NCO chains first, all accumulates last) and spills hundreds of values */ \
-            asm volatile("" : "+v"(acc), "+v"(ch##a.y), "+v"(ch##a.p), "+v"(ch##b.y), "+v"(ch##b.p),        \
-                              "+v"(ch##c.y), "+v"(ch##c.p), "+v"(ch##d.y), "+v"(ch##d.p));                   \
-            o[u] = acc;                              \
-        }                                            \
-        GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)  \
-        __builtin_amdgcn_sched_barrier(0);           \
+// group temporaries are live at once.  sched_barrier keeps the parts apart.  `near` is wave-uniform after the
+// ballot: no lane of the wave has any of the four codes within 16 samples of its wrap -> fast body.
+#define GAL_PART(a, b, c, d)                                                     \
+    if (a < NCH) {                                                               \
+        ChanGroup gr##a = {0u, 0, 1}, gr##b = {0u, 0, 1};                        \
+        ChanGroup gr##c = {0u, 0, 1}, gr##d = {0u, 0, 1};                        \
+        bool near = (GSZ != SYN_GROUP);                                          \
+        GAL_NEAR(a) GAL_NEAR(b) GAL_NEAR(c) GAL_NEAR(d)                          \
+        if (__builtin_amdgcn_ballot_w64(near) == 0) {                            \
+            GAL_BEGIN_F(a) GAL_BEGIN_F(b) GAL_BEGIN_F(c) GAL_BEGIN_F(d)          \
+            _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
+            {                                                                    \
+                int acc = o[u];                                                  \
+                GAL_STEP_F(a) GAL_STEP_F(b) GAL_STEP_F(c) GAL_STEP_F(d)          \
+                GAL_PIN(a, b, c, d)                                              \
+                o[u] = acc;                                                      \
+            }                                                                    \
+        } else {                                                                 \
+            GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)          \
+            _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
+            {                                                                    \
+                int acc = o[u];                                                  \
+                GAL_STEP_S(a) GAL_STEP_S(b) GAL_STEP_S(c) GAL_STEP_S(d)          \
+                GAL_PIN(a, b, c, d)                                              \
+                o[u] = acc;                                                      \
+            }                                                                    \
+            GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)                          \
+        }                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                       \
     }
 
     int s0 = 0;
@@ -904,8 +967,12 @@ __global__ __launch_bounds__(SYN_BLOCK) void k_synth(const DevPlan *__restrict__
         out[s0] = GAL_PACK(o[0]);
     }
 #undef GAL_PART
-#undef GAL_BEGIN
-#undef GAL_STEP
+#undef GAL_PIN
+#undef GAL_NEAR
+#undef GAL_BEGIN_F
+#undef GAL_BEGIN_S
+#undef GAL_STEP_F
+#undef GAL_STEP_S
 #undef GAL_END
 
     // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit.

@@ -33,7 +33,7 @@ def test_full_epoch_size_bit_exact(pkg):
     """Reference geometry: 260000 samples per epoch, 12 channels, several epochs."""
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=12, n_slots=16, samples_per_epoch=260000, seed=5)
     iq, st, stats = _compare(pkg, p, 260000)
-    assert stats["chunk_samples"] == 1024 and stats["chunks_per_epoch"] == 254
+    assert stats["chunk_samples"] == 1040 and stats["chunks_per_epoch"] == 250  # chunk divides the code period
 
 
 def test_page_flip_mid_epoch(pkg):
@@ -69,6 +69,34 @@ def test_ragged_sizes(pkg):
     for n_samp, chunk in [(1000, 0), (2604, 0), (26000, 100), (26000, 252), (4096, 4)]:
         p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=5, n_slots=8, samples_per_epoch=n_samp, seed=n_samp)
         _compare(pkg, p, n_samp, chunk_samples=chunk)
+
+
+@pytest.mark.parametrize("rate", [2.047e6, 2.2e6, 4.092e6, 10e6])
+def test_sample_rates_window_limits(pkg, rate):
+    """The 16-half-chip window of k_synth is full at f_code/fs = 0.5 (2.047 MS/s: 15.99 half chips per 16
+    samples); high rates give groups that stay inside one chip.  The reference fixes 2.6 MS/s
+    (include/constants.h:96); the loop itself is rate-agnostic and so is the oracle."""
+    n_samp = int(rate / 100)  # 10 ms epochs: 2.5 code periods each
+    p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=6, n_slots=8, samples_per_epoch=n_samp, sample_rate=rate,
+                                     seed=int(rate) % 1000)
+    _compare(pkg, p, n_samp, rate=rate)
+    _compare(pkg, p, n_samp, rate=rate, chunk_samples=64)
+
+
+def test_code_wrap_at_every_group_position(pkg):
+    """Code phases chosen so that the wrap (x >= 4092) falls on each of the 16 positions of a sample group,
+    including the first sample (wrap pending from the previous group) and the first sample of a chunk."""
+    n_samp, n_slots = 4160, 16  # 4 chunks of 1040 when chunk_samples=1040
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=16, n_slots=n_slots, samples_per_epoch=n_samp, seed=77)
+    step = p["f_code"][0] / 2.6e6
+    for j in range(n_slots):
+        # wrap just before sample 1040 + j of the first epoch
+        p["code_phase0"][0, j] = 4092.0 - (1040 + j) * step[j] + 0.25 * step[j]
+    for chunk in (1040, 0, 16):
+        with pkg.SynthEngine(samples_per_epoch=n_samp, n_slots=n_slots, device=0, chunk_samples=chunk) as eng:
+            iq, st, stats = eng.run_host(p[:1])
+        ref_iq, _ = oracle_run(p[:1], n_samp, 2.6e6)
+        assert np.array_equal(iq, ref_iq), chunk
 
 
 def test_channel_comes_and_goes_and_state_carry(pkg):
@@ -121,6 +149,10 @@ def test_invalid_batches_are_rejected(pkg):
             eng.run_host(bad)
         bad = p.copy()
         bad["ibit0"][0, 0] = 500
+        with pytest.raises(pkg.GalSynthError):
+            eng.run_host(bad)
+        bad = p.copy()
+        bad["f_code"][1, 0] = 1.31e6  # more than half a chip per sample: outside the half-chip window
         with pytest.raises(pkg.GalSynthError):
             eng.run_host(bad)
 
