@@ -135,7 +135,42 @@ struct WalkOut {
     double p;       // phase after the last sample
     int last_w;     // local index after the last wrapping step, -1 if the walk never wrapped
     double last_r;  // phase at last_w
+    double margin;  // min distance of any visited state to the boundaries of its own binade (see below)
+    int tdir;       // first wrap whose rounded add was a TIE (sum exactly between two grid points of [1,2)):
+                    // +1 / -1 = the add rounded up / down (rounded minus exact sum), 0 = no tie in this walk.
+                    // A trajectory shifted by an ODD multiple of 2^-52 resolves that tie the other way: from
+                    // there on it is off by the shift minus tdir * 2^-52 (an even multiple: later ties agree).
 };
+
+// Distance of the states of one closed-form batch to their binade's boundaries.  a and b are the first and
+// the last state of the batch (the batch never leaves the binade, so the extremes are at its ends; a == b
+// for an empty batch).  Used for TRANSLATED acceptance in the stitcher: if a whole trajectory is shifted by
+// delta (a multiple of 2^-52, |delta| below this margin) every rounded add sees the same binade, hence the
+// same rounding grid, and -- outside tie epochs -- yields the same result shifted by delta, bit for bit.
+GAL_HD double binade_margin(double a, double b)
+{
+    const uint64_t ua = d2u(a) & ~kSign, ub = d2u(b) & ~kSign;
+    const uint64_t ulo = ua < ub ? ua : ub, uhi = ua < ub ? ub : ua;
+    const double lo = u2d(ulo), hi = u2d(uhi);
+    const double pk = u2d(ulo & 0xfff0000000000000ull);  // binade floor (0 for zero / subnormal: margin 0)
+    const double m1 = lo - pk, m2 = (pk + pk) - hi;
+    return m1 < m2 ? m1 : m2;
+}
+
+// Can a wrap step with this carrier step land exactly between two grid points of [1,2) (spacing 2^-52)?
+// Phases in [0.5,1) are multiples of 2^-53, so the sum is an odd multiple of 2^-53 only if the step is a
+// multiple of 2^-53 itself: an odd one ties at every wrap, an even one at most at the first wrap of its epoch
+// (the phase it inherits may carry the 2^-53 bit; after a wrap everything is a multiple of 2^-52).  How such a
+// tie resolves depends on the parity of the phase, which a shift by an odd multiple of 2^-52 flips -- legs that
+// touch such an epoch are never accepted by translation.  Steps of a quarter cycle or more may wrap from a
+// lower binade: treated as tie-prone wholesale.
+GAL_HD bool tie_step(double d)
+{
+    const double ad = d < 0.0 ? -d : d;
+    if (!(ad < 0.25)) return true;
+    const double t53 = ad * 9007199254740992.0;  // * 2^53, exact
+    return t53 == (double)(long long)t53;
+}
 
 template <class Emit>
 GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, int cp0, Emit emit)
@@ -146,6 +181,9 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
     WalkOut o;
     o.last_w = -1;
     o.last_r = 0.0;
+    o.tdir = 0;
+    const bool tieprone = tie_step(d);
+    double mg = 4.0;
     while (i < N) {
         if (next_cp == i) {
             emit(c, p);
@@ -154,18 +192,29 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
         }
         const int stop = next_cp < N ? next_cp : N;  // never run past a checkpoint or the end
         const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
+        const double a = p;
         p = fma_exact((double)b.n, b.inc, p);
+        const double m = binade_margin(a, p);
+        mg = m < mg ? m : mg;
         i += b.n;
         if (i < stop) {
             const double q = p + d;
             const double t = __builtin_trunc(q);
+            const bool wrapped = t != 0.0;
+            if (tieprone && wrapped && o.tdir == 0) {  // rare: only steps that are multiples of 2^-53
+                const double bv = q - p;               // TwoSum: err = (p + d) - q exactly
+                const double err = (p - (q - bv)) + (d - bv);
+                if (err == 1.1102230246251565e-16) o.tdir = -1;   // exact sum above q: rounded down
+                if (err == -1.1102230246251565e-16) o.tdir = 1;   // rounded up
+            }
             p = q - t;  // == carr_step(p, d)
             ++i;
-            const bool wrapped = t != 0.0;
             o.last_w = wrapped ? i : o.last_w;
             o.last_r = wrapped ? p : o.last_r;
         }
     }
+    const double m = binade_margin(p, p);  // the state handed over
+    o.margin = m < mg ? m : mg;
     o.p = p;
     return o;
 }

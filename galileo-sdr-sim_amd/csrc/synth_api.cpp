@@ -100,6 +100,7 @@ struct gal_synth {
     void *own_iq = nullptr;
     size_t own_iq_bytes = 0;
     int *h_ctr = nullptr;  // pinned
+    int64_t legs_walked = 0, legs_translated = 0, n_fallbacks = 0;  // last finish(): carrier legs walked / translated
     gal_chan_state_t *h_state = nullptr;  // pinned [S]
     gal_synth_stats_t stats{};
 };
@@ -377,6 +378,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmw = take(LEGS * S * 8),
                  o_clmr = take(LEGS * S * 8);
     const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
+    const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tiep = take(LEGS * S),
+                 o_tdir = take(LEGS * S);
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ctr = take(CTR_COUNT * 4);
 
@@ -411,6 +414,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.clm_w = (long long *)(base + o_clmw); P.clm_r = (double *)(base + o_clmr);
     P.pend = (double *)(base + o_pend);
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
+    P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tiep = (uint8_t *)(base + o_tiep);
+    P.tdir = (int8_t *)(base + o_tdir);
+    P.translate = 1;
+    if (const char *env = getenv("GAL_WALK_TRANSLATE")) P.translate = atoi(env) != 0;  // test hook
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
 
@@ -551,11 +558,48 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         ms_walk += ms_synth;  // the first, speculative synthesis was wasted work
         ms_synth = extra;
     }
+    if (ctr_end[CTR_MISMATCH] != 0 && P->translate) {
+        // The replay kernel found a checkpoint that genuine stepping does not reproduce.  The only unverified-
+        // by-walking inputs are the TRANSLATED legs: redo the carrier chain with every leg walked and verified
+        // bitwise, then the synthesis.  (Never observed; kept so that a flaw in the translation argument can
+        // cost time but not correctness.)
+        DevPlan Pw = *P;
+        Pw.translate = 0;
+        const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
+        HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), st));
+        galk_launch_carr_guess(&Pw, st);
+        int first = 1;
+        do {
+            if (!first && ctr_walk[CTR_PASSES] >= max_passes)
+                return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes", ctr_walk[CTR_PASSES]);
+            for (int k = 0; k < 2; ++k) {
+                galk_launch_walk_carr(&Pw, first, st);
+                galk_launch_carr_scan(&Pw, st);
+                first = 0;
+            }
+            HIP_TRY(hipMemcpyAsync(ctr_walk, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        } while (ctr_walk[CTR_UNVERIFIED] != 0);
+        galk_launch_state_phase(P, st);
+        HIP_TRY(hipEventRecord(h->ev[1], st));
+        int rc = enqueue_synth(h, h->last_iq);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(h->ev[2], st));
+        HIP_TRY(hipMemcpyAsync(ctr_end, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float extra = 0;
+        hipEventElapsedTime(&extra, h->ev[1], h->ev[2]);
+        ms_walk += ms_synth;
+        ms_synth = extra;
+        h->n_fallbacks += 1;
+    }
     h->stats.walk_passes = ctr_end[CTR_PASSES];
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;
+    h->legs_walked = ctr_end[CTR_WALKS];
+    h->legs_translated = ctr_end[CTR_SHIFTS];
     if (stats) *stats = h->stats;
     if (state_out) {
         HIP_TRY(hipMemcpy(state_out, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost));
@@ -563,6 +607,15 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     if (h->stats.chain_mismatch != 0)
         return fail(GAL_E_CHAIN, "replay kernel disagreed with the NCO walker at %d chunk boundaries",
                     h->stats.chain_mismatch);
+    return GAL_OK;
+}
+
+int gal_synth_walk_counts(const gal_synth_t *h, int64_t *legs_walked, int64_t *legs_translated, int64_t *fallbacks)
+{
+    if (!h) return fail(GAL_E_INVAL, "null handle");
+    if (legs_walked) *legs_walked = h->legs_walked;
+    if (legs_translated) *legs_translated = h->legs_translated;
+    if (fallbacks) *fallbacks = h->n_fallbacks;
     return GAL_OK;
 }
 

@@ -8,7 +8,7 @@
 
 #include "../../include/galsynth.h"
 
-enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_UNVER_NEXT = 3, CTR_COUNT = 4 };
+enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_UNVER_NEXT = 3, CTR_WALKS = 4, CTR_SHIFTS = 5, CTR_COUNT = 6 };
 
 // Everything lives in HBM; [E][S] arrays are indexed e * S + s.
 struct DevPlan {
@@ -51,7 +51,12 @@ struct DevPlan {
     double *clm_r;
     double *pend;        // phase after the leg's last sample (that walk)
     uint8_t *verified;
-    uint8_t *dirty;
+    uint8_t *dirty;      // 0 clean, 1 walk again from the new anchor, 2 translate by `shift` instead of walking
+    double *marg;        // min distance of the leg's walked states to their binade boundaries (nco_walk.h)
+    uint8_t *tiep;       // the walk touched a tie-prone epoch: translated only by even multiples of 2^-52
+    int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
+    double *shift;       // pending translation (new anchor residual - walked anchor residual)
+    int translate;       // 0: always re-walk (fallback / tests)
 
     // checkpoints, one per chunk + end state
     double *cp_x;     // [E][S][CP1]

@@ -226,12 +226,35 @@ __global__ void k_walk_carr(DevPlan P, int first)
         P.anc_r[li] = p;
         P.verified[li] = 0;
     } else {
-        if (!P.dirty[li]) return;
+        const int dk = P.dirty[li];
+        if (!dk) return;
+        if (dk == 2) {
+            // TRANSLATED acceptance: the stitcher moved the anchor by `shift` (same wrap event, a multiple of
+            // 2^-52 smaller than the leg's binade margin, no tie-prone epoch on the way): a walk from the new
+            // anchor would visit the same binades step by step, so every state it produces is the old one
+            // plus the shift, bit for bit (nco_walk.h: binade_margin).  k_synth's replay check covers it.
+            const double dl = P.shift[li];
+            int nck = P.nchunks - w * P.Lc;
+            nck = nck > P.Lc ? P.Lc : nck;
+            double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
+            for (int c = 0; c < nck; ++c) cpp[c] += dl;
+            if (w == P.W - 1) cpp[nck] += dl;
+            P.pend[li] += dl;
+            if (P.clm_w[li] >= 0) P.clm_r[li] += dl;
+            P.marg[li] -= __builtin_fabs(dl);
+            P.dirty[li] = 0;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_SHIFTS], __builtin_popcountll(m));
+            return;
+        }
         cur = P.anc_w[li];
         p = P.anc_r[li];
     }
     long long lw = -1;
     double lr = 0.0;
+    double mg = 4.0;
+    bool tiep = false;
+    int tdir = 0;
     while (cur < A) {  // anchor -> leg start
         const int ec = (int)(cur / P.N);
         long long seg_end = (long long)(ec + 1) * P.N;
@@ -243,6 +266,9 @@ __global__ void k_walk_carr(DevPlan P, int first)
             lw = cur + o.last_w;
             lr = o.last_r;
         }
+        mg = o.margin < mg ? o.margin : mg;
+        tiep |= tie_step(d);
+        tdir = tdir ? tdir : o.tdir;
         p = o.p;
         cur = seg_end;
     }
@@ -259,7 +285,12 @@ __global__ void k_walk_carr(DevPlan P, int first)
     P.pend[li] = o.p;
     P.clm_w[li] = lw;  // -1: no wrap between the anchor and the end of the leg
     P.clm_r[li] = lr;
+    P.marg[li] = o.margin < mg ? o.margin : mg;
+    P.tiep[li] = (tiep || tie_step(d)) ? 1 : 0;
+    P.tdir[li] = (int8_t)(tdir ? tdir : o.tdir);
     P.dirty[li] = 0;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
 }
 
 // k_carr_scan: one 256-thread block per slot stitches the legs.  Sequential statement (what the three
@@ -269,11 +300,12 @@ __global__ void k_walk_carr(DevPlan P, int first)
 //                       link_ok   =  anchor_i bitwise == (lc_w, lc_r)  and the leg was walked from it
 //                       allok    &=  link_ok ;   verified_i = allok
 //                       new anchor = (lc_w, lc_r + D)            (predicted true value of that claim)
-//                       D_leg     =  new anchor - old anchor      (0 if it is a different wrap event)
-//                       leg saw a wrap -> (lc_w, lc_r) = its claim, D = D_leg   (else the state is inherited)
-// A leg is accepted only through bitwise equality with the verified chain, so the shift heuristic (rounded-
-// add chains commute with shifts by multiples of 2^-52 while the itinerary is unchanged; 2^-51 in "tie
-// epochs" whose step is an odd multiple of 2^-53) affects the number of passes, never the result.
+//                       t         =  new anchor - old anchor      (0 if it is a different wrap event)
+//                       leg saw a wrap -> (lc_w, lc_r) = its claim, D = tie_flip(t)   (else inherited)
+// A leg is accepted only through bitwise equality with the verified chain; the prediction (rounded-add chains
+// commute with shifts by multiples of 2^-52 while the itinerary is unchanged, up to the tie flip) decides how
+// many passes are needed, and -- for legs accepted by translation -- rests on nco_walk.h: binade_margin, with
+// k_synth's replay check behind it.
 struct ClaimState {
     int kind;  // 0 nothing yet, 1 defined, 2 chain broken (idle epoch)
     long long w;
@@ -282,6 +314,7 @@ struct ClaimState {
 
 struct LegRec {
     bool act, root, dirty, hw;
+    int tdir;
     long long A, aw, cw;
     double ar, cr, known;
 };
@@ -302,22 +335,24 @@ __device__ __forceinline__ LegRec leg_load(const DevPlan &P, int s, int i, doubl
     L.cw = P.clm_w[li];
     L.cr = P.clm_r[li];
     L.hw = L.act && L.cw >= 0;
+    L.tdir = P.tdir[li];
     L.dirty = L.act && P.dirty[li] != 0;
     return L;
 }
 
 // The pending correction D travels along the chain as   D <- D + c[(D / 2^-52) mod 4]   per wrap-bearing leg:
-// normally c = G (the gap between the claim and the anchor that was walked, a multiple of 2^-52); in a tie
-// epoch D is first rounded to a multiple of 2^-51, ties to even, which depends on D only through
-// D mod 2^-50.  Such maps (plus "reset to a constant") are closed under composition, so the fold over many
-// legs is a 4-entry table and the block scan reproduces the sequential statement exactly.
+// a leg that was walked from an anchor G below the claim in front of it is off by t = G + D, a multiple of
+// 2^-52, all the way -- except that an ODD t flips the first tie its walk met (nco_walk.h: WalkOut::tdir),
+// after which it is off by t - tdir * 2^-52.  Such maps (plus "reset to a constant") are closed under
+// composition, so the fold over many legs is a 4-entry table and the block scan reproduces the sequential
+// statement exactly.
 #define GAL_U52 2.220446049250313e-16  // 2^-52
 
 __device__ __forceinline__ int d_residue(double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); }
 
-__device__ __forceinline__ double tie_round(double D)  // to a multiple of 2^-51, ties to even (exact)
+__device__ __forceinline__ double tie_flip(double t, int tdir)
 {
-    return (D + 3.0) - 3.0;
+    return (tdir != 0 && (d_residue(t) & 1)) ? t - (double)tdir * GAL_U52 : t;
 }
 
 struct DMap {
@@ -350,7 +385,8 @@ __device__ __forceinline__ DMap dmap_combine(const DMap &a, const DMap &b)  // a
 
 // What one leg does to the chain, given the claim state `lc` in front of it (exact, from sweep 1).
 struct LegOp {
-    bool act, root, have, link_ok, hw, same, tie;
+    bool act, root, have, link_ok, hw, same;
+    int tdir;
     long long nw;  // event the leg should be anchored at
     double base;   // its residual before the pending correction is added
     double G;      // gap: claim residual minus the anchor residual that was walked (same event only)
@@ -361,7 +397,7 @@ __device__ __forceinline__ LegOp leg_op(const DevPlan &P, int s, const LegRec &L
     LegOp o;
     o.act = L.act;
     o.root = L.root;
-    o.have = false; o.link_ok = false; o.hw = false; o.same = false; o.tie = false;
+    o.have = false; o.link_ok = false; o.hw = false; o.same = false; o.tdir = L.tdir;
     o.nw = 0; o.base = 0.0; o.G = 0.0;
     if (!L.act) {
         lc.kind = 2;
@@ -374,13 +410,6 @@ __device__ __forceinline__ LegOp leg_op(const DevPlan &P, int s, const LegRec &L
     }
     o.have = lc.kind == 1;
     o.link_ok = o.have && !L.dirty && L.aw == lc.w && d2u(L.ar) == d2u(lc.r);
-    {  // tie epochs quantise phase differences to multiples of 2^-51 at every wrap
-        long long ea = lc.w > 0 ? (lc.w - 1) / P.N : 0;
-        ea = ea < P.E ? ea : P.E - 1;
-        const double dp = P.dstep[(int)ea * P.S + s];
-        const double t53 = dp * 9007199254740992.0;  // * 2^53, exact
-        o.tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
-    }
     o.nw = lc.w;
     o.base = lc.r;
     o.same = o.have && L.aw == lc.w;
@@ -400,7 +429,7 @@ __device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
     if (o.root) D = 0.0;
     if (!o.hw) return D;
     if (!o.same) return 0.0;
-    return o.G + (o.tie ? tie_round(D) : D);
+    return tie_flip(o.G + D, o.tdir);
 }
 
 #define SCAN_THREADS 1024
@@ -554,16 +583,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
                 D = 0.0;
             }
             allok &= o.link_ok ? 1 : 0;
-            const double nr = o.base + (o.tie ? tie_round(D) : D);
+            const double nr = o.base + D;
             const size_t li = (size_t)s * P.LEGS + i;
             if (allok) {
                 P.verified[li] = 1;
             } else {
                 ++unver;
                 if (o.have && (L.aw != o.nw || d2u(L.ar) != d2u(nr))) {
+                    // same wrap event, only its residual moved: translate the leg instead of walking it again
+                    // when the move is provably itinerary-preserving (k_walk_carr, dirty == 2)
+                    const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
+                    const bool tr = P.translate && L.aw == o.nw && (!P.tiep[li] || !(d_residue(dl) & 1)) &&
+                                    __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
                     P.anc_w[li] = o.nw;
                     P.anc_r[li] = nr;
-                    P.dirty[li] = 1;
+                    P.dirty[li] = tr ? 2 : 1;
+                    if (tr) P.shift[li] = dl;
                 }
             }
             D = leg_d_out(o, D);

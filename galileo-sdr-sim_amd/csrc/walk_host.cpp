@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "nco_walk.h"
@@ -99,9 +101,18 @@ void galwalk_code_brute(double x, int ibit, double c, int N, int R, double *cpx,
 extern "C" {
 int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t *flags, const double *p0,
                                  const double *dstep, double start0, int max_passes, double *pend_out,
-                                 long *walks, int *unver_hist, int nthreads)
+                                 long *walks, int *unver_hist, int nthreads, int R, double *cp_out, int translate,
+                                 long *shifts)
 {
+    // R > 0: checkpoints every R samples inside each leg go to cp_out[leg * (L / R) + c] (L % R == 0);
+    // translate != 0: legs whose anchor residual merely moved are shifted instead of walked again
+    // (synth_kernels.hip: k_walk_carr dirty == 2 / k_carr_scan sweep 3)
     const int LEGS = E * W;
+    const int Lc = R > 0 ? L / R : 0;
+    std::vector<double> marg(LEGS, 0.0), shift(LEGS, 0.0);
+    std::vector<uint8_t> tiep(LEGS, 0);
+    std::vector<int> tdir(LEGS, 0);
+    long nshift = 0;
     std::vector<double> pg(E, 0.0), rs(LEGS, 0.0), rc(LEGS, 0.0), pend(LEGS, 0.0);
     std::vector<long long> ws(LEGS, 0), wc(LEGS, -1);
     std::vector<uint8_t> ver(LEGS, 0), dirty(LEGS, 0), hw(LEGS, 0);
@@ -139,10 +150,44 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                 else { ws[i] = gw[e]; rs[i] = gr[e]; }
                 ver[i] = 0;
             } else if (!dirty[i]) continue;
+            int n = N - w * L;
+            if (n > L) n = L;
+            if (!first && dirty[i] == 2) {  // translated acceptance
+                const double dl = shift[i];
+                if (cp_out) for (int c = 0; c * R < n; ++c) cp_out[(size_t)i * Lc + c] += dl;
+                pend[i] += dl;
+                if (getenv("GALWALK_DEBUG")) {
+                    long long cur = ws[i];
+                    double p = rs[i];
+                    double mg2 = 4.0;
+                    while (cur < A) {
+                        const int ec = (int)(cur / N);
+                        long long seg_end = (long long)(ec + 1) * N;
+                        if (seg_end > A) seg_end = A;
+                        const int nn = (int)(seg_end - cur);
+                        const WalkOut o = carr_walk_track(p, dstep[ec], 1.0 / __builtin_fabs(dstep[ec]), nn, nn, nn, [](int, double) {});
+                        mg2 = std::min(mg2, o.margin);
+                        p = o.p;
+                        cur = seg_end;
+                    }
+                    const WalkOut o = carr_walk_track(p, dstep[e], 1.0 / __builtin_fabs(dstep[e]), n, n, n, [](int, double) {});
+                    if (d2u(o.p) != d2u(pend[i]))
+                        fprintf(stderr, "TRANSLATE MISMATCH leg %d (e %d w %d) anchor %lld r_new %a dl %a marg(before) %a marg_newwalk %a A %lld d %a pend_tr %a pend_walk %a pass %d\n",
+                                i, e, w, ws[i], rs[i], dl, marg[i], std::min(mg2, o.margin), A, dstep[e], pend[i], o.p, pass);
+                }
+                if (hw[i]) rc[i] += dl;
+                marg[i] -= __builtin_fabs(dl);
+                dirty[i] = 0;
+                ++nshift;
+                continue;
+            }
             long long cur = ws[i];
             double p = rs[i];
             long long lw = -1;
             double lr = 0.0;
+            double mg = 4.0;
+            bool tp = false;
+            int td = 0;
             while (cur < A) {  // anchor -> leg start, epoch by epoch (the step changes at epoch boundaries)
                 const int ec = (int)(cur / N);
                 long long seg_end = (long long)(ec + 1) * N;
@@ -151,14 +196,20 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                 const double d = dstep[ec];
                 const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
                 if (o.last_w >= 0) { lw = cur + o.last_w; lr = o.last_r; }
+                mg = std::min(mg, o.margin);
+                tp |= tie_step(d);
+                td = td ? td : o.tdir;
                 p = o.p;
                 cur = seg_end;
             }
-            int n = N - w * L;
-            if (n > L) n = L;
             const double d = dstep[e];
-            const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
+            const WalkOut o = (cp_out && R > 0)
+                ? carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, R, 0, [&](int c, double v) { cp_out[(size_t)i * Lc + c] = v; })
+                : carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
             if (o.last_w >= 0) { lw = A + o.last_w; lr = o.last_r; }
+            marg[i] = std::min(mg, o.margin);
+            tiep[i] = (tp || tie_step(d)) ? 1 : 0;
+            tdir[i] = td ? td : o.tdir;
             pend[i] = o.p;
             hw[i] = lw >= 0;
             wc[i] = lw;
@@ -169,9 +220,9 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
         int unver = 0;
         // ---- stitcher (== leg_op / leg_d_out / DMap of synth_kernels.hip)
         struct Lc { int kind; long long w; double r; };
-        struct Op { bool act, root, have, link_ok, hw, same, tie; long long nw; double base, G; };
+        struct Op { bool act, root, have, link_ok, hw, same; int tdir; long long nw; double base, G; };
         auto leg_op = [&](int i, Lc &lc) {
-            Op o = {false, false, false, false, false, false, false, 0, 0.0, 0.0};
+            Op o = {false, false, false, false, false, false, tdir[i], 0, 0.0, 0.0};
             const int e = i / W, w = i % W;
             o.act = prn[e] > 0;
             if (!o.act) { lc.kind = 2; return o; }
@@ -179,10 +230,6 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             if (o.root) { lc.kind = 1; lc.w = leg_start(i); lc.r = (flags[e] & 1u) ? p0[e] : start0; }
             o.have = lc.kind == 1;
             o.link_ok = o.have && !dirty[i] && ws[i] == lc.w && d2u(rs[i]) == d2u(lc.r);
-            long long ea = lc.w > 0 ? (lc.w - 1) / N : 0;
-            ea = ea < E ? ea : E - 1;
-            const double t53 = dstep[ea] * 9007199254740992.0;
-            o.tie = (t53 == (double)(long long)t53) && (((long long)t53) & 1LL);
             o.nw = lc.w;
             o.base = lc.r;
             o.same = o.have && ws[i] == lc.w;
@@ -191,23 +238,30 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             if (o.hw) { lc.w = wc[i]; lc.r = rc[i]; }
             return o;
         };
-        auto tie_round = [](double D) { return (D + 3.0) - 3.0; };
+        auto odd52 = [](double t) { return (int)((long long)(t * 4503599627370496.0) & 1LL); };
+        auto tie_flip = [&](double t, int td) { return (td != 0 && odd52(t)) ? t - (double)td * 2.220446049250313e-16 : t; };
         auto d_out = [&](const Op &o, double D) {
             if (!o.act) return 0.0;
             if (o.root) D = 0.0;
             if (!o.hw) return D;
             if (!o.same) return 0.0;
-            return o.G + (o.tie ? tie_round(D) : D);
+            return tie_flip(o.G + D, o.tdir);
         };
         auto apply_leg = [&](int i, const Op &o, int &allok, double &D) {
             if (!o.act) { allok = 0; D = 0.0; return; }
             if (o.root) { allok = 1; D = 0.0; }
             allok &= o.link_ok ? 1 : 0;
-            const double nr = o.base + (o.tie ? tie_round(D) : D);
+            const double nr = o.base + D;
             if (allok) ver[i] = 1;
             else {
                 ++unver;
-                if (o.have && (ws[i] != o.nw || d2u(rs[i]) != d2u(nr))) { ws[i] = o.nw; rs[i] = nr; dirty[i] = 1; }
+                if (o.have && (ws[i] != o.nw || d2u(rs[i]) != d2u(nr))) {
+                    const double dl = nr - rs[i];
+                    const bool tr = translate && ws[i] == o.nw && (!tiep[i] || !odd52(dl)) &&
+                                    __builtin_fabs(dl) + 8.881784197001252e-16 < marg[i];
+                    ws[i] = o.nw; rs[i] = nr; dirty[i] = tr ? 2 : 1;
+                    if (tr) shift[i] = dl;
+                }
             }
             D = d_out(o, D);
         };
@@ -282,6 +336,7 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
         if (unver == 0) { ++pass; break; }
     }
     if (walks) *walks = nwalk;
+    if (shifts) *shifts = nshift;
     memcpy(pend_out, pend.data(), sizeof(double) * LEGS);
     for (int i = 0; i < LEGS; ++i)
         if (prn[i / W] > 0 && !ver[i]) return -1;

@@ -83,6 +83,7 @@ EXPORTED_SYMBOLS = (
     "gal_synth_set_stream",
     "gal_synth_plan",
     "gal_synth_output_bytes",
+    "gal_synth_walk_counts",
     "gal_synth_execute",
     "gal_synth_finish",
     "gal_synth_run_host",
@@ -115,6 +116,9 @@ def load_library():
     lib.gal_synth_destroy.argtypes = [vp]
     lib.gal_synth_set_stream.argtypes = [vp, vp]
     lib.gal_synth_plan.argtypes = [vp, vp, i32, vp]
+    lib.gal_synth_walk_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                          ctypes.POINTER(ctypes.c_int64)]
+    lib.gal_synth_walk_counts.restype = ctypes.c_int
     lib.gal_synth_output_bytes.argtypes = [vp]
     lib.gal_synth_output_bytes.restype = ctypes.c_size_t
     lib.gal_synth_execute.argtypes = [vp, vp]
@@ -228,6 +232,12 @@ class SynthEngine:
 
     def output_bytes(self):
         return int(self._lib.gal_synth_output_bytes(self._h))
+
+    def walk_counts(self):
+        """(legs walked, legs translated, fallbacks since create) of the last finish()."""
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.gal_synth_walk_counts(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def execute(self, iq_dev_ptr):
         """iq_dev_ptr: integer device address (e.g. torch tensor .data_ptr()), 16-byte aligned."""

@@ -132,6 +132,11 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
  * n_slots entries, may be NULL) and statistics (may be NULL). */
 int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats);
 
+/* Diagnostics of the last gal_synth_finish(): carrier-chain legs evaluated by walking, legs accepted by
+ * translation (csrc/nco_walk.h: binade_margin), and how often (since create) the replay check forced the
+ * all-walked fallback.  Any pointer may be NULL. */
+int gal_synth_walk_counts(const gal_synth_t *h, int64_t *legs_walked, int64_t *legs_translated, int64_t *fallbacks);
+
 /* Convenience: plan + execute into an internal device buffer + copy to host `iq_host` + finish. */
 int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                        const gal_chan_state_t *state_in, int16_t *iq_host,

@@ -166,6 +166,26 @@ def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
     assert stats["walk_passes"] >= 2
 
 
+def test_translated_legs_on_moving_receiver(pkg):
+    """M-DYN-like Doppler (changes every epoch): most second-pass legs are accepted by translation, a few
+    are walked again, and the replay check never has to force the all-walked fallback."""
+    p = pkg.workloads.make_synthetic(n_epochs=40, n_chan=12, n_slots=16, samples_per_epoch=260000, seed=4242,
+                                     dyn_track=True)
+    # sprinkle tie-prone steps (multiples of 2^-52 / 2^-53 cycles per sample): never translated
+    for e, j, k in [(5, 0, 52), (9, 3, 53), (17, 7, 52), (30, 11, 50)]:
+        d = p["f_carr"][e, j] / 2.6e6
+        p["f_carr"][e, j] = np.round(d * 2.0 ** k) / 2.0 ** k * 2.6e6
+        p["f_code"][e, j] = 1.023e6 + p["f_carr"][e, j] * 0.0006493506493506494
+    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=16, device=0) as eng:
+        iq, st, stats = eng.run_host(p)
+        walked, translated, fallbacks = eng.walk_counts()
+    ref_iq, ref_st = oracle_run(p, 260000, 2.6e6)
+    assert np.array_equal(iq, ref_iq)
+    assert stats["chain_mismatch"] == 0 and fallbacks == 0
+    legs = 40 * 8 * 12
+    assert translated > legs // 2 and walked < legs + legs // 4, (walked, translated)
+
+
 def test_two_handles_in_flight(pkg):
     """Software pipeline as bench.py runs it: two handles on two streams, executes interleaved."""
     import torch

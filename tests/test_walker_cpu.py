@@ -27,7 +27,7 @@ def W(pkg):
     lib.galwalk_code.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
     lib.galwalk_code_brute.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
     lib.galwalk_spec_wrap.restype = i
-    lib.galwalk_spec_wrap.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i]
+    lib.galwalk_spec_wrap.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i, i, vp, i, vp]
     return lib
 
 
@@ -149,9 +149,84 @@ def test_wrap_anchored_stitching_as_on_gpu(W):
             hist = np.zeros(64, dtype=np.int32)
             walks = ctypes.c_long()
             r = W.galwalk_spec_wrap(E, Wl, L, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data,
-                                    0.0, 64, pend.ctypes.data, ctypes.byref(walks), hist.ctypes.data, nthreads)
+                                    0.0, 64, pend.ctypes.data, ctypes.byref(walks), hist.ctypes.data, nthreads,
+                                    0, None, 0, None)
             assert 0 < r <= 6, (r, nthreads, hist[:12])
             assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), truth.view(np.uint64))
             passes.append(r)
         # the block-parallel form composes the pending-correction maps exactly: same pass count as sequential
         assert passes[0] == passes[1] == passes[2], passes
+
+
+def _chain_truth_cp(W, p, d, N, R):
+    """Brute-force chain: phase before every R-th sample of every epoch, and the epoch end phases."""
+    nc = (N + R - 1) // R
+    cps = np.zeros((len(d), nc))
+    ends = np.zeros(len(d))
+    for e in range(len(d)):
+        p = W.galwalk_carr_brute(p, d[e], N, R, cps[e].ctypes.data)
+        ends[e] = p
+    return cps, ends
+
+
+def _run_spec(W, d, p_start, N, Wl, L, R, translate, nthreads=256):
+    E = len(d)
+    prn = np.full(E, 3, dtype=np.int32)
+    flags = np.zeros(E, dtype=np.uint32)
+    p0 = np.zeros(E)
+    flags[0] = 1
+    p0[0] = p_start
+    pend = np.zeros(E * Wl)
+    cp = np.zeros(E * Wl * (L // R))
+    walks, shifts = ctypes.c_long(), ctypes.c_long()
+    r = W.galwalk_spec_wrap(E, Wl, L, N, prn.ctypes.data, flags.ctypes.data, p0.ctypes.data, d.ctypes.data, 0.0, 64,
+                            pend.ctypes.data, ctypes.byref(walks), None, nthreads, R, cp.ctypes.data, translate,
+                            ctypes.byref(shifts))
+    return r, pend, cp.reshape(E, Wl * (L // R)), walks.value, shifts.value
+
+
+def test_translated_legs_are_bit_exact(W):
+    """Translated acceptance (k_walk_carr dirty == 2): a leg whose anchor residual moved by less than its binade
+    margin is shifted instead of walked again.  Every checkpoint and every leg end must still equal the chain
+    stepped sample by sample, and most second-pass walks must disappear."""
+    rng = np.random.default_rng(11)
+    N, Wl, L, R = 26000, 8, 3264, 102
+    ncp = (N + R - 1) // R
+    cases = []
+    for t in range(6):
+        f0 = rng.uniform(-3500, 3500)
+        cases.append((f0 - 0.05 * np.arange(400)) * DELT)
+    cases.append(np.linspace(60.0, -60.0, 300) * DELT)                    # sign change, slow
+    cases.append(-(2500.0 + 0.3 * np.arange(300)) * DELT)                 # negative Doppler
+    cases.append(np.full(200, 1234.5) * DELT)                             # constant step
+    tie = np.full(120, np.ldexp(2 * 6001 + 1, -53))                       # odd multiple of 2^-53: tie-prone
+    cases.append(tie)
+    mix = (1800.0 + 0.01 * np.arange(200)) * DELT
+    mix[50:60] = np.ldexp(2 * 5003 + 1, -53)                              # a few tie-prone epochs inside
+    cases.append(mix)
+    # steps with few significant bits sprinkled between ordinary ones: multiples of 2^-k around the 2^-52/2^-53
+    # grids of the wrap step (an EVEN multiple of 2^-53 still ties at the first wrap of its epoch, because the
+    # phase it inherits may carry the 2^-53 bit -- found by the replay check on the M-DYN workload)
+    for k in (50, 52, 53, 54, 56):
+        dd = (rng.uniform(-3000, 3000) + 0.07 * np.arange(240)) * DELT
+        sel = rng.random(240) < 0.25
+        dd[sel] = np.round(dd[sel] * 2.0 ** k) / 2.0 ** k
+        cases.append(dd)
+    tot_w0 = tot_w1 = tot_s = 0
+    for ci, d in enumerate(cases):
+        d = np.ascontiguousarray(d)
+        p_start = rng.uniform(0, 1)
+        cps, ends = _chain_truth_cp(W, p_start, d, N, R)
+        for translate in (0, 1):
+            r, pend, cp, walks, shifts = _run_spec(W, d, p_start, N, Wl, L, R, translate)
+            # the tie flip is predicted exactly (WalkOut::tdir): tie-prone epochs cost no extra passes
+            assert 0 < r <= 4, (r, translate, ci)
+            assert np.array_equal(pend[Wl - 1::Wl].view(np.uint64), ends.view(np.uint64)), translate
+            assert np.array_equal(cp[:, :ncp].view(np.uint64), cps.view(np.uint64)), translate
+            if translate:
+                tot_w1 += walks
+                tot_s += shifts
+            else:
+                tot_w0 += walks
+                assert shifts == 0
+    assert tot_s > 0 and tot_w1 < 0.7 * tot_w0, (tot_w0, tot_w1, tot_s)

@@ -1,0 +1,37 @@
+#!/bin/bash
+# PMC passes for k_synth on the default bench workload (run on the GPU box from the repo root):
+#   tools/pmc_synth.sh <tag>   ->  gpurun_out/<tag>_pmc_*.json  (copy the ones to be judged into profiles/)
+# Counters are collected in their own rocprofv3 runs (no tracing options), a few per pass.
+set -u
+tag=${1:-rXX}
+export TMPDIR=/tmp
+out=gpurun_out/pmc_$tag
+mkdir -p $out
+cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline 1"
+i=0
+for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
+            "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" "WRITE_SIZE FETCH_SIZE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- $cmd > $out/p$i.log 2>&1
+done
+python3 - "$out" "$tag" <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        if "k_synth" not in r["Kernel_Name"]:
+            continue
+        per[r["Dispatch_Id"]][r["Counter_Name"]] = per[r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    for d in per.values():
+        for k, v in d.items():
+            acc[k].append(v)
+res = {k: sum(v) / len(v) for k, v in acc.items()}
+res["launches_averaged"] = {k: len(v) for k, v in acc.items()}
+if "WRITE_SIZE" in res:
+    # guide: WRITE_SIZE / FETCH_SIZE are in KiB on gfx950 (tools/wrcal.hip calibration: exact for coalesced writes)
+    res["hbm_bytes_per_launch"] = int((res["WRITE_SIZE"] + res["FETCH_SIZE"]) * 1024)
+json.dump(res, open("gpurun_out/%s_pmc_k_synth_all.json" % tag, "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
+PY
