@@ -140,6 +140,7 @@ struct WalkOut {
                     // +1 / -1 = the add rounded up / down (rounded minus exact sum), 0 = no tie in this walk.
                     // A trajectory shifted by an ODD multiple of 2^-52 resolves that tie the other way: from
                     // there on it is off by the shift minus tdir * 2^-52 (an even multiple: later ties agree).
+    int tpos;       // local index right after that step (valid when tdir != 0)
 };
 
 // Distance of the states of one closed-form batch to their binade's boundaries.  a and b are the first and
@@ -182,6 +183,7 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
     o.last_w = -1;
     o.last_r = 0.0;
     o.tdir = 0;
+    o.tpos = -1;
     const bool tieprone = tie_step(d);
     double mg = 4.0;
     while (i < N) {
@@ -206,6 +208,7 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
                 const double err = (p - (q - bv)) + (d - bv);
                 if (err == 1.1102230246251565e-16) o.tdir = -1;   // exact sum above q: rounded down
                 if (err == -1.1102230246251565e-16) o.tdir = 1;   // rounded up
+                if (o.tdir) o.tpos = i + 1;
             }
             p = q - t;  // == carr_step(p, d)
             ++i;
@@ -262,6 +265,27 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
     return r;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Mean advance per sample of the ROUNDED carrier chain: inside the binade [2^-j, 2^-j+1) every step adds
+// RN_g(d) (g the binade's ulp) rather than d, and a phase sweeping (0,1) spends the fraction 2^-j of its
+// steps there.  Used only for the first-pass GUESSES of the speculative stitcher: with the systematic part of
+// the rounding drift removed, guessed and true wrap residuals differ by a random walk of a few 2^-53 per wrap
+// instead of up to 2^-54 per SAMPLE, so almost every leg can be accepted by translation.
+GAL_HD double eff_step(double d)
+{
+    const double ad = d < 0.0 ? -d : d;
+    if (!(ad > 1e-12) || !(ad < 0.25)) return d;
+    double acc = 0.0, w = 0.5, pk = 0.5;
+    for (int j = 1; j <= 40; ++j) {
+        if (pk <= ad) break;              // below the step's own binade nothing is rounded
+        acc += w * ((ad + pk) - pk);      // RN to the ulp of [pk, 2pk)
+        w *= 0.5;
+        pk *= 0.5;
+    }
+    acc += 2.0 * w * ad;                  // the remaining fraction of the sweep adds d itself
+    return d < 0.0 ? -acc : acc;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Ideal-arithmetic prediction of the last wrap at or before local sample `a` of an epoch that starts at

@@ -378,7 +378,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmw = take(LEGS * S * 8),
                  o_clmr = take(LEGS * S * 8);
     const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
-    const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tiep = take(LEGS * S),
+    const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ctr = take(CTR_COUNT * 4);
@@ -414,7 +414,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.clm_w = (long long *)(base + o_clmw); P.clm_r = (double *)(base + o_clmr);
     P.pend = (double *)(base + o_pend);
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
-    P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tiep = (uint8_t *)(base + o_tiep);
+    P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
     P.translate = 1;
     if (const char *env = getenv("GAL_WALK_TRANSLATE")) P.translate = atoi(env) != 0;  // test hook

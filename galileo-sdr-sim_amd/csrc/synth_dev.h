@@ -53,8 +53,8 @@ struct DevPlan {
     uint8_t *verified;
     uint8_t *dirty;      // 0 clean, 1 walk again from the new anchor, 2 translate by `shift` instead of walking
     double *marg;        // min distance of the leg's walked states to their binade boundaries (nco_walk.h)
-    uint8_t *tiep;       // the walk touched a tie-prone epoch: translated only by even multiples of 2^-52
     int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
+    long long *tpos;     // global sample index right after that tie step
     double *shift;       // pending translation (new anchor residual - walked anchor residual)
     int translate;       // 0: always re-walk (fallback / tests)
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
         const uint32_t fl = P.flags[idx];
         const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
         const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
-        const double d = P.dstep[idx];
+        const double d = eff_step(P.dstep[idx]);  // mean advance of the rounded chain (nco_walk.h)
         const double adv = (double)P.N * d;
         double mine = 0.0;
 #pragma unroll
@@ -185,6 +185,8 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
     }
 }
 
+__device__ __forceinline__ int d_residue_u52(double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); }
+
 // k_walk_carr: one lane per (leg, slot).  A leg is walked from its ANCHOR -- the last wrap event at or before
 // its first sample, (omega, r): "the phase before global sample omega is r", or the chain root -- first up to
 // the leg start (no output, epoch by epoch because the step changes), then through the leg itself, emitting
@@ -215,7 +217,7 @@ __global__ void k_walk_carr(DevPlan P, int first)
         // first pass: anchor from ideal arithmetic (predicted last wrap at or before the leg start)
         int om;
         double rr;
-        if (ideal_last_wrap(P.pguess[(size_t)s * P.E + e], P.dstep[idx], w * L, &om, &rr)) {
+        if (ideal_last_wrap(P.pguess[(size_t)s * P.E + e], eff_step(P.dstep[idx]), w * L, &om, &rr)) {
             cur = (long long)e * P.N + om;
             p = rr;
         } else {
@@ -230,18 +232,24 @@ __global__ void k_walk_carr(DevPlan P, int first)
         if (!dk) return;
         if (dk == 2) {
             // TRANSLATED acceptance: the stitcher moved the anchor by `shift` (same wrap event, a multiple of
-            // 2^-52 smaller than the leg's binade margin, no tie-prone epoch on the way): a walk from the new
-            // anchor would visit the same binades step by step, so every state it produces is the old one
-            // plus the shift, bit for bit (nco_walk.h: binade_margin).  k_synth's replay check covers it.
+            // 2^-52 smaller than the leg's binade margin): a walk from the new anchor would visit the same
+            // binades step by step, so every state it produces is the old one plus the shift, bit for bit
+            // (nco_walk.h: binade_margin; ties: WalkOut::tdir).  k_synth's replay check covers it.
             const double dl = P.shift[li];
+            // an odd shift flips the first tie of the walk: from that wrap on the trajectory is off by dl2
+            const int td = P.tdir[li];
+            const bool flip = td != 0 && (d_residue_u52(dl) & 1);
+            const double dl2 = flip ? dl - (double)td * 2.220446049250313e-16 : dl;
+            const long long tp = flip ? P.tpos[li] : (long long)1 << 62;  // global index right after the tie step
             int nck = P.nchunks - w * P.Lc;
             nck = nck > P.Lc ? P.Lc : nck;
             double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-            for (int c = 0; c < nck; ++c) cpp[c] += dl;
-            if (w == P.W - 1) cpp[nck] += dl;
-            P.pend[li] += dl;
-            if (P.clm_w[li] >= 0) P.clm_r[li] += dl;
-            P.marg[li] -= __builtin_fabs(dl);
+            for (int c = 0; c < nck; ++c) cpp[c] += (A + (long long)c * P.R >= tp) ? dl2 : dl;
+            if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
+            P.pend[li] += dl2;
+            if (P.clm_w[li] >= 0) P.clm_r[li] += (P.clm_w[li] >= tp) ? dl2 : dl;
+            P.marg[li] -= __builtin_fabs(dl) + 2.220446049250313e-16;
+            if (flip) P.tdir[li] = (int8_t)-td;  // the shifted trajectory resolved that tie the other way
             P.dirty[li] = 0;
             const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
             if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_SHIFTS], __builtin_popcountll(m));
@@ -253,8 +261,8 @@ __global__ void k_walk_carr(DevPlan P, int first)
     long long lw = -1;
     double lr = 0.0;
     double mg = 4.0;
-    bool tiep = false;
     int tdir = 0;
+    long long tpos = -1;
     while (cur < A) {  // anchor -> leg start
         const int ec = (int)(cur / P.N);
         long long seg_end = (long long)(ec + 1) * P.N;
@@ -267,8 +275,10 @@ __global__ void k_walk_carr(DevPlan P, int first)
             lr = o.last_r;
         }
         mg = o.margin < mg ? o.margin : mg;
-        tiep |= tie_step(d);
-        tdir = tdir ? tdir : o.tdir;
+        if (!tdir && o.tdir) {
+            tdir = o.tdir;
+            tpos = cur + o.tpos;
+        }
         p = o.p;
         cur = seg_end;
     }
@@ -286,8 +296,12 @@ __global__ void k_walk_carr(DevPlan P, int first)
     P.clm_w[li] = lw;  // -1: no wrap between the anchor and the end of the leg
     P.clm_r[li] = lr;
     P.marg[li] = o.margin < mg ? o.margin : mg;
-    P.tiep[li] = (tiep || tie_step(d)) ? 1 : 0;
-    P.tdir[li] = (int8_t)(tdir ? tdir : o.tdir);
+    if (!tdir && o.tdir) {
+        tdir = o.tdir;
+        tpos = A + o.tpos;
+    }
+    P.tdir[li] = (int8_t)tdir;
+    P.tpos[li] = tpos;
     P.dirty[li] = 0;
     const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
                     // same wrap event, only its residual moved: translate the leg instead of walking it again
                     // when the move is provably itinerary-preserving (k_walk_carr, dirty == 2)
                     const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
-                    const bool tr = P.translate && L.aw == o.nw && (!P.tiep[li] || !(d_residue(dl) & 1)) &&
+                    const bool tr = P.translate && L.aw == o.nw &&
                                     __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
                     P.anc_w[li] = o.nw;
                     P.anc_r[li] = nr;

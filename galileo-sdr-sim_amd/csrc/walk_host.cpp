@@ -109,9 +109,10 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
     // (synth_kernels.hip: k_walk_carr dirty == 2 / k_carr_scan sweep 3)
     const int LEGS = E * W;
     const int Lc = R > 0 ? L / R : 0;
+    const bool use_eff = getenv("GALWALK_NO_EFF") == nullptr;
     std::vector<double> marg(LEGS, 0.0), shift(LEGS, 0.0);
-    std::vector<uint8_t> tiep(LEGS, 0);
     std::vector<int> tdir(LEGS, 0);
+    std::vector<long long> tpos(LEGS, -1);
     long nshift = 0;
     std::vector<double> pg(E, 0.0), rs(LEGS, 0.0), rc(LEGS, 0.0), pend(LEGS, 0.0);
     std::vector<long long> ws(LEGS, 0), wc(LEGS, -1);
@@ -129,8 +130,9 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             gr[e] = lr;
             int om;
             double rr;
-            if (ideal_last_wrap(p, dstep[e], N, &om, &rr)) { lw = (long long)e * N + om; lr = rr; }
-            p = p + (double)N * dstep[e];
+            const double de = use_eff ? eff_step(dstep[e]) : dstep[e];
+            if (ideal_last_wrap(p, de, N, &om, &rr)) { lw = (long long)e * N + om; lr = rr; }
+            p = p + (double)N * de;
             p = p - __builtin_trunc(p);
         }
     }
@@ -146,7 +148,7 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             if (first) {  // anchor predicted by ideal arithmetic
                 int om;
                 double rr;
-                if (ideal_last_wrap(pg[e], dstep[e], w * L, &om, &rr)) { ws[i] = (long long)e * N + om; rs[i] = rr; }
+                if (ideal_last_wrap(pg[e], use_eff ? eff_step(dstep[e]) : dstep[e], w * L, &om, &rr)) { ws[i] = (long long)e * N + om; rs[i] = rr; }
                 else { ws[i] = gw[e]; rs[i] = gr[e]; }
                 ver[i] = 0;
             } else if (!dirty[i]) continue;
@@ -154,8 +156,11 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             if (n > L) n = L;
             if (!first && dirty[i] == 2) {  // translated acceptance
                 const double dl = shift[i];
-                if (cp_out) for (int c = 0; c * R < n; ++c) cp_out[(size_t)i * Lc + c] += dl;
-                pend[i] += dl;
+                const bool flip = tdir[i] != 0 && ((long long)(dl * 4503599627370496.0) & 1LL);
+                const double dl2 = flip ? dl - (double)tdir[i] * 2.220446049250313e-16 : dl;
+                const long long tp = flip ? tpos[i] : (long long)1 << 62;
+                if (cp_out) for (int c = 0; c * R < n; ++c) cp_out[(size_t)i * Lc + c] += (A + (long long)c * R >= tp) ? dl2 : dl;
+                pend[i] += dl2;
                 if (getenv("GALWALK_DEBUG")) {
                     long long cur = ws[i];
                     double p = rs[i];
@@ -175,8 +180,9 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                         fprintf(stderr, "TRANSLATE MISMATCH leg %d (e %d w %d) anchor %lld r_new %a dl %a marg(before) %a marg_newwalk %a A %lld d %a pend_tr %a pend_walk %a pass %d\n",
                                 i, e, w, ws[i], rs[i], dl, marg[i], std::min(mg2, o.margin), A, dstep[e], pend[i], o.p, pass);
                 }
-                if (hw[i]) rc[i] += dl;
-                marg[i] -= __builtin_fabs(dl);
+                if (hw[i]) rc[i] += (wc[i] >= tp) ? dl2 : dl;
+                marg[i] -= __builtin_fabs(dl) + 2.220446049250313e-16;
+                if (flip) tdir[i] = -tdir[i];
                 dirty[i] = 0;
                 ++nshift;
                 continue;
@@ -186,8 +192,8 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             long long lw = -1;
             double lr = 0.0;
             double mg = 4.0;
-            bool tp = false;
             int td = 0;
+            long long tpo = -1;
             while (cur < A) {  // anchor -> leg start, epoch by epoch (the step changes at epoch boundaries)
                 const int ec = (int)(cur / N);
                 long long seg_end = (long long)(ec + 1) * N;
@@ -197,8 +203,7 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                 const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
                 if (o.last_w >= 0) { lw = cur + o.last_w; lr = o.last_r; }
                 mg = std::min(mg, o.margin);
-                tp |= tie_step(d);
-                td = td ? td : o.tdir;
+                if (!td && o.tdir) { td = o.tdir; tpo = cur + o.tpos; }
                 p = o.p;
                 cur = seg_end;
             }
@@ -208,8 +213,9 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                 : carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
             if (o.last_w >= 0) { lw = A + o.last_w; lr = o.last_r; }
             marg[i] = std::min(mg, o.margin);
-            tiep[i] = (tp || tie_step(d)) ? 1 : 0;
-            tdir[i] = td ? td : o.tdir;
+            if (!td && o.tdir) { td = o.tdir; tpo = A + o.tpos; }
+            tdir[i] = td;
+            tpos[i] = tpo;
             pend[i] = o.p;
             hw[i] = lw >= 0;
             wc[i] = lw;
@@ -257,8 +263,10 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                 ++unver;
                 if (o.have && (ws[i] != o.nw || d2u(rs[i]) != d2u(nr))) {
                     const double dl = nr - rs[i];
-                    const bool tr = translate && ws[i] == o.nw && (!tiep[i] || !odd52(dl)) &&
+                    const bool tr = translate && ws[i] == o.nw &&
                                     __builtin_fabs(dl) + 8.881784197001252e-16 < marg[i];
+                    if (translate && getenv("GALWALK_DEBUG2") && !tr)
+                        fprintf(stderr, "REWALK leg %d same %d tdir %d odd %d dl %a marg %a\n", i, (int)(ws[i] == o.nw), tdir[i], odd52(dl), dl, marg[i]);
                     ws[i] = o.nw; rs[i] = nr; dirty[i] = tr ? 2 : 1;
                     if (tr) shift[i] = dl;
                 }
