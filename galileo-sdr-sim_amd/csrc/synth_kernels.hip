@@ -451,15 +451,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
+    if (P.ctr[CTR_MODE] == 1) return;  // the pass before only translated: nothing new to stitch (k_carr_publish)
     __shared__ int s_kind[SCAN_THREADS];
     __shared__ long long s_w[SCAN_THREADS];
     __shared__ double s_r[SCAN_THREADS];
     __shared__ int s_fv[SCAN_THREADS], s_v[SCAN_THREADS], s_ic[SCAN_THREADS];
     __shared__ double s_K[SCAN_THREADS], s_c[4][SCAN_THREADS];
-    __shared__ int s_unver;
+    __shared__ int s_unver, s_rewalk;
     const int s = blockIdx.x;
     const int t = threadIdx.x;
-    if (t == 0) s_unver = 0;
+    if (t == 0) {
+        s_unver = 0;
+        s_rewalk = 0;
+    }
     const double start0 = P.state_in[s].carr_phase;
     const int K = (P.LEGS + SCAN_THREADS - 1) / SCAN_THREADS;
     const int i0 = t * K;
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
             allok = s_fv[t - 1] ? s_v[t - 1] : 0;
             D = s_ic[t - 1] ? s_K[t - 1] : s_c[0][t - 1];  // the prefix map applied to D = 0
         }
-        int unver = 0;
+        int unver = 0, rewalk = 0;
         for (int i = i0; i < i1; ++i) {
             const LegRec L = leg_load(P, s, i, start0);
             const LegOp o = leg_op(P, s, L, lc);
@@ -613,23 +617,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
                     P.anc_r[li] = nr;
                     P.dirty[li] = tr ? 2 : 1;
                     if (tr) P.shift[li] = dl;
+                    rewalk += tr ? 0 : 1;
                 }
+                rewalk += o.have ? 0 : 1;
             }
             D = leg_d_out(o, D);
         }
         if (unver) atomicAdd(&s_unver, unver);
+        if (rewalk) atomicAdd(&s_rewalk, rewalk);
     }
     __syncthreads();
     if (t == 0 && s_unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], s_unver);
+    if (t == 0 && s_rewalk) atomicAdd(&P.ctr[CTR_REWALK_NEXT], s_rewalk);
 }
 
-// after every slot's scan: publish the count the next pass looks at
+// after every slot's scan: publish the count the next pass looks at.  When the stitcher asked for translations
+// only (no leg has to be walked again), the translated claims are by construction the anchors it predicted
+// for their successors, so the next pass completes the chain and its scan is skipped (CTR_MODE); what stands
+// behind this shortcut is the same argument as for a single translated leg, and k_synth's replay check.
 __global__ void k_carr_publish(DevPlan P)
 {
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    P.ctr[CTR_UNVERIFIED] = P.ctr[CTR_UNVER_NEXT];
+    if (P.ctr[CTR_MODE] == 1) {
+        P.ctr[CTR_UNVERIFIED] = 0;
+        P.ctr[CTR_MODE] = 0;
+        P.ctr[CTR_PASSES] += 1;
+        return;
+    }
+    const int unv = P.ctr[CTR_UNVER_NEXT], rw = P.ctr[CTR_REWALK_NEXT];
+    P.ctr[CTR_UNVERIFIED] = unv;
     P.ctr[CTR_UNVER_NEXT] = 0;
+    P.ctr[CTR_REWALK_NEXT] = 0;
     P.ctr[CTR_PASSES] += 1;
+    if (unv > 0 && rw == 0 && P.translate) P.ctr[CTR_MODE] = 1;
 }
 
 // Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88: the page

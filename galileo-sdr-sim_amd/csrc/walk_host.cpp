@@ -139,6 +139,7 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
     auto leg_start = [&](int i) { return (long long)(i / W) * N + (long long)(i % W) * L; };
     long nwalk = 0;
     int pass = 0;
+    int mode = 0, rewalk = 0;  // k_carr_publish: translation-only pass pending -> its scan is skipped
     for (; pass < max_passes; ++pass) {
         const int first = pass == 0;
         for (int i = 0; i < LEGS; ++i) {
@@ -223,7 +224,14 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
             dirty[i] = 0;
             ++nwalk;
         }
+        if (mode == 1) {  // every pending leg was translated onto the anchor the stitcher predicted
+            for (int i = 0; i < LEGS; ++i) ver[i] = 1;
+            if (unver_hist) unver_hist[pass] = 0;
+            ++pass;
+            break;
+        }
         int unver = 0;
+        rewalk = 0;
         // ---- stitcher (== leg_op / leg_d_out / DMap of synth_kernels.hip)
         struct Lc { int kind; long long w; double r; };
         struct Op { bool act, root, have, link_ok, hw, same; int tdir; long long nw; double base, G; };
@@ -269,7 +277,9 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
                         fprintf(stderr, "REWALK leg %d same %d tdir %d odd %d dl %a marg %a\n", i, (int)(ws[i] == o.nw), tdir[i], odd52(dl), dl, marg[i]);
                     ws[i] = o.nw; rs[i] = nr; dirty[i] = tr ? 2 : 1;
                     if (tr) shift[i] = dl;
+                    rewalk += tr ? 0 : 1;
                 }
+                rewalk += o.have ? 0 : 1;
             }
             D = d_out(o, D);
         };
@@ -342,6 +352,7 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
         }
         if (unver_hist) unver_hist[pass] = unver;
         if (unver == 0) { ++pass; break; }
+        if (rewalk == 0 && translate) mode = 1;
     }
     if (walks) *walks = nwalk;
     if (shifts) *shifts = nshift;
