@@ -101,31 +101,6 @@ GAL_HD Batch nco_batch(double x, double d, int n_max, double cap, double inv_ad)
 // starts from).  inv_ad = 1.0 / fabs(d) (any value if d == 0).
 // Loop shape (uniform across lanes): [checkpoint?] [closed-form batch, capped at the next checkpoint]
 // [one genuine step unless the batch ended on the checkpoint].
-template <class Emit>
-GAL_HD double carr_walk(double p, double d, double inv_ad, int N, int R, Emit emit)
-{
-    int i = 0;
-    int next_cp = 0, c = 0;
-    while (i < N) {
-        if (next_cp == i) {
-            emit(c, p);
-            ++c;
-            next_cp += R;
-        }
-        const int stop = next_cp < N ? next_cp : N;     // never run past a checkpoint or the end
-        const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
-        p = fma_exact((double)b.n, b.inc, p);
-        i += b.n;
-        if (i < stop) {
-            p = carr_step(p, d);
-            ++i;
-        }
-    }
-    return p;
-}
-
-
-
 // carr_walk with wrap tracking: additionally reports the LAST wrap inside the walk -- the local sample
 // index right after the wrapping step and the residual phase there -- which is what the speculative
 // stitcher (synth_kernels.hip: k_walk_carr / k_carr_scan) uses as a leg's hand-over state: right after a
@@ -173,6 +148,12 @@ GAL_HD bool tie_step(double d)
     return t53 == (double)(long long)t53;
 }
 
+// The carrier walk proper.  Loop shape (uniform across lanes): [checkpoint?] [closed-form batch inside the
+// current binade, capped at the next checkpoint] [one genuine step unless the batch ended on the checkpoint].
+// The batch is a specialisation of nco_batch for the case that matters -- phase and step of the same sign
+// (|p| grows towards the wrap), 2^-30 <= |d| -- with everything that depends only on d hoisted out of the
+// loop; other states (a phase still running against a step that changed sign, degenerate steps) take the
+// general nco_batch.  Same results as stepping sample by sample, bit for bit (tests/test_walker_cpu.py).
 template <class Emit>
 GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, int cp0, Emit emit)
 {
@@ -185,6 +166,13 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
     o.tdir = 0;
     o.tpos = -1;
     const bool tieprone = tie_step(d);
+    const uint64_t db = d2u(d), da = db & ~kSign;
+    const double ad = u2d(da);
+    const uint32_t ed = (uint32_t)(da >> 52);
+    const uint32_t dsign = (uint32_t)(db >> 63);
+    const bool lean_d = (ad >= 9.313225746154785e-10) && (ad < 1.0);  // 2^-30 <= |d| < 1
+    // the one binade in which |d| is an odd multiple of half an ulp (round-to-even ties inside a batch)
+    const uint32_t e_tie = ed + 1u + (uint32_t)__builtin_ctzll(da | (1ull << 52));
     double mg = 4.0;
     while (i < N) {
         if (next_cp == i) {
@@ -193,12 +181,43 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
             next_cp += R;
         }
         const int stop = next_cp < N ? next_cp : N;  // never run past a checkpoint or the end
-        const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
-        const double a = p;
-        p = fma_exact((double)b.n, b.inc, p);
-        const double m = binade_margin(a, p);
-        mg = m < mg ? m : mg;
-        i += b.n;
+        const uint64_t pb = d2u(p), pa = pb & ~kSign;
+        const bool lean = lean_d && (((uint32_t)(pb >> 63) == dsign) || pa == 0);
+        if (lean) {
+            const uint32_t ea = (uint32_t)(pa >> 52);
+            const bool can = ea > ed;                      // above the step's binade (hence normal)
+            const uint64_t pkb = (uint64_t)(can ? ea : 1023u) << 52;
+            const double pk = u2d(pkb);                    // binade floor 2^k
+            const double top = u2d(pkb | 0x000fffffffffffffull);  // largest double of the binade
+            const double a = u2d(pa);
+            const double dk = (ad + pk) - pk;              // RN_g(|d|), ties to even; > 0 because |d| >= 2^-30 > g/2
+            const bool odd_tie = (ea == e_tie) & ((uint32_t)pa & 1u);  // a tie binade needs x/g even
+            const double t = top - a;                      // room to the binade ceiling, exact, >= 0
+            // t / dk through the caller's reciprocal of |d|: |dk - |d|| <= g/2 keeps the estimate within
+            // 2^-33 / |d| <= 2^-3 of the true quotient, so it overshoots floor(t/dk) by at most one, which the
+            // exact remainder test catches (n*dk is a multiple of g below 2^(k+1): exactly representable)
+            double q = t * inv_ad;
+            const double qmax = (double)(stop - i);
+            q = q > qmax ? qmax : q;
+            int n = (int)q;
+            n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
+            n = n < 0 ? 0 : n;
+            n = (can & !odd_tie) ? n : 0;
+            const double nd = (double)n;
+            const double room = fma_exact(-nd, dk, t);     // ceiling minus the last state of the batch
+            const double m1 = can ? a - pk : binade_margin(p, p);
+            mg = m1 < mg ? m1 : mg;
+            mg = (can && room < mg) ? room : mg;
+            p = fma_exact(nd, dsign ? -dk : dk, p);
+            i += n;
+        } else {
+            const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
+            const double a0 = p;
+            p = fma_exact((double)b.n, b.inc, p);
+            const double m = binade_margin(a0, p);
+            mg = m < mg ? m : mg;
+            i += b.n;
+        }
         if (i < stop) {
             const double q = p + d;
             const double t = __builtin_trunc(q);
@@ -220,6 +239,15 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
     o.margin = m < mg ? m : mg;
     o.p = p;
     return o;
+}
+
+// Carrier chain: N samples with constant step d.  `emit(c, p)` receives the phase BEFORE sample c*R for
+// c = 0 .. ceil(N/R)-1; the return value is the phase after sample N-1 (what the next epoch starts from).
+// inv_ad = 1.0 / fabs(d) (any value if d == 0).
+template <class Emit>
+GAL_HD double carr_walk(double p, double d, double inv_ad, int N, int R, Emit emit)
+{
+    return carr_walk_track(p, d, inv_ad, N, R, 0, emit).p;
 }
 
 // Code chain: N samples, step c > 0, wrap at 4092 checked BEFORE each sample's use

@@ -10,9 +10,11 @@ mkdir -p $out
 cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline 1"
 i=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
-            "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" "WRITE_SIZE FETCH_SIZE"; do
+            "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" "WRITE_SIZE" "FETCH_SIZE"; do
     i=$((i+1))
-    rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- $cmd > $out/p$i.log 2>&1
+    # (WRITE_SIZE and FETCH_SIZE do not fit one pass on gfx950: rocprofv3 aborts and then hangs -> own passes,
+    # and every pass under its own timeout)
+    timeout 150 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- $cmd > $out/p$i.log 2>&1 || echo "pass $i ($ctrs) failed or timed out"
 done
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, json, sys, collections
@@ -29,9 +31,11 @@ for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
             acc[k].append(v)
 res = {k: sum(v) / len(v) for k, v in acc.items()}
 res["launches_averaged"] = {k: len(v) for k, v in acc.items()}
-if "WRITE_SIZE" in res:
-    # guide: WRITE_SIZE / FETCH_SIZE are in KiB on gfx950 (tools/wrcal.hip calibration: exact for coalesced writes)
-    res["hbm_bytes_per_launch"] = int((res["WRITE_SIZE"] + res["FETCH_SIZE"]) * 1024)
+if "WRITE_SIZE" in res and "FETCH_SIZE" in res:
+    # WRITE_SIZE is in KiB on gfx950 (tools/wrcal.hip: exact for a coalesced 1 GiB fill); FETCH_SIZE counts
+    # 32-byte requests against a 64-byte unit there, i.e. the raw KiB figure is doubled (MI355X_MICROARCH guide,
+    # HBM / rocprofv3 section) -- same correction as in profiles/r01_pmc_write_fetch.md
+    res["hbm_bytes_per_launch"] = int((res["WRITE_SIZE"] + 2.0 * res["FETCH_SIZE"]) * 1024)
 json.dump(res, open("gpurun_out/%s_pmc_k_synth_all.json" % tag, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
