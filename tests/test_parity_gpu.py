@@ -186,6 +186,52 @@ def test_translated_legs_on_moving_receiver(pkg):
     assert translated > legs // 2 and walked < legs + legs // 4, (walked, translated)
 
 
+def test_full_size_properties(pkg):
+    """BASELINE configs[1] size (M-SYN12: 1199 epochs x 260000 samples x 12 SVs = 1.247 GB of IQ), where the
+    oracle would need minutes: size-independent properties instead.
+      * chunking / leg layout must not matter: chunk 1040 (default), 1024 and 520 give the same bytes;
+      * a run split in two calls with the carried state equals the single run (gal_chan_state_t contract);
+      * the first 8 epochs equal the oracle; the chain self-check is clean; no leg is walked twice."""
+    import torch
+
+    n, rate = 260000, 2.6e6
+    p = pkg.workloads.m_syn12()
+    E = p.shape[0]
+    outs = []
+    for chunk in (0, 1024, 520):
+        with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0, chunk_samples=chunk) as eng:
+            eng.plan(p)
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr())
+            st, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0
+            if chunk == 0:
+                walked, translated, fallbacks = eng.walk_counts()
+                assert fallbacks == 0 and walked <= E * 8 * 12 + 64, (walked, translated)
+                state_full = st
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref_iq, _ = oracle_run(p[:8], n, rate)
+    assert np.array_equal(outs[0][: 8 * n * 2].cpu().numpy(), ref_iq)
+    del outs[1:]
+    # split run: 700 + 499 epochs
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
+        eng.plan(p[:700])
+        a = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(a.data_ptr())
+        st_a, _ = eng.finish()
+        q = p[700:].copy()
+        q["flags"][0, :12] = 0  # continues from the carried state
+        eng.plan(q, st_a)
+        b = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(b.data_ptr())
+        st_b, _ = eng.finish()
+    assert torch.equal(outs[0][: a.numel()], a) and torch.equal(outs[0][a.numel():], b)
+    act = state_full["prn"] > 0
+    assert np.array_equal(st_b["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+    assert np.array_equal(st_b["page"][act], state_full["page"][act])
+
+
 def test_two_handles_in_flight(pkg):
     """Software pipeline as bench.py runs it: two handles on two streams, executes interleaved."""
     import torch
