@@ -831,11 +831,10 @@ __device__ __forceinline__ void group_begin_slow(const ChanState &c, ChanGroup &
     g.m = g.mw - 16;
 }
 
-// One sample of one channel, src/galileo-sdr.cpp:509-532, branch-free, for a group without a code wrap.
-// Returns ip + (qp << 16).  cs2 = 2 * f_code * delt.  s_lut2 points at entry k = 0 of the first of FOUR
-// 1024-entry tables indexed by k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0,
-// -LUT[k & 511].  The two's-complement mask of :509-510, the sign and the zero case of v are all folded into
-// the LDS address.
+// One sample of one channel, src/galileo-sdr.cpp:509-532, branch-free.  Returns ip + (qp << 16).
+// cs2 = 2 * f_code * delt.  s_lut2 points at entry k = 0 of the first of FOUR 1024-entry tables indexed by
+// k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0, -LUT[k & 511].  The two's-complement
+// mask of :509-510, the sign and the zero case of v are all folded into the LDS address.
 __device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
                                          const int *s_lut2)
 {
@@ -852,6 +851,28 @@ __device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const
     // --- NCO updates, :528-532
     c.y = c.y + cs2;
     c.p = carr_step(c.p, ds);
+    return t;
+}
+
+// The fast group body's version: no code wrap inside the group, and the carrier phase runs MIRRORED -- c.p holds
+// |p| (p and the step have the same sign throughout the group, checked by the caller), so that
+// `p += d; p -= (long)p` (:531-532) becomes  |p| = fract(|p| + |d|): for 0 <= x < 2, x - floor(x) is the
+// reference's x - trunc(x), IEEE addition is sign-symmetric and the subtraction is exact, hence the same bits
+// with one instruction less.  The table index (int)(511 p) = -(int)(511 |p|) for negative p: sgn4 = +-4.
+__device__ __forceinline__ int chan_step_fast(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
+                                              const int sgn4, const int *s_lut2)
+{
+    const int ic = (int)c.y;
+    int off;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(ic), "v"(g.m));
+    const uint32_t q = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);
+    const int k = (int)(511.0 * c.p);
+    int a4;  // signed byte offset of entry k in table 0
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(a4) : "v"(k), "s"(sgn4));
+    asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(q), "v"(a4));
+    const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_lut2) + a4);
+    c.y = c.y + cs2;
+    c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));
     return t;
 }
 
@@ -949,10 +970,15 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 
 // idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 gives a zero
 // contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
-#define GAL_NEAR(j) if (j < NCH && j < nact) near |= ch##j.y >= thr;
+#define GAL_HI(x) ((uint32_t)(d2u(x) >> 32))
+#define GAL_NEAR(j) if (j < NCH && j < nact) near |= (ch##j.y >= thr) | ((int)(GAL_HI(ch##j.p) ^ GAL_HI(ds##j)) < 0);
+#define GAL_MIRROR(j)                                                                                   \
+    if (j < NCH && j < nact)                                                                            \
+        ch##j.p = u2d(((uint64_t)(GAL_HI(ch##j.p) ^ (GAL_HI(ds##j) & 0x80000000u)) << 32) | (uint32_t)d2u(ch##j.p));
 #define GAL_BEGIN_F(j) if (j < NCH && j < nact) group_begin_fast<j>(ch##j, gr##j, s_str);
 #define GAL_BEGIN_S(j) if (j < NCH && j < nact) group_begin_slow<j>(ch##j, gr##j, s_str);
-#define GAL_STEP_F(j) if (j < NCH) acc += chan_step(ch##j, gr##j, cs##j, ds##j, s_lut2);
+#define GAL_SGN4(j) const int sg4##j = 4 + (((int)(d2u(ds##j) >> 32) >> 31) & -8); /* +-4, scalar ALU */
+#define GAL_STEP_F(j) if (j < NCH) acc += chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, s_lut2);
 #define GAL_STEP_S(j) if (j < NCH) acc += chan_step_wrap(ch##j, gr##j, cs##j, ds##j, s_lut2);
 #define GAL_END(j) if (j < NCH && j < nact) group_end<j>(ch##j, gr##j, Pd, act, e);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
@@ -972,6 +998,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         GAL_NEAR(a) GAL_NEAR(b) GAL_NEAR(c) GAL_NEAR(d)                          \
         if (__builtin_amdgcn_ballot_w64(near) == 0) {                            \
             GAL_BEGIN_F(a) GAL_BEGIN_F(b) GAL_BEGIN_F(c) GAL_BEGIN_F(d)          \
+            GAL_MIRROR(a) GAL_MIRROR(b) GAL_MIRROR(c) GAL_MIRROR(d)              \
+            GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
             _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
             {                                                                    \
                 int acc = o[u];                                                  \
@@ -979,6 +1007,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 GAL_PIN(a, b, c, d)                                              \
                 o[u] = acc;                                                      \
             }                                                                    \
+            GAL_MIRROR(a) GAL_MIRROR(b) GAL_MIRROR(c) GAL_MIRROR(d)              \
         } else {                                                                 \
             GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)          \
             _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
@@ -1038,6 +1067,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_PART
 #undef GAL_PIN
 #undef GAL_NEAR
+#undef GAL_MIRROR
+#undef GAL_HI
+#undef GAL_SGN4
 #undef GAL_BEGIN_F
 #undef GAL_BEGIN_S
 #undef GAL_STEP_F
@@ -1053,7 +1085,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         const size_t cp = (size_t)idx * G.CP1 + c + 1;                                \
         const uint32_t v = Pd->cp_ib[cp];                                             \
         bad += d2u(ch##j.y) != d2u(2.0 * Pd->cp_x[cp]);                               \
-        bad += d2u(ch##j.p) != d2u(Pd->cp_p[cp]);                                     \
+        bad += ch##j.p != Pd->cp_p[cp]; /* numeric: the mirrored form may leave -0.0 for +0.0 */ \
         bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
     }
         GAL_CH_LIST(GAL_CHECK)
