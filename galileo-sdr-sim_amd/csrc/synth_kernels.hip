@@ -8,19 +8,21 @@
 //                  checkpoint (phase, symbol index, page-flip flag) every R samples           [nco_walk.h]
 //   k_pages        which page is in force at each epoch start (pages change only when a symbol counter
 //                  wraps inside the sample loop, :497-506)                [both on the helper stream]
-//   k_carr_guess / k_walk_carr / k_carr_scan (+ k_carr_publish), 2-4 passes
+//   k_carr_guess / k_walk_carr / k_carr_scan (+ k_carr_publish), normally 2 passes
 //                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively on LEGS
 //                  (8 per epoch): a leg is walked from its anchor = the last wrap event before it (first
-//                  guess: ideal arithmetic); the stitcher accepts a leg only when its anchor is BITWISE the
-//                  claim of the verified chain before it, otherwise re-anchors it at the predicted claim
-//                  (rounded-add chains commute with shifts on the 2^-52 grid every wrap residual lives on)
+//                  guess: drift-compensated ideal arithmetic); the stitcher accepts a leg only when its
+//                  anchor is BITWISE the claim of the verified chain before it, otherwise re-anchors it at
+//                  the predicted claim (rounded-add chains commute with shifts on the 2^-52 grid every wrap
+//                  residual lives on, up to one predictable tie flip).  A re-anchored leg whose anchor only
+//                  moved by less than its binade margin is TRANSLATED in the next pass instead of walked.
 //   k_state_phase  end-of-batch carrier phase per slot
 //   k_synth<NCH>   the hot kernel: one lane replays R consecutive samples for ALL active channels with the
 //                  reference's exact operation sequence from its checkpoint, accumulates packed
-//                  (Q<<16)+I in a register, and stores int16 I/Q in 64-byte bursts.  PRN memory codes (bit
-//                  planes) and the sin/cos LUT live in LDS.  Each lane finally checks its end state against
-//                  the next checkpoint, so the closed-form walkers are verified against genuine stepping
-//                  on every run.
+//                  (Q<<16)+I in a register, and stores int16 I/Q in 64-byte bursts.  PRN memory codes (as
+//                  2-bit-per-half-chip streams) and the sin/cos LUT live in LDS.  Each lane finally checks
+//                  its end state against the next checkpoint, so whatever the walkers and the translation
+//                  produced is verified against genuine stepping on every run.
 // No MFMA anywhere: this is FP64/integer ALU work bounded above by the 4 B/sample HBM write.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
