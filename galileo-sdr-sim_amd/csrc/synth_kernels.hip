@@ -107,26 +107,47 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
     long long c_w = 0;
     double c_r = 0.0;
     const double start0 = P.state_in[s].carr_phase;
+    // the loads of round r+1 are issued before round r is processed (the rounds are serial, the loads are not)
+    int n_prn = 0;
+    uint32_t n_fl = 0;
+    double n_p0 = 0.0, n_ds = 0.0;
+    {
+        const int idx0 = (lane < P.E ? lane : 0) * P.S + s;
+        n_prn = lane < P.E ? P.prn[idx0] : 0;
+        n_fl = P.flags[idx0];
+        n_p0 = P.p0[idx0];
+        n_ds = P.dstep[idx0];
+    }
     for (int base = 0; base < P.E; base += 64) {
         const int e = base + lane;
         const bool in = e < P.E;
-        const int idx = (in ? e : 0) * P.S + s;
-        const int prn = in ? P.prn[idx] : 0;
-        const uint32_t fl = P.flags[idx];
-        const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
+        const int prn = n_prn;
+        const uint32_t fl = n_fl;
+        const double p0 = (fl & GAL_CH_RESTART) ? n_p0 : start0;
+        const double ds_raw = n_ds;
+        {
+            const int en = e + 64;
+            const int idxn = (en < P.E ? en : 0) * P.S + s;
+            n_prn = en < P.E ? P.prn[idxn] : 0;
+            n_fl = P.flags[idxn];
+            n_p0 = P.p0[idxn];
+            n_ds = P.dstep[idxn];
+        }
         const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
-        const double d = eff_step(P.dstep[idx]);  // mean advance of the rounded chain (nco_walk.h)
-        const double adv = (double)P.N * d;
+        const double d = eff_step(ds_raw);  // mean advance of the rounded chain (nco_walk.h)
+        const double adv = prn > 0 ? (double)P.N * d : 0.0;  // idle epochs leave the phase alone
+        const int rs = reset ? 1 : 0;
         double mine = 0.0;
+        // branch-free on purpose: the only dependent chain per step is select -> add -> trunc -> sub on the
+        // wave-uniform phase; the lane reads (v_readlane with literal lanes) do not depend on it
 #pragma unroll
         for (int k = 0; k < 64; ++k) {
-            const int prn_k = __builtin_amdgcn_readlane(prn, k);
-            if (prn_k > 0) {  // wave-uniform branch
-                if (__builtin_amdgcn_readlane((int)reset, k)) p = readlane_f64(p0, k);
-                if (k == lane) mine = p;
-                p = p + readlane_f64(adv, k);
-                p = p - __builtin_trunc(p);
-            }
+            const double a_k = readlane_f64(adv, k);
+            const double p0_k = readlane_f64(p0, k);
+            p = __builtin_amdgcn_readlane(rs, k) ? p0_k : p;
+            mine = (k == lane) ? p : mine;
+            p = p + a_k;
+            p = p - __builtin_trunc(p);
         }
         // the last event up to the END of my epoch: a wrap inside it, else its root, else nothing
         int kind = 0;
@@ -146,27 +167,15 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
                 r = mine;
             }
         }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {  // inclusive "last one that speaks"
-            const int k2 = __shfl_up(kind, off);
-            const long long w2 = __shfl_up(w, off);
-            const double r2 = __shfl_up(r, off);
-            if (lane >= off && kind == 0) {
-                kind = k2;
-                w = w2;
-                r = r2;
-            }
-        }
-        if (kind == 0) {
-            kind = c_kind;
-            w = c_w;
-            r = c_r;
-        }
-        // exclusive value = what stands before my epoch
-        int xk = __shfl_up(kind, 1);
-        long long xw = __shfl_up(w, 1);
-        double xr = __shfl_up(r, 1);
-        if (lane == 0) {
+        // "the last one that speaks" before my epoch: a ballot names the speakers, the highest one below my lane
+        // is the source -- one cross-lane read per word instead of a 6-step shuffle scan
+        const uint64_t spk = __builtin_amdgcn_ballot_w64(kind != 0);
+        const uint64_t below = spk & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        int xk = __shfl(kind, src);
+        long long xw = __shfl(w, src);
+        double xr = __shfl(r, src);
+        if (!below) {  // nobody in this round before me: what the previous rounds left
             xk = c_kind;
             xw = c_w;
             xr = c_r;
@@ -177,9 +186,12 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
             P.gss_w[(size_t)s * P.E + e] = use_root ? (long long)e * P.N : xw;
             P.gss_r[(size_t)s * P.E + e] = use_root ? mine : xr;
         }
-        c_kind = __shfl(kind, 63);
-        c_w = __shfl(w, 63);
-        c_r = __shfl(r, 63);
+        if (spk) {  // wave-uniform: the last speaker of this round is the carry of the next
+            const int last = 63 - __builtin_clzll(spk);
+            c_kind = __shfl(kind, last);
+            c_w = __shfl(w, last);
+            c_r = __shfl(r, last);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk
