@@ -1036,6 +1036,16 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         __builtin_amdgcn_sched_barrier(0);                                       \
     }
 
+// Balanced parts: a part with a single channel has no ILP to hide its FP64/LDS latency, so 5, 6, 7, 9 and 10
+// channels are cut 3+2, 3+3, 4+3, 3+3+3 and 4+3+3 instead of 4+1, 4+2, 4+3, 4+4+1 and 4+4+2 (positions >= NCH
+// are compiled out; 10 and 11 serve as the dummies).
+#define GAL_ALL_PARTS                                                                            \
+    if constexpr (NCH == 5) { GAL_PART(0, 1, 2, 11) GAL_PART(3, 4, 10, 11) }                      \
+    else if constexpr (NCH == 6) { GAL_PART(0, 1, 2, 11) GAL_PART(3, 4, 5, 11) }                  \
+    else if constexpr (NCH == 9) { GAL_PART(0, 1, 2, 11) GAL_PART(3, 4, 5, 11) GAL_PART(6, 7, 8, 11) } \
+    else if constexpr (NCH == 10) { GAL_PART(0, 1, 2, 3) GAL_PART(4, 5, 6, 11) GAL_PART(7, 8, 9, 11) } \
+    else { GAL_PART(0, 1, 2, 3) GAL_PART(4, 5, 6, 7) GAL_PART(8, 9, 10, 11) }
+
     int s0 = 0;
     for (; s0 + SYN_GROUP <= nsteps; s0 += SYN_GROUP) {
         constexpr int GSZ = SYN_GROUP;
@@ -1056,9 +1066,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #pragma unroll
             for (int u = 0; u < SYN_GROUP; ++u) o[u] = 0;
         }
-        GAL_PART(0, 1, 2, 3)
-        GAL_PART(4, 5, 6, 7)
-        GAL_PART(8, 9, 10, 11)
+        GAL_ALL_PARTS
         if (vec_ok) {
 #pragma unroll
             for (int q = 0; q < SYN_GROUP / 4; ++q)
@@ -1073,11 +1081,10 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         constexpr int GSZ = 1;
         int o[1];
         o[0] = ACC ? GAL_UNPACK(out[s0]) : 0;
-        GAL_PART(0, 1, 2, 3)
-        GAL_PART(4, 5, 6, 7)
-        GAL_PART(8, 9, 10, 11)
+        GAL_ALL_PARTS
         out[s0] = GAL_PACK(o[0]);
     }
+#undef GAL_ALL_PARTS
 #undef GAL_PART
 #undef GAL_PIN
 #undef GAL_NEAR
