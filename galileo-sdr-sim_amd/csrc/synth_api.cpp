@@ -417,7 +417,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
     P.translate = 1;
-    if (const char *env = getenv("GAL_WALK_TRANSLATE")) P.translate = atoi(env) != 0;  // test hook
+    // test hook: 0 = never translate, 2 = translate with one deliberately wrong shift (exercises the fallback)
+    if (const char *env = getenv("GAL_WALK_TRANSLATE")) P.translate = atoi(env);
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
 

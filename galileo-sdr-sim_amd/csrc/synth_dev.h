@@ -57,7 +57,7 @@ struct DevPlan {
     int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
     long long *tpos;     // global sample index right after that tie step
     double *shift;       // pending translation (new anchor residual - walked anchor residual)
-    int translate;       // 0: always re-walk (fallback / tests)
+    int translate;       // 1 normal; 0: always re-walk (fallback / tests); 2: test hook, see k_walk_carr
 
     // checkpoints, one per chunk + end state
     double *cp_x;     // [E][S][CP1]

@@ -249,7 +249,8 @@ __global__ void k_walk_carr(DevPlan P, int first)
             // 2^-52 smaller than the leg's binade margin): a walk from the new anchor would visit the same
             // binades step by step, so every state it produces is the old one plus the shift, bit for bit
             // (nco_walk.h: binade_margin; ties: WalkOut::tdir).  k_synth's replay check covers it.
-            const double dl = P.shift[li];
+            double dl = P.shift[li];
+            if (P.translate == 2 && li == 5) dl += 4.440892098500626e-16;  // TEST HOOK: a deliberately wrong shift
             // an odd shift flips the first tie of the walk: from that wrap on the trajectory is off by dl2
             const int td = P.tdir[li];
             const bool flip = td != 0 && (d_residue_u52(dl) & 1);

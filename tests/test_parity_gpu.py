@@ -232,6 +232,24 @@ def test_full_size_properties(pkg):
     assert np.array_equal(st_b["page"][act], state_full["page"][act])
 
 
+def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
+    """Safety net of the translated acceptance: a leg shifted by the wrong amount (test hook) must be caught by
+    k_synth's replay check; gal_synth_finish then redoes the chain with every leg walked and repeats the
+    synthesis -- the caller still gets bit-exact IQ, and the fallback is counted."""
+    p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=4, n_slots=8, samples_per_epoch=260000, seed=99)
+    monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")
+    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0) as eng:
+        iq, st, stats = eng.run_host(p)
+        walked, translated, fallbacks = eng.walk_counts()
+    ref_iq, ref_st = oracle_run(p, 260000, 2.6e6)
+    assert fallbacks == 1 and stats["chain_mismatch"] == 0
+    assert np.array_equal(iq, ref_iq)
+    act = ref_st["prn"] > 0
+    assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+    monkeypatch.setenv("GAL_WALK_TRANSLATE", "0")  # and the all-walked mode on its own
+    _compare(pkg, p, 260000)
+
+
 def test_two_handles_in_flight(pkg):
     """Software pipeline as bench.py runs it: two handles on two streams, executes interleaved."""
     import torch
