@@ -174,67 +174,82 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
     // the one binade in which |d| is an odd multiple of half an ulp (round-to-even ties inside a batch)
     const uint32_t e_tie = ed + 1u + (uint32_t)__builtin_ctzll(da | (1ull << 52));
     double mg = 4.0;
+    // one genuine step with everything that hangs on it (wrap bookkeeping, tie record)
+#define GAL_GENUINE_STEP()                                                                           \
+    {                                                                                                \
+        const double q_ = p + d;                                                                     \
+        const double t_ = __builtin_trunc(q_);                                                       \
+        const bool wrapped_ = t_ != 0.0;                                                             \
+        if (tieprone && wrapped_ && o.tdir == 0) { /* rare: only steps that are multiples of 2^-53 */ \
+            const double bv_ = q_ - p; /* TwoSum: err = (p + d) - q exactly */                       \
+            const double err_ = (p - (q_ - bv_)) + (d - bv_);                                        \
+            if (err_ == 1.1102230246251565e-16) o.tdir = -1; /* exact sum above q: rounded down */   \
+            if (err_ == -1.1102230246251565e-16) o.tdir = 1; /* rounded up */                        \
+            if (o.tdir) o.tpos = i + 1;                                                              \
+        }                                                                                            \
+        p = q_ - t_; /* == carr_step(p, d) */                                                        \
+        ++i;                                                                                         \
+        o.last_w = wrapped_ ? i : o.last_w;                                                          \
+        o.last_r = wrapped_ ? p : o.last_r;                                                          \
+    }
+    // ---- general iterations: until phase and step have the same sign (at most one carrier cycle, after a
+    //      Doppler sign change or a restart), and throughout for degenerate steps
     while (i < N) {
+        const uint64_t pb = d2u(p);
+        if (lean_d && (((uint32_t)(pb >> 63) == dsign) || (pb & ~kSign) == 0)) break;
         if (next_cp == i) {
             emit(c, p);
             ++c;
             next_cp += R;
         }
         const int stop = next_cp < N ? next_cp : N;  // never run past a checkpoint or the end
-        const uint64_t pb = d2u(p), pa = pb & ~kSign;
-        const bool lean = lean_d && (((uint32_t)(pb >> 63) == dsign) || pa == 0);
-        if (lean) {
-            const uint32_t ea = (uint32_t)(pa >> 52);
-            const bool can = ea > ed;                      // above the step's binade (hence normal)
-            const uint64_t pkb = (uint64_t)(can ? ea : 1023u) << 52;
-            const double pk = u2d(pkb);                    // binade floor 2^k
-            const double top = u2d(pkb | 0x000fffffffffffffull);  // largest double of the binade
-            const double a = u2d(pa);
-            const double dk = (ad + pk) - pk;              // RN_g(|d|), ties to even; > 0 because |d| >= 2^-30 > g/2
-            const bool odd_tie = (ea == e_tie) & ((uint32_t)pa & 1u);  // a tie binade needs x/g even
-            const double t = top - a;                      // room to the binade ceiling, exact, >= 0
-            // t / dk through the caller's reciprocal of |d|: |dk - |d|| <= g/2 keeps the estimate within
-            // 2^-33 / |d| <= 2^-3 of the true quotient, so it overshoots floor(t/dk) by at most one, which the
-            // exact remainder test catches (n*dk is a multiple of g below 2^(k+1): exactly representable)
-            double q = t * inv_ad;
-            const double qmax = (double)(stop - i);
-            q = q > qmax ? qmax : q;
-            int n = (int)q;
-            n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
-            n = n < 0 ? 0 : n;
-            n = (can & !odd_tie) ? n : 0;
-            const double nd = (double)n;
-            const double room = fma_exact(-nd, dk, t);     // ceiling minus the last state of the batch
-            const double m1 = can ? a - pk : binade_margin(p, p);
-            mg = m1 < mg ? m1 : mg;
-            mg = (can && room < mg) ? room : mg;
-            p = fma_exact(nd, dsign ? -dk : dk, p);
-            i += n;
-        } else {
-            const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
-            const double a0 = p;
-            p = fma_exact((double)b.n, b.inc, p);
-            const double m = binade_margin(a0, p);
-            mg = m < mg ? m : mg;
-            i += b.n;
-        }
-        if (i < stop) {
-            const double q = p + d;
-            const double t = __builtin_trunc(q);
-            const bool wrapped = t != 0.0;
-            if (tieprone && wrapped && o.tdir == 0) {  // rare: only steps that are multiples of 2^-53
-                const double bv = q - p;               // TwoSum: err = (p + d) - q exactly
-                const double err = (p - (q - bv)) + (d - bv);
-                if (err == 1.1102230246251565e-16) o.tdir = -1;   // exact sum above q: rounded down
-                if (err == -1.1102230246251565e-16) o.tdir = 1;   // rounded up
-                if (o.tdir) o.tpos = i + 1;
-            }
-            p = q - t;  // == carr_step(p, d)
-            ++i;
-            o.last_w = wrapped ? i : o.last_w;
-            o.last_r = wrapped ? p : o.last_r;
-        }
+        const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
+        const double a0 = p;
+        p = fma_exact((double)b.n, b.inc, p);
+        const double m = binade_margin(a0, p);
+        mg = m < mg ? m : mg;
+        i += b.n;
+        if (i < stop) GAL_GENUINE_STEP()
     }
+    // ---- lean iterations: |p| only grows until the wrap, which keeps the sign -- the regime is permanent
+    const double sd = dsign ? -1.0 : 1.0;
+    while (i < N) {
+        if (next_cp == i) {
+            emit(c, p);
+            ++c;
+            next_cp += R;
+        }
+        const int stop = next_cp < N ? next_cp : N;
+        const uint64_t pa = d2u(p) & ~kSign;
+        const uint32_t ea = (uint32_t)(pa >> 52);
+        const bool can = ea > ed;                      // above the step's binade (hence normal)
+        const uint64_t pkb = (uint64_t)ea << 52;
+        const double pk = u2d(pkb);                    // binade floor 2^k (0 for a zero / subnormal phase)
+        const double top = u2d(pkb | 0x000fffffffffffffull);  // largest double of the binade
+        const double a = u2d(pa);
+        const double dk = (ad + pk) - pk;              // RN_g(|d|), ties to even; > 0 because |d| >= 2^-30 > g/2
+        const bool odd_tie = (ea == e_tie) & ((uint32_t)pa & 1u);  // a tie binade needs x/g even
+        const double t = top - a;                      // room to the binade ceiling, exact, >= 0
+        // t / dk through the caller's reciprocal of |d|: |dk - |d|| <= g/2 keeps the estimate within
+        // 2^-33 / |d| <= 2^-3 of the true quotient, so it overshoots floor(t/dk) by at most one, which the
+        // exact remainder test catches (n*dk is a multiple of g below 2^(k+1): exactly representable)
+        double q = t * inv_ad;
+        const double qmax = (double)(stop - i);
+        q = q > qmax ? qmax : q;
+        int n = (int)q;
+        n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
+        n = n < 0 ? 0 : n;
+        n = (can & !odd_tie) ? n : 0;
+        const double nd = (double)n;
+        const double room = fma_exact(-nd, dk, t);     // ceiling minus the last state of the batch (>= 0)
+        const double m1 = a - pk;                      // first state of the batch above the binade floor
+        mg = m1 < mg ? m1 : mg;
+        mg = room < mg ? room : mg;
+        p = fma_exact(nd * sd, dk, p);
+        i += n;
+        if (i < stop) GAL_GENUINE_STEP()
+    }
+#undef GAL_GENUINE_STEP
     const double m = binade_margin(p, p);  // the state handed over
     o.margin = m < mg ? m : mg;
     o.p = p;
