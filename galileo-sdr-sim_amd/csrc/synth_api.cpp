@@ -67,7 +67,7 @@ void init_tables()
 }
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
-constexpr int kDefaultPasses = 4;   // speculative carrier passes enqueued up front (3 normally suffice)
+constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare
 
 }  // namespace
 

@@ -259,7 +259,15 @@ __global__ void k_walk_carr(DevPlan P, int first)
             int nck = P.nchunks - w * P.Lc;
             nck = nck > P.Lc ? P.Lc : nck;
             double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-            for (int c = 0; c < nck; ++c) cpp[c] += (A + (long long)c * P.R >= tp) ? dl2 : dl;
+            // (eight independent read-modify-writes in flight: a plain loop waits for every load)
+            for (int c0 = 0; c0 < nck; c0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = c0 + k < nck ? cpp[c0 + k] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < nck) cpp[c0 + k] = v[k] + ((A + (long long)(c0 + k) * P.R >= tp) ? dl2 : dl);
+            }
             if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
             P.pend[li] += dl2;
             if (P.clm_w[li] >= 0) P.clm_r[li] += (P.clm_w[li] >= tp) ? dl2 : dl;
