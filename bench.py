@@ -196,7 +196,10 @@ def main():
         solo_ms = sum(x["ms_synth"] for x in inflight_stats) / len(inflight_stats)
     samples_per_step = args.epochs * n_samp
     # integrity of what was timed: a checksum of the last output (outside the timed region)
-    chk = int(out.view(torch.int32).to(torch.int64).sum().item()) & 0xFFFFFFFF
+    chk = 0
+    v32 = out.view(torch.int32)
+    for a in range(0, v32.numel(), 1 << 28):  # in pieces: the int64 widening of a 60 GB output is 120 GB
+        chk = (chk + int(v32[a:a + (1 << 28)].to(torch.int64).sum().item())) & 0xFFFFFFFF
     elapsed, total_samples, chk = pkg.shard.reduce_report(dist, "cuda", elapsed, samples_per_step * args.steps, chk)
     value = total_samples / elapsed / 1e6
 
