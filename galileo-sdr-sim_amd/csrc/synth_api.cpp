@@ -265,7 +265,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             if (r.prn > GAL_NUM_PRN) return fail(GAL_E_INVAL, "epoch %d slot %d: PRN %d out of range", e, s, r.prn);
             if (r.ibit0 < 0 || r.ibit0 >= GAL_N_SYM_PAGE)
                 return fail(GAL_E_INVAL, "epoch %d slot %d: ibit0 %d out of range", e, s, r.ibit0);
-            if (!(r.code_phase0 >= 0.0) || !(r.code_phase0 < 2.0 * GAL_CODE_LEN) || !std::isfinite(r.f_code) ||
+            // the reference produces code_phase0 in [0, 4092) (src/gal-sig.cpp:336); a pending wrap is accepted,
+            // but not one that is followed by a second wrap within a few samples (k_synth: one wrap per group)
+            if (!(r.code_phase0 >= 0.0) || !(r.code_phase0 < 1.5 * GAL_CODE_LEN) || !std::isfinite(r.f_code) ||
                 !(r.f_code > 0.0) || !std::isfinite(r.f_carr))
                 return fail(GAL_E_INVAL, "epoch %d slot %d: bad phase/frequency", e, s);
             if (!(std::fabs(r.f_carr) < h->cfg.sample_rate) || !(r.f_code < h->cfg.sample_rate * 4000.0))

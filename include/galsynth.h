@@ -56,7 +56,7 @@ typedef struct gal_chan_epoch {
     uint32_t reserved;
     double   f_carr;       /* Hz, chan.f_carr (src/gal-sig.cpp:318)                                             */
     double   f_code;       /* Hz, chan.f_code (src/gal-sig.cpp:320)                                             */
-    double   code_phase0;  /* chips, chan.code_phase at epoch start (src/gal-sig.cpp:336)                       */
+    double   code_phase0;  /* chips, chan.code_phase at epoch start (src/gal-sig.cpp:336), in [0, 6138)         */
     double   carr_phase0;  /* cycles; used only with GAL_CH_RESTART (src/channel.cpp:98-99)                     */
     uint32_t page_next[GAL_PAGE_WORDS]; /* page generateINavMsg(grx_of_this_epoch) would produce: installed when
                                            ibit wraps 499->0 inside this epoch (src/galileo-sdr.cpp:497-506)    */
