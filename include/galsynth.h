@@ -54,8 +54,8 @@ typedef struct gal_chan_epoch {
     int32_t  ibit0;        /* chan.ibit at epoch start, 0..499 (src/gal-sig.cpp:334,338)                         */
     uint32_t flags;        /* GAL_CH_*                                                                           */
     uint32_t reserved;
-    double   f_carr;       /* Hz, chan.f_carr (src/gal-sig.cpp:318)                                             */
-    double   f_code;       /* Hz, chan.f_code (src/gal-sig.cpp:320)                                             */
+    double   f_carr;       /* Hz, chan.f_carr (src/gal-sig.cpp:318); |f_carr| < sample_rate                     */
+    double   f_code;       /* Hz, chan.f_code (src/gal-sig.cpp:320); 2^-20 <= f_code / sample_rate <= 0.5      */
     double   code_phase0;  /* chips, chan.code_phase at epoch start (src/gal-sig.cpp:336), in [0, 6138)         */
     double   carr_phase0;  /* cycles; used only with GAL_CH_RESTART (src/channel.cpp:98-99)                     */
     uint32_t page_next[GAL_PAGE_WORDS]; /* page generateINavMsg(grx_of_this_epoch) would produce: installed when
