@@ -86,3 +86,49 @@ def test_reallocation_every_30s(pkg):
                 assert abs(r["f_carr"]) < 5000 and abs(r["f_code"] - 1.023e6) < 4
             prev[s] = r["prn"]
     assert n_restart >= (rows["prn"][0] > 0).sum()
+
+
+def _ecef(lat_deg, lon_deg, h):
+    a, e2 = 6378137.0, 0.0818191908426 ** 2
+    la, lo = np.radians(lat_deg), np.radians(lon_deg)
+    n = a / np.sqrt(1.0 - e2 * np.sin(la) ** 2)
+    return np.array([(n + h) * np.cos(la) * np.cos(lo), (n + h) * np.cos(la) * np.sin(lo), (n * (1 - e2) + h) * np.sin(la)])
+
+
+def test_user_motion_file(pkg, tmp_path):
+    """-u: CSV `t,x,y,z` (ECEF m, 10 Hz) -- new semantics, the reference parses the option but ignores the file
+    (src/main.cpp:216,323); position enters only through xyz[iumd] (src/galileo-sdr.cpp:448).  A track that
+    stands still gives the same SV set as -l at that place and constant geometry rates; a 10 m/s circle
+    modulates the Doppler of every SV within the line-of-sight bound; a short file limits the duration."""
+    import pytest
+
+    x0 = _ecef(-6.0, 51.0, 100.0)
+    still = tmp_path / "still.csv"
+    still.write_text("".join("%.1f,%.4f,%.4f,%.4f\n" % (0.1 * i, *x0) for i in range(60)))
+    a = pkg.Scenario(NAV, llh=(-6, 51, 100), start="2022/02/20,12:00:00", duration_s=6, iono_enable=False).all()
+    b = pkg.Scenario(NAV, llh=(0, 0, 0), start="2022/02/20,12:00:00", duration_s=6, iono_enable=False,
+                     motion_file=str(still)).all()
+    assert a.shape == b.shape == (59, 16)
+    assert np.array_equal(a["prn"], b["prn"])
+    assert np.allclose(a["f_carr"], b["f_carr"], atol=0.05)  # same place up to the 0.1 mm of the CSV digits
+    # circle of r = 100 m at 10 m/s in the local horizontal plane (east/north at the start point)
+    la, lo = np.radians(-6.0), np.radians(51.0)
+    east = np.array([-np.sin(lo), np.cos(lo), 0.0])
+    north = np.array([-np.sin(la) * np.cos(lo), -np.sin(la) * np.sin(lo), np.cos(la)])
+    t = 0.1 * np.arange(300)
+    track = x0 + 100.0 * (np.outer(np.cos(0.1 * t) - 1.0, east) + np.outer(np.sin(0.1 * t), north))
+    circ = tmp_path / "circle.csv"
+    circ.write_text("".join("%.1f,%.4f,%.4f,%.4f\n" % (t[i], *track[i]) for i in range(300)))
+    c = pkg.Scenario(NAV, start="2022/02/20,12:00:00", duration_s=30, iono_enable=False, motion_file=str(circ)).all()
+    s = pkg.Scenario(NAV, llh=(-6, 51, 100), start="2022/02/20,12:00:00", duration_s=30, iono_enable=False).all()
+    assert c.shape == (299, 16) and np.array_equal(c["prn"][0], s["prn"][0])
+    act = c["prn"][0] > 0
+    dev = (c["f_carr"] - s["f_carr"])[:, act]
+    assert np.abs(dev).max() < 10.0 / 0.1902936727983649 + 1.0  # |v| / lambda
+    assert np.abs(dev).max() > 10.0                             # and it does move
+    assert np.all(np.abs(c["f_code"][:, act] - 1.023e6 - c["f_carr"][:, act] * 0.0006493506493506494) < 1e-6)
+    # fewer positions than the requested duration: the file decides
+    short = pkg.Scenario(NAV, start="2022/02/20,12:00:00", duration_s=30, iono_enable=False, motion_file=str(still))
+    assert short.all().shape[0] == 59
+    with pytest.raises(pkg.GalScenError):
+        pkg.Scenario(NAV, start="2022/02/20,12:00:00", duration_s=3, motion_file=str(tmp_path / "missing.csv"))
