@@ -488,16 +488,10 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), st));
     HIP_TRY(hipEventRecord(h->ev[0], st));
     galk_launch_prep(P, st);
-    // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the
-    // carrier chain: they run on a second stream beside the carrier passes and join before k_synth
     HIP_TRY(hipEventRecord(h->ev_prep, st));
-    HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
-    galk_launch_walk_code(P, h->aux_stream);
-    galk_launch_pages(P, h->aux_stream);
-    HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     galk_launch_carr_guess(P, st);
     // Speculative carrier walk: kDefaultPasses passes are enqueued back to back (each is a no-op once the
-    // chain is verified -- 2-3 normally suffice), then the synthesis kernel, all asynchronously: the host does
+    // chain is verified -- 2 normally suffice), then the synthesis kernel, all asynchronously: the host does
     // not wait here, so several handles can be kept in flight (the latency-bound walk of one batch then
     // runs beside the issue-bound synthesis of another).  gal_synth_finish() looks at the counter; in the rare
     // case that the chain was not verified by then it iterates further and repeats the synthesis.
@@ -506,6 +500,15 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, st);
         galk_launch_carr_scan(P, st);
+        if (pass == 0) {
+            // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on
+            // the carrier chain: they run on a second stream beside the carrier passes and join before k_synth
+            // (enqueued after the first carrier pass: the carrier chain is the critical path)
+            HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
+            galk_launch_walk_code(P, h->aux_stream);
+            galk_launch_pages(P, h->aux_stream);
+            HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
+        }
     }
     HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
     galk_launch_state_phase(P, st);
