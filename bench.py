@@ -7,6 +7,7 @@ workload M-SYN12 of SURVEY.md §8(d) = BASELINE.json configs[1] geometry (static
 2.6 MS/s -> 1199 epochs x 260000 samples = 311.74 M complex samples = 1.247 GB of int16 IQ).
 
     python bench.py --gpus N --steps K --warmup W
+Default: two engine handles in flight (software pipeline, see --pipeline), 100 timed steps.
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`;
 one process per GPU, each rank synthesises its OWN independent scenario of the same size (weak scaling,
 no data-path collective: scenarios shard embarrassingly); torch.distributed (RCCL)
@@ -98,18 +99,20 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (1.6 ms each; the pipeline is empty at both "
+                    "ends of the timed region, so few steps mostly measure its fill and drain)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--epochs", type=int, default=1199, help="epochs per step (default: the 120 s scenario)")
     ap.add_argument("--channels", type=int, default=12)
     ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = auto)")
     ap.add_argument("--workload", default="syn12", choices=["syn12", "syn24", "dyn"],
                     help="syn12 = headline M-SYN12 (BASELINE configs[1] size); syn24 = config 4 geometry (24 SVs, "
                     "25 MS/s); dyn = config 3 (12 SVs, Doppler from a 10 Hz circular track)")
-    ap.add_argument("--pipeline", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="engine handles in flight: software pipeline, the NCO walks of the next steps (latency "
-                    "bound) run beside the synthesis kernel of step k (issue bound); every step still does the "
-                    "complete pass into its own buffers (measured: 1 -> 2 -> 3 handles = 2.17 -> 1.85 -> 1.80 ms)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4],
+                    help="engine handles in flight: 2 = software pipeline, the NCO walk of step k+1 (latency "
+                    "bound, on the handle's high-priority stream) runs beside the synthesis kernel of step k (issue "
+                    "bound); every step still does the complete pass into its own buffers (measured: 1 / 2 / 3 "
+                    "handles = 2.19 / 1.67 / 1.85 ms per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -77,6 +77,11 @@ struct gal_synth {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // code-chain walk + page resolution run beside the carrier passes
+    // the walker chain runs on the handle's own HIGH-PRIORITY stream: k_synth fills every SIMD's register file,
+    // so walker workgroups of the next batch only get on when a synthesis wave retires -- with priority they
+    // are first in line then, instead of queueing behind the pending synthesis workgroups of other handles
+    hipStream_t walk_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_walk = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
@@ -166,6 +171,22 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     h->stream = h->own_stream;
     if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
+    {
+        int use = 1;
+        if (const char *env = getenv("GAL_WALK_PRIORITY")) use = atoi(env);  // 0: everything on one stream
+        if (use) {
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&h->walk_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming) != hipSuccess)
+                return bail(fail(GAL_E_DEVICE, "priority stream creation failed"));
+            hipStreamDestroy(h->aux_stream);
+            h->aux_stream = nullptr;
+            if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, greatest) != hipSuccess)
+                return bail(fail(GAL_E_DEVICE, "priority stream creation failed"));
+        }
+    }
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
@@ -218,6 +239,9 @@ int gal_synth_destroy(gal_synth_t *h)
         if (e) hipEventDestroy(e);
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
+    if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->ev_walk) hipEventDestroy(h->ev_walk);
+    if (h->walk_stream) hipStreamDestroy(h->walk_stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -485,11 +509,18 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const DevPlan *P = &h->P;
-    HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), st));
-    HIP_TRY(hipEventRecord(h->ev[0], st));
-    galk_launch_prep(P, st);
-    HIP_TRY(hipEventRecord(h->ev_prep, st));
-    galk_launch_carr_guess(P, st);
+    // ws: the walker chain (the handle's high-priority stream, ordered after the caller's stream by an event)
+    hipStream_t ws = st;
+    if (h->walk_stream) {
+        ws = h->walk_stream;
+        HIP_TRY(hipEventRecord(h->ev_in, st));
+        HIP_TRY(hipStreamWaitEvent(ws, h->ev_in, 0));
+    }
+    HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), ws));
+    HIP_TRY(hipEventRecord(h->ev[0], ws));
+    galk_launch_prep(P, ws);
+    HIP_TRY(hipEventRecord(h->ev_prep, ws));
+    galk_launch_carr_guess(P, ws);
     // Speculative carrier walk: kDefaultPasses passes are enqueued back to back (each is a no-op once the
     // chain is verified -- 2 normally suffice), then the synthesis kernel, all asynchronously: the host does
     // not wait here, so several handles can be kept in flight (the latency-bound walk of one batch then
@@ -498,8 +529,8 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     int n_passes = kDefaultPasses;
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;  // test hook
     for (int pass = 0; pass < n_passes; ++pass) {
-        galk_launch_walk_carr(P, pass == 0, st);
-        galk_launch_carr_scan(P, st);
+        galk_launch_walk_carr(P, pass == 0, ws);
+        galk_launch_carr_scan(P, ws);
         if (pass == 0) {
             // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on
             // the carrier chain: they run on a second stream beside the carrier passes and join before k_synth
@@ -510,8 +541,12 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
             HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
         }
     }
-    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
-    galk_launch_state_phase(P, st);
+    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, ws));
+    galk_launch_state_phase(P, ws);
+    if (ws != st) {
+        HIP_TRY(hipEventRecord(h->ev_walk, ws));
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_walk, 0));
+    }
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
     HIP_TRY(hipEventRecord(h->ev[1], st));
     int rc = enqueue_synth(h, (uint32_t *)iq_dev);
