@@ -279,6 +279,13 @@ def test_randomised_soak(pkg):
         assert np.array_equal(st["page"][act], ref_st["page"][act])
 
 
+def test_single_stream_mode(pkg, monkeypatch):
+    """GAL_WALK_PRIORITY=0: walkers and synthesis on the caller's stream (no internal high-priority stream)."""
+    monkeypatch.setenv("GAL_WALK_PRIORITY", "0")
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=606)
+    _compare(pkg, p, 52000)
+
+
 def test_two_handles_in_flight(pkg):
     """Software pipeline as bench.py runs it: two handles on two streams, executes interleaved."""
     import torch
