@@ -492,6 +492,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 static int enqueue_synth(gal_synth *h, uint32_t *iq)
 {
     const size_t ES = (size_t)h->P.E * h->P.S;
+    if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
+        HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->P.E * (size_t)h->P.N * 4u, h->stream));
+        return GAL_OK;
+    }
     for (int g = 0; g < h->n_groups; ++g) {
         const int rc = galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, h->d_act + (size_t)g * ES,
                                          h->d_nact + (size_t)g * h->P.E, iq, h->stream);

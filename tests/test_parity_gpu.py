@@ -279,6 +279,20 @@ def test_randomised_soak(pkg):
         assert np.array_equal(st["page"][act], ref_st["page"][act])
 
 
+def test_batch_without_any_channel(pkg):
+    """All slots idle for a whole batch (found by tools/fuzz_parity.py with split runs): zeros, as the reference's
+    loop stores when no channel has a PRN (src/galileo-sdr.cpp:489,536-537); also as the tail of a split run."""
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=2, n_slots=8, samples_per_epoch=20000, seed=17)
+    p[2:] = np.zeros((), dtype=p.dtype)
+    iq, st, stats = _compare(pkg, p, 20000)
+    assert not iq[2 * 20000 * 2:].any()
+    with pkg.SynthEngine(samples_per_epoch=20000, n_slots=8, device=0) as eng:
+        iq1, st1, _ = eng.run_host(p[:2])
+        iq2, st2, _ = eng.run_host(p[2:], st1)
+    assert not iq2.any() and not (st2["prn"] > 0).any()
+    assert np.array_equal(np.concatenate([iq1, iq2]), iq)
+
+
 def test_single_stream_mode(pkg, monkeypatch):
     """GAL_WALK_PRIORITY=0: walkers and synthesis on the caller's stream (no internal high-priority stream)."""
     monkeypatch.setenv("GAL_WALK_PRIORITY", "0")

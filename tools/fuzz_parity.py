@@ -84,7 +84,15 @@ def main():
         try:
             with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0,
                                  chunk_samples=chunk) as eng:
-                iq, st, stats = eng.run_host(p)
+                cut = int(rng.integers(1, p.shape[0])) if (p.shape[0] > 1 and rng.random() < 0.4) else 0
+                if cut:  # the same run in two calls, the channel state carried by the caller
+                    iq1, st1, stats = eng.run_host(p[:cut])
+                    fb_total += eng.walk_counts()[2]
+                    iq2, st, stats2 = eng.run_host(p[cut:], st1)
+                    iq = np.concatenate([iq1, iq2])
+                    stats["chain_mismatch"] += stats2["chain_mismatch"]
+                else:
+                    iq, st, stats = eng.run_host(p)
                 fb_total += eng.walk_counts()[2]
         except pkg.GalSynthError as ex:
             # the engine may reject what the oracle also rejects (e.g. f_code / fs outside the window)
