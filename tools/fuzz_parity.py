@@ -22,7 +22,7 @@ RESTART = 1
 
 def random_case(rng, big=False):
     rate = float(rng.choice([2.047e6, 2.6e6, 2.6e6, 2.6e6, 4.0e6, 4.092e6, 10e6, 25e6]))
-    n_slots = int(rng.choice([4, 8, 16, 16, 24]))
+    n_slots = int(rng.choice([4, 8, 16, 16, 24, 40, 64]))
     n_chan = int(rng.integers(1, n_slots + 1))
     n_ep = int(rng.integers(1, 7))
     n_samp = int(rng.choice([rng.integers(16, 3000), rng.integers(3000, 70000), int(rate / 10) if rate <= 4.1e6 else 40000]))
@@ -35,7 +35,7 @@ def random_case(rng, big=False):
     p = pkg.workloads.make_synthetic(n_epochs=n_ep, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp,
                                      sample_rate=rate, seed=int(rng.integers(1 << 30)), doppler_span=span,
                                      drift_hz_per_epoch=float(rng.choice([-0.05, 0.0, 3.0, -40.0])),
-                                     prns=[int(x) for x in rng.permutation(50)[:n_chan] + 1])
+                                     prns=[int(x) for x in (rng.permutation(50)[:n_chan] + 1 if n_chan <= 50 else rng.integers(1, 51, n_chan))])
     for j in range(n_chan):
         r = rng.random()
         if r < 0.15:   # exactly zero or tiny Doppler in some epochs
@@ -53,6 +53,12 @@ def random_case(rng, big=False):
             p["ibit0"][0, j] = int(rng.choice([498, 499, 0]))
         if rng.random() < 0.3:
             p["code_phase0"][int(rng.integers(0, n_ep)), j] = float(rng.choice([4091.99, 4092.0 + 0.3, 6137.9, 0.0]))
+        if rng.random() < 0.15 and n_ep > 1 and p["prn"][-1, j] > 0:  # re-acquired mid-run: fresh carrier and page
+            e = int(rng.integers(1, n_ep))
+            if p["prn"][e, j] > 0:
+                p["flags"][e, j] = RESTART
+                p["carr_phase0"][e, j] = rng.uniform(-0.999, 0.999)
+                p["page_init"][e, j] = p["page_next"][(e + 1) % n_ep, j]
         if rng.random() < 0.2 and n_ep > 2:  # vanish
             e = int(rng.integers(1, n_ep))
             p[e:, j] = np.zeros((), dtype=p.dtype)
