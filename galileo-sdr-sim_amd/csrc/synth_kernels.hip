@@ -757,6 +757,7 @@ __global__ void k_state_phase(DevPlan P)
 #define SYN_BLOCK 256
 #define SYN_GROUP 16
 #define STR_WORDS 512
+#define STR_PITCH 513  // LDS words per channel: one pad word (= word 0) so that "the next word" never wraps
 #ifndef SYN_WAVES
 #define SYN_WAVES 3  // waves per SIMD the register allocation aims at (LDS allows 4 blocks per CU)
 #endif
@@ -822,10 +823,10 @@ template <int J>
 __device__ __forceinline__ void group_begin_fast(const ChanState &c, ChanGroup &g, const uint32_t *s_str)
 {
     const int ic0 = (int)c.y;  // y < 8184 - 16*cs2: no wrap before the group ends
-    const int w = ic0 >> 4;
-    const uint32_t lo = s_str[J * STR_WORDS + w];
-    const uint32_t hi = s_str[J * STR_WORDS + ((w + 1) & (STR_WORDS - 1))];
-    g.W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(ic0 & 15) << 1) ^ GAL_SIGN_MASK((c.st >> 10) & 3u);
+    const uint32_t *wp = s_str + J * STR_PITCH + (ic0 >> 4);
+    const uint32_t lo = wp[0], hi = wp[1];  // (the pad word makes wp[1] valid for the last word; ds_read2_b32)
+    const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
+    g.W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)ic0 << 1) ^ mask;  // v_alignbit uses shift[4:0]
     g.m = -2 * ic0;
 }
 
@@ -836,9 +837,9 @@ __device__ __forceinline__ void group_begin_slow(const ChanState &c, ChanGroup &
     const double ye = pend ? c.y - 8184.0 : c.y;
     const int ic0 = (int)ye;
     const int w = ic0 >> 4;
-    const uint32_t lo = s_str[J * STR_WORDS + w];
-    const uint32_t hi = s_str[J * STR_WORDS + ((w + 1) & (STR_WORDS - 1))];
-    const uint32_t head = s_str[J * STR_WORDS];
+    const uint32_t lo = s_str[J * STR_PITCH + w];
+    const uint32_t hi = s_str[J * STR_PITCH + w + 1];
+    const uint32_t head = s_str[J * STR_PITCH];
     const uint32_t sg_nxt = (c.st >> 12) & 3u;
     const uint32_t sg_cur = pend ? sg_nxt : ((c.st >> 10) & 3u);
     uint32_t W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(ic0 & 15) << 1) ^ GAL_SIGN_MASK(sg_cur);
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                                                      const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
 {
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
-    __shared__ uint32_t s_str[NCH * STR_WORDS];
+    __shared__ uint32_t s_str[NCH * STR_PITCH];
     __shared__ int s_lut[4 * 1024];  // table q = nz | neg<<1, entry k + 512: {0, +LUT, 0, -LUT}[q][k & 511]
     const int *s_lut2 = s_lut + 512;
 
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     for (int j = 0; j < nact; ++j) {
         const int prn = Pd->prn[e * G.S + act[j]];
         const uint32_t *src = Pd->str + (size_t)(prn - 1) * STR_WORDS;
-        for (int i = tid; i < STR_WORDS; i += SYN_BLOCK) s_str[j * STR_WORDS + i] = src[i];
+        for (int i = tid; i < STR_PITCH; i += SYN_BLOCK) s_str[j * STR_PITCH + i] = src[i & (STR_WORDS - 1)];
     }
     __syncthreads();
 
