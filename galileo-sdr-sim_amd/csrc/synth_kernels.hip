@@ -801,7 +801,9 @@ struct ChanState {
     double y;     // TWICE the code phase, i.e. in BOC half chips (pre wrap-check).  Doubling is exact in binary
                   // floating point and commutes with rounding, so y_n == 2*x_n bit for bit when the step is
                   // doubled too; (int)y is then the reference's icode = (int)(code_phase*2) (:512) for free.
-    double p;     // carrier phase, cycles
+    double p;     // carrier phase, cycles, MIRRORED: the reference's carr_phase times the sign of this epoch's
+                  // step, so that it is >= 0 whenever phase and step agree in sign (always, except during the
+                  // first cycle after a Doppler sign change or a restart)
     uint32_t st;  // packed symbol state, see above
 };
 
@@ -860,29 +862,31 @@ __device__ __forceinline__ void group_begin_slow(const ChanState &c, ChanGroup &
 // k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0, -LUT[k & 511].  The two's-complement
 // mask of :509-510, the sign and the zero case of v are all folded into the LDS address.
 __device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
-                                         const int *s_lut2)
+                                         const int sgn4, const int *s_lut2)
 {
     // --- chip lookup, :512-521: icode = (int)(2x); selector bits of that half chip
     const int ic = (int)c.y;
     int off;
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(ic), "v"(g.m));
     const uint32_t q = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);  // v_bfe_u32 uses offset[4:0]
-    // --- carrier LUT, :509-510: trunc toward zero (mask, sign and zero folded into the table choice)
-    int a4 = (int)(511.0 * c.p) << 2;  // byte offset of entry k in table 0
+    // --- carrier LUT, :509-510: trunc toward zero (mask, sign and zero folded into the table choice).  c.p is
+    //     the MIRRORED phase (see ChanState): (int)(511 p) = +-(int)(511 c.p), sgn4 = +-4 bytes per entry
+    const int k = (int)(511.0 * c.p);
+    int a4;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(a4) : "v"(k), "s"(sgn4));
     // (spelled in asm: the combiner otherwise re-associates the shift-add into shifts, masks and an add3)
     asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(q), "v"(a4));
     const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_lut2) + a4);
-    // --- NCO updates, :528-532
+    // --- NCO updates, :528-532 (mirrored: IEEE addition and truncation are sign-symmetric)
     c.y = c.y + cs2;
-    c.p = carr_step(c.p, ds);
+    c.p = carr_step(c.p, __builtin_fabs(ds));
     return t;
 }
 
-// The fast group body's version: no code wrap inside the group, and the carrier phase runs MIRRORED -- c.p holds
-// |p| (p and the step have the same sign throughout the group, checked by the caller), so that
-// `p += d; p -= (long)p` (:531-532) becomes  |p| = fract(|p| + |d|): for 0 <= x < 2, x - floor(x) is the
-// reference's x - trunc(x), IEEE addition is sign-symmetric and the subtraction is exact, hence the same bits
-// with one instruction less.  The table index (int)(511 p) = -(int)(511 |p|) for negative p: sgn4 = +-4.
+// The fast group body's version: no code wrap inside the group, and the mirrored phase is non-negative (phase and
+// step have the same sign, checked by the caller), so that `p += d; p -= (long)p` (:531-532) becomes
+// |p| = fract(|p| + |d|): for 0 <= x < 2, x - floor(x) is the reference's x - trunc(x) and the subtraction is
+// exact, hence the same bits with one instruction less.
 __device__ __forceinline__ int chan_step_fast(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
                                               const int sgn4, const int *s_lut2)
 {
@@ -903,12 +907,12 @@ __device__ __forceinline__ int chan_step_fast(ChanState &c, const ChanGroup &g, 
 // The same with the symbol advance of :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact);
 // the symbol counter is advanced in the group epilogue.
 __device__ __forceinline__ int chan_step_wrap(ChanState &c, ChanGroup &g, const double cs2, const double ds,
-                                              const int *s_lut2)
+                                              const int sgn4, const int *s_lut2)
 {
     const bool ge = c.y >= 8184.0;
     c.y = c.y - (ge ? 8184.0 : 0.0);
     g.m = ge ? g.mw : g.m;
-    return chan_step(c, g, cs2, ds, s_lut2);
+    return chan_step(c, g, cs2, ds, sgn4, s_lut2);
 }
 
 template <int J>
@@ -963,6 +967,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 
     // Per-channel state as individually named scalars (macro-expanded), NOT arrays: hipcc turns small
     // per-thread arrays into wide vector registers and copies whole tuples around every conditional update.
+#define GAL_HI(x) ((uint32_t)(d2u(x) >> 32))
+#define GAL_MIRROR_BITS(p, ds) p = u2d(((uint64_t)(GAL_HI(p) ^ (GAL_HI(ds) & 0x80000000u)) << 32) | (uint32_t)d2u(p));
 #define GAL_DECL(j)                                                                         \
     ChanState ch##j = {0.0, 0.0, 0u};                                                       \
     double cs##j = 0.0, ds##j = 0.0;                                                        \
@@ -970,10 +976,11 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         const int idx = __builtin_amdgcn_readfirstlane(e * G.S + (int)act[j]);              \
         const size_t cp = (size_t)idx * G.CP1 + c;                                          \
         ch##j.y = 2.0 * Pd->cp_x[cp];                                                       \
-        ch##j.p = Pd->cp_p[cp];                                                             \
+        ch##j.p = Pd->cp_p[cp]; /* mirrored below, once ds is known */                      \
         const uint32_t v = Pd->cp_ib[cp]; /* ibit | flipped<<16 */                          \
         cs##j = uniform_f64(2.0 * Pd->cstep[idx]);                                          \
         ds##j = uniform_f64(Pd->dstep[idx]);                                                \
+        GAL_MIRROR_BITS(ch##j.p, ds##j)                                                     \
         ch##j.st = sym_state(Pd, idx, (int)(v & 0xffffu), (int)(v >> 16));                  \
     }
     GAL_CH_LIST(GAL_DECL)
@@ -994,16 +1001,12 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 
 // idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 gives a zero
 // contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
-#define GAL_HI(x) ((uint32_t)(d2u(x) >> 32))
-#define GAL_NEAR(j) if (j < NCH && j < nact) near |= (ch##j.y >= thr) | ((int)(GAL_HI(ch##j.p) ^ GAL_HI(ds##j)) < 0);
-#define GAL_MIRROR(j)                                                                                   \
-    if (j < NCH && j < nact)                                                                            \
-        ch##j.p = u2d(((uint64_t)(GAL_HI(ch##j.p) ^ (GAL_HI(ds##j) & 0x80000000u)) << 32) | (uint32_t)d2u(ch##j.p));
+#define GAL_NEAR(j) if (j < NCH && j < nact) near |= (ch##j.y >= thr) | ((int)GAL_HI(ch##j.p) < 0);
 #define GAL_BEGIN_F(j) if (j < NCH && j < nact) group_begin_fast<j>(ch##j, gr##j, s_str);
 #define GAL_BEGIN_S(j) if (j < NCH && j < nact) group_begin_slow<j>(ch##j, gr##j, s_str);
 #define GAL_SGN4(j) const int sg4##j = 4 + (((int)(d2u(ds##j) >> 32) >> 31) & -8); /* +-4, scalar ALU */
 #define GAL_STEP_F(j) if (j < NCH) acc += chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, s_lut2);
-#define GAL_STEP_S(j) if (j < NCH) acc += chan_step_wrap(ch##j, gr##j, cs##j, ds##j, s_lut2);
+#define GAL_STEP_S(j) if (j < NCH) acc += chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, s_lut2);
 #define GAL_END(j) if (j < NCH && j < nact) group_end<j>(ch##j, gr##j, Pd, act, e);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
 // (all NCO chains first, all accumulates last) and spills hundreds of values
@@ -1022,7 +1025,6 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         GAL_NEAR(a) GAL_NEAR(b) GAL_NEAR(c) GAL_NEAR(d)                          \
         if (__builtin_amdgcn_ballot_w64(near) == 0) {                            \
             GAL_BEGIN_F(a) GAL_BEGIN_F(b) GAL_BEGIN_F(c) GAL_BEGIN_F(d)          \
-            GAL_MIRROR(a) GAL_MIRROR(b) GAL_MIRROR(c) GAL_MIRROR(d)              \
             GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
             _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
             {                                                                    \
@@ -1031,9 +1033,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 if (u & 1) { GAL_PIN(a, b, c, d) } /* 2 steps per scheduling unit: measured best (1: -2 %, 4: spills) */ \
                 o[u] = acc;                                                      \
             }                                                                    \
-            GAL_MIRROR(a) GAL_MIRROR(b) GAL_MIRROR(c) GAL_MIRROR(d)              \
         } else {                                                                 \
             GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)          \
+            GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
             _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
             {                                                                    \
                 int acc = o[u];                                                  \
@@ -1098,8 +1100,6 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_PART
 #undef GAL_PIN
 #undef GAL_NEAR
-#undef GAL_MIRROR
-#undef GAL_HI
 #undef GAL_SGN4
 #undef GAL_BEGIN_F
 #undef GAL_BEGIN_S
@@ -1116,11 +1116,14 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         const size_t cp = (size_t)idx * G.CP1 + c + 1;                                \
         const uint32_t v = Pd->cp_ib[cp];                                             \
         bad += d2u(ch##j.y) != d2u(2.0 * Pd->cp_x[cp]);                               \
-        bad += ch##j.p != Pd->cp_p[cp]; /* numeric: the mirrored form may leave -0.0 for +0.0 */ \
+        { double pm = Pd->cp_p[cp]; GAL_MIRROR_BITS(pm, ds##j)                            \
+          bad += ch##j.p != pm; } /* numeric: the mirrored form may leave -0.0 for +0.0 */ \
         bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
     }
         GAL_CH_LIST(GAL_CHECK)
 #undef GAL_CHECK
+#undef GAL_MIRROR_BITS
+#undef GAL_HI
         // ... and the carrier must enter this epoch exactly where it left the previous one (:531-532)
         if (c == 0 && e > 0) {
 #define GAL_LINK(j)                                                                                  \
