@@ -928,7 +928,9 @@ __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, cons
 #define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define GAL_MAX_NCH 12
 // acc = Q*65536 + I with |I|,|Q| < 32768  ->  little-endian int16 pair I,Q (:536-537)
-#define GAL_PACK(acc) ((((uint32_t)(acc) + 0x8000u) & 0xffff0000u) | ((uint32_t)(acc) & 0xffffu))
+// = (((acc) + 0x8000) & 0xffff0000) | ((acc) & 0xffff): the byte permute takes bytes 3,2 of the rounded sum and
+// bytes 1,0 of acc in one instruction
+#define GAL_PACK(acc) __builtin_amdgcn_perm((uint32_t)(acc) + 0x8000u, (uint32_t)(acc), 0x07060100u)
 #define GAL_UNPACK(w) ((int)((w) & 0xffff0000u) + (int)(short)((w) & 0xffffu))
 
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
