@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, int iters)
         ia[j] = threadIdx.x + j;
     }
     const double c = seed * 1e-3;
+    const double cs = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(uint64_t, c) >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint64_t, c)));
+    const int si = __builtin_amdgcn_readfirstlane(iters | 3);
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int j = 0; j < CHAINS; ++j) {
@@ -36,6 +38,13 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, int iters)
             if (OP == 12) asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(ia[j]) : "v"(a[j]));
             if (OP == 13) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(a[j]) : "v"(i));
             if (OP == 14) asm volatile("v_cmp_le_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a[j]) : "v"(c), "v"(ia[j]), "v"(i) : "vcc");
+            if (OP == 15) asm volatile("v_add_f64 %0, %1, %0" : "+v"(a[j]) : "s"(cs));
+            if (OP == 16) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 17) asm volatile("v_bfe_u32 %0, %0, %1, 2" : "+v"(ia[j]) : "v"(i));
+            if (OP == 18) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(ia[j]) : "s"(si));
+            if (OP == 19) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 20) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 21) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(ia[j]) : "v"(i), "s"(si));
         }
     }
     double s = 0;
@@ -78,7 +87,12 @@ int main()
     r[5] = run<5>(names[5], d); r[6] = run<6>(names[6], d); r[7] = run<7>(names[7], d); r[8] = run<8>(names[8], d);
     r[9] = run<9>(names[9], d); r[10] = run<10>(names[10], d); r[11] = run<11>(names[11], d);
     r[12] = run<12>(names[12], d); r[13] = run<13>(names[13], d); r[14] = run<14>(names[14], d);
+    const double r15 = run<15>("v_add_f64 sgpr", d), r16 = run<16>("v_lshl_add_u32", d), r17 = run<17>("v_bfe_u32", d);
+    const double r18 = run<18>("v_mul_i32_i24 s", d), r19 = run<19>("v_mul_lo_u32", d), r20 = run<20>("v_add3_u32", d);
+    const double r21 = run<21>("v_perm_b32", d);
     printf("\nrelative to v_add_u32 (= 1 issue slot):\n");
+    printf("  v_add_f64 sgpr   %.2f\n  v_lshl_add_u32   %.2f\n  v_bfe_u32        %.2f\n  v_mul_i32_i24 s  %.2f\n  v_mul_lo_u32     %.2f\n  v_add3_u32       %.2f\n  v_perm_b32       %.2f\n",
+           r15 / ref, r16 / ref, r17 / ref, r18 / ref, r19 / ref, r20 / ref, r21 / ref);
     for (int i = 1; i < 15; ++i) printf("  %-16s %.2f\n", names[i], r[i] / ref);
     return 0;
 }
