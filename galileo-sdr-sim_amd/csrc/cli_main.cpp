@@ -54,7 +54,7 @@ void usage(const char *prog)
 struct Slot {  // one pinned host buffer of the double-buffered sink
     int16_t *host = nullptr;
     size_t bytes = 0;
-    hipEvent_t copied = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr};  // the batch leaves the GPU in two halves on two copy streams
     bool full = false;
 };
 
@@ -165,8 +165,16 @@ int main(int argc, char *argv[])
             fprintf(stderr, "ERROR: buffer allocation failed\n");
             exit(1);
         }
-        hipEventCreate(&slot[i].copied);
+        hipEventCreate(&slot[i].copied[0]);
+        hipEventCreate(&slot[i].copied[1]);
     }
+    // device -> host on two streams of their own: two DMA engines share the link, and the copy of batch k runs
+    // beside the front-end and the synthesis of batch k+1
+    hipStream_t copy_stream[2];
+    hipEvent_t computed;
+    hipStreamCreateWithFlags(&copy_stream[0], hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&copy_stream[1], hipStreamNonBlocking);
+    hipEventCreateWithFlags(&computed, hipEventDisableTiming);
 
     // writer thread: drains full slots in order
     std::mutex mu;
@@ -180,7 +188,8 @@ int main(int argc, char *argv[])
             if (!slot[next_write].full) return;
             Slot &s = slot[next_write];
             lk.unlock();
-            hipEventSynchronize(s.copied);
+            hipEventSynchronize(s.copied[0]);
+            hipEventSynchronize(s.copied[1]);
             if (fwrite(s.host, 1, s.bytes, fp) != s.bytes) io_error = true;
             lk.lock();
             s.full = false;
@@ -216,8 +225,20 @@ int main(int argc, char *argv[])
             break;
         }
         slot[cur].bytes = epoch_bytes * n;
-        hipMemcpyAsync(slot[cur].host, d_iq[cur], slot[cur].bytes, hipMemcpyDeviceToHost, stream);
-        hipEventRecord(slot[cur].copied, stream);
+        hipEventRecord(computed, stream);
+        {
+            const size_t half = epoch_bytes * (size_t)((n + 1) / 2);
+            const size_t part[2] = {half, slot[cur].bytes - half};
+            size_t off = 0;
+            for (int k = 0; k < 2; ++k) {
+                hipStreamWaitEvent(copy_stream[k], computed, 0);
+                if (part[k])
+                    hipMemcpyAsync((char *)slot[cur].host + off, (const char *)d_iq[cur] + off, part[k],
+                                   hipMemcpyDeviceToHost, copy_stream[k]);
+                hipEventRecord(slot[cur].copied[k], copy_stream[k]);
+                off += part[k];
+            }
+        }
         if (gal_synth_finish(eng, state.data(), nullptr) != GAL_OK) {
             fprintf(stderr, "\nERROR: %s\n", gal_synth_last_error());
             rc = 1;
