@@ -1,13 +1,14 @@
 // synth_kernels.hip -- gfx950 (CDNA4) kernels of the Galileo E1B/C IQ synthesis engine.
 //
 // Replaces the per-sample loop of the reference, src/galileo-sdr.cpp:481-539.
-// Pipeline per batch of epochs (handle stream + one helper stream, joined by events):
+// Pipeline per batch of epochs (walker chain on two high-priority streams of the handle, k_synth on the
+// caller's stream, joined by events):
 //   k_prep         AoS epoch records -> SoA, NCO steps c = f_code*delt, d = f_carr*delt (one rounding each,
 //                  exactly the product the reference recomputes every sample, :528,:531)
 //   k_walk_code    one lane per (epoch, slot): exact closed-form walk of the code-phase chain, emitting a
 //                  checkpoint (phase, symbol index, page-flip flag) every R samples           [nco_walk.h]
 //   k_pages        which page is in force at each epoch start (pages change only when a symbol counter
-//                  wraps inside the sample loop, :497-506)                [both on the helper stream]
+//                  wraps inside the sample loop, :497-506)                [both on the second walker stream]
 //   k_carr_guess / k_walk_carr / k_carr_scan (+ k_carr_publish), normally 2 passes
 //                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively on LEGS
 //                  (8 per epoch): a leg is walked from its anchor = the last wrap event before it (first
@@ -330,7 +331,7 @@ __global__ void k_walk_carr(DevPlan P, int first)
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
 }
 
-// k_carr_scan: one 256-thread block per slot stitches the legs.  Sequential statement (what the three
+// k_carr_scan: one 1024-thread block per slot stitches the legs.  Sequential statement (what the three
 // block-wide sweeps below compute; walk_host.cpp::galwalk_spec_wrap runs the same statement on the host):
 //     chain state: last claim (lc_w, lc_r), its pending correction D, allok
 //     for each leg i:   root      -> (lc_w, lc_r) = (first sample, given phase), D = 0, allok = true

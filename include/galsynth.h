@@ -121,10 +121,11 @@ size_t gal_synth_output_bytes(const gal_synth_t *h);
 
 /*
  * Run the hot path for the planned batch: NCO walk + per-sample synthesis, writing
- * interleaved int16 I,Q (little endian) to iq_dev (DEVICE memory, 16-byte aligned).  Asynchronous on
- * the handle's stream (plus two internal helper streams joined by events); may be called repeatedly for
- * the same plan.  Several handles may be in flight on different streams: the latency-bound walk of one
- * batch then overlaps the synthesis kernel of another (bench.py --pipeline).
+ * interleaved int16 I,Q (little endian) to iq_dev (DEVICE memory, 16-byte aligned).  Asynchronous: the
+ * walker chain runs on the handle's own high-priority streams (ordered after the work already on the handle's
+ * stream), the synthesis kernel on the handle's stream; may be called repeatedly for the same plan.  Several
+ * handles may be in flight on different streams: the latency-bound walk of one batch then runs beside the
+ * synthesis kernel of another (bench.py --pipeline).
  */
 int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
 
