@@ -176,15 +176,20 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         if (const char *env = getenv("GAL_WALK_PRIORITY")) use = atoi(env);  // 0: everything on one stream
         if (use) {
             int least = 0, greatest = 0;
-            hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (hipStreamCreateWithPriority(&h->walk_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
-                hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming) != hipSuccess)
-                return bail(fail(GAL_E_DEVICE, "priority stream creation failed"));
-            hipStreamDestroy(h->aux_stream);
-            h->aux_stream = nullptr;
-            if (hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, greatest) != hipSuccess)
-                return bail(fail(GAL_E_DEVICE, "priority stream creation failed"));
+            hipStream_t ws = nullptr, as = nullptr;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+                hipStreamCreateWithPriority(&ws, hipStreamNonBlocking, greatest) == hipSuccess &&
+                hipStreamCreateWithPriority(&as, hipStreamNonBlocking, greatest) == hipSuccess &&
+                hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming) == hipSuccess) {
+                h->walk_stream = ws;
+                hipStreamDestroy(h->aux_stream);
+                h->aux_stream = as;
+            } else {  // no stream priorities here: everything stays on the caller's stream (still correct)
+                (void)hipGetLastError();
+                if (ws) hipStreamDestroy(ws);
+                if (as) hipStreamDestroy(as);
+            }
         }
     }
     for (auto &e : h->ev)
