@@ -96,6 +96,7 @@ struct gal_synth {
     DevPlan P{};
     bool planned = false;
     bool executed = false;
+    bool in_flight = false;  // execute() enqueued, finish() not yet called
     int n_groups = 0;  // channel groups (each <= kKernelMaxChan) -> synth launches per execute
     std::vector<int> group_nch;
     uint8_t *d_act = nullptr;  // [groups][E][S]
@@ -271,6 +272,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                    const gal_chan_state_t *state_in)
 {
+    if (h && h->in_flight)
+        return fail(GAL_E_STATE, "gal_synth_plan while a batch is in flight: call gal_synth_finish first");
     if (!h || !params || n_epochs < 1) return fail(GAL_E_INVAL, "gal_synth_plan: bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const int E = n_epochs, S = h->cfg.n_slots, N = h->cfg.samples_per_epoch;
@@ -514,6 +517,8 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
 {
     if (!h || !iq_dev) return fail(GAL_E_INVAL, "gal_synth_execute: null argument");
     if (!h->planned) return fail(GAL_E_STATE, "gal_synth_execute before gal_synth_plan");
+    if (h->in_flight)
+        return fail(GAL_E_STATE, "gal_synth_execute while a batch is in flight: call gal_synth_finish first");
     if (((uintptr_t)iq_dev) & 15) return fail(GAL_E_INVAL, "iq_dev must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
@@ -564,6 +569,7 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
     HIP_TRY(hipMemcpyAsync(h->h_ctr + CTR_COUNT, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
     h->last_iq = (uint32_t *)iq_dev;
     h->executed = true;
+    h->in_flight = true;
     return GAL_OK;
 }
 
@@ -571,6 +577,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
 {
     if (!h) return fail(GAL_E_INVAL, "null handle");
     if (!h->executed) return fail(GAL_E_STATE, "gal_synth_finish before gal_synth_execute");
+    h->in_flight = false;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const DevPlan *P = &h->P;

@@ -293,6 +293,28 @@ def test_batch_without_any_channel(pkg):
     assert np.array_equal(np.concatenate([iq1, iq2]), iq)
 
 
+def test_call_sequence_is_checked(pkg):
+    """plan / execute while a batch is in flight would race with the kernels still reading the plan: GAL_E_STATE."""
+    import torch
+
+    p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=3, n_slots=8, samples_per_epoch=20000, seed=5)
+    with pkg.SynthEngine(samples_per_epoch=20000, n_slots=8, device=0) as eng:
+        with pytest.raises(pkg.GalSynthError):
+            eng.finish()
+        eng.plan(p)
+        out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(out.data_ptr())
+        with pytest.raises(pkg.GalSynthError):
+            eng.execute(out.data_ptr())
+        with pytest.raises(pkg.GalSynthError):
+            eng.plan(p)
+        st, stats = eng.finish()
+        eng.execute(out.data_ptr())  # the same plan again
+        eng.finish()
+        ref_iq, _ = oracle_run(p, 20000, 2.6e6)
+        assert np.array_equal(out.cpu().numpy(), ref_iq)
+
+
 def test_single_stream_mode(pkg, monkeypatch):
     """GAL_WALK_PRIORITY=0: walkers and synthesis on the caller's stream (no internal high-priority stream)."""
     monkeypatch.setenv("GAL_WALK_PRIORITY", "0")
