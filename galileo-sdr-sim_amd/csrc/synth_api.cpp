@@ -23,7 +23,7 @@ void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_state_phase(const DevPlan *P, hipStream_t st);
 int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
-                      const int *nact, uint32_t *iq, hipStream_t st);
+                      const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st);
 }
 
 namespace {
@@ -103,6 +103,7 @@ struct gal_synth {
     int *d_nact = nullptr;     // [groups][E]
     int nact_max = 0;
     uint32_t *last_iq = nullptr;
+    int range_e0 = 0, range_ne = 0;  // epoch range of the last execute
     void *own_iq = nullptr;
     size_t own_iq_bytes = 0;
     int *h_ctr = nullptr;  // pinned
@@ -501,12 +502,12 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq)
 {
     const size_t ES = (size_t)h->P.E * h->P.S;
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
-        HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->P.E * (size_t)h->P.N * 4u, h->stream));
+        HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
         return GAL_OK;
     }
     for (int g = 0; g < h->n_groups; ++g) {
         const int rc = galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, h->d_act + (size_t)g * ES,
-                                         h->d_nact + (size_t)g * h->P.E, iq, h->stream);
+                                         h->d_nact + (size_t)g * h->P.E, iq, h->range_e0, h->range_ne, h->stream);
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
     }
     HIP_TRY(hipGetLastError());
@@ -515,8 +516,20 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq)
 
 int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
 {
+    if (!h) return fail(GAL_E_INVAL, "gal_synth_execute: null argument");
+    if (!h->planned) return fail(GAL_E_STATE, "gal_synth_execute before gal_synth_plan");
+    return gal_synth_execute_range(h, iq_dev, 0, h->P.E);
+}
+
+int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch, int32_t n_epochs)
+{
     if (!h || !iq_dev) return fail(GAL_E_INVAL, "gal_synth_execute: null argument");
     if (!h->planned) return fail(GAL_E_STATE, "gal_synth_execute before gal_synth_plan");
+    if (first_epoch < 0 || n_epochs < 1 || first_epoch + n_epochs > h->P.E)
+        return fail(GAL_E_INVAL, "gal_synth_execute_range: epochs [%d, %d) outside the planned batch of %d", first_epoch,
+                    first_epoch + n_epochs, h->P.E);
+    h->range_e0 = first_epoch;
+    h->range_ne = n_epochs;
     if (h->in_flight)
         return fail(GAL_E_STATE, "gal_synth_execute while a batch is in flight: call gal_synth_finish first");
     if (((uintptr_t)iq_dev) & 15) return fail(GAL_E_INVAL, "iq_dev must be 16-byte aligned");

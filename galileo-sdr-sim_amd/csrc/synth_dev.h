@@ -75,6 +75,7 @@ struct DevPlan {
 // that rarely used pointers do not occupy SGPRs inside the sample loop)
 struct SynGeom {
     int S, N, R, nchunks, CP1, blocks_per_epoch;
+    int e0;  // first epoch of the executed range (the output buffer starts there)
 };
 
 #endif

@@ -945,8 +945,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     __shared__ int s_lut[4 * 1024];  // table q = nz | neg<<1, entry k + 512: {0, +LUT, 0, -LUT}[q][k & 511]
     const int *s_lut2 = s_lut + 512;
 
-    const int e = blockIdx.x / G.blocks_per_epoch;
-    const int tg = blockIdx.x - e * G.blocks_per_epoch;
+    const int er = blockIdx.x / G.blocks_per_epoch;  // epoch relative to the executed range
+    const int tg = blockIdx.x - er * G.blocks_per_epoch;
+    const int e = G.e0 + er;
     const int tid = threadIdx.x;
     const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
     const uint8_t *act = act_all + (size_t)e * G.S;
@@ -996,11 +997,11 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_CSMAX
     const double thr = uniform_f64(8184.0 - 16.0 * csmax);
 
-    uint32_t *out = iq + (size_t)e * G.N + n0;
+    uint32_t *out = iq + (size_t)er * G.N + n0;  // iq holds the executed range only
     // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
     // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
     // bursts at 1.2x: tools/wrcal.hip).
-    const bool vec_ok = ((((size_t)e * G.N + n0) & 15) == 0);
+    const bool vec_ok = ((((size_t)er * G.N + n0) & 15) == 0);
 
 // idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 gives a zero
 // contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
@@ -1188,10 +1189,11 @@ extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
 
 template <bool ACC>
 static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact,
-                          uint32_t *iq, hipStream_t st)
+                          uint32_t *iq, int e0, int ne, hipStream_t st)
 {
-    const dim3 grid(P->E * P->blocks_per_epoch), block(SYN_BLOCK);
+    const dim3 grid(ne * P->blocks_per_epoch), block(SYN_BLOCK);
     SynGeom G;
+    G.e0 = e0;
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1; G.blocks_per_epoch = P->blocks_per_epoch;
     switch (nch) {
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq); break;
@@ -1204,8 +1206,8 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
 }
 
 extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
-                                 const int *nact, uint32_t *iq, hipStream_t st)
+                                 const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st)
 {
-    return accumulate ? launch_synth_t<true>(P, Pd, nch, act, nact, iq, st)
-                      : launch_synth_t<false>(P, Pd, nch, act, nact, iq, st);
+    return accumulate ? launch_synth_t<true>(P, Pd, nch, act, nact, iq, e0, ne, st)
+                      : launch_synth_t<false>(P, Pd, nch, act, nact, iq, e0, ne, st);
 }

@@ -18,6 +18,15 @@ def rank_workload(rank, n_epochs, n_chan=12, n_slots=16, samples_per_epoch=26000
                                     seed=workloads.SEED + rank, dyn_track=dyn_track)
 
 
+def epoch_range(rank, world, n_epochs):
+    """Contiguous epoch range [first, first + count) of ONE scenario for rank `rank` (strong scaling, SURVEY.md
+    §8e-ii): every rank plans the whole scenario -- the NCO walk over all epochs is what gives it the exact
+    carrier state at its first epoch -- and synthesises only its own range (gal_synth_execute_range)."""
+    base, extra = divmod(n_epochs, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
 def reduce_report(dist, device, elapsed_s, n_samples, checksum):
     """MAX of the elapsed time, SUM of samples, XOR-free SUM of 32-bit checksums over ranks."""
     import torch

@@ -85,6 +85,7 @@ EXPORTED_SYMBOLS = (
     "gal_synth_output_bytes",
     "gal_synth_walk_counts",
     "gal_synth_execute",
+    "gal_synth_execute_range",
     "gal_synth_finish",
     "gal_synth_run_host",
     "gal_tables_e1b",
@@ -122,6 +123,8 @@ def load_library():
     lib.gal_synth_output_bytes.argtypes = [vp]
     lib.gal_synth_output_bytes.restype = ctypes.c_size_t
     lib.gal_synth_execute.argtypes = [vp, vp]
+    lib.gal_synth_execute_range.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32]
+    lib.gal_synth_execute_range.restype = ctypes.c_int
     lib.gal_synth_finish.argtypes = [vp, vp, ctypes.POINTER(_Stats)]
     lib.gal_synth_run_host.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.POINTER(_Stats)]
     for name in ("gal_tables_e1b", "gal_tables_e1c", "gal_tables_cos512", "gal_tables_sin512"):
@@ -239,9 +242,14 @@ class SynthEngine:
         self._check(self._lib.gal_synth_walk_counts(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
-    def execute(self, iq_dev_ptr):
-        """iq_dev_ptr: integer device address (e.g. torch tensor .data_ptr()), 16-byte aligned."""
-        self._check(self._lib.gal_synth_execute(self._h, ctypes.c_void_p(int(iq_dev_ptr))))
+    def execute(self, iq_dev_ptr, first_epoch=0, n_epochs=None):
+        """iq_dev_ptr: integer device address (e.g. torch tensor .data_ptr()), 16-byte aligned.  With
+        first_epoch / n_epochs only that epoch range of the plan is synthesised (into a buffer of that size)."""
+        if first_epoch == 0 and n_epochs is None:
+            self._check(self._lib.gal_synth_execute(self._h, ctypes.c_void_p(int(iq_dev_ptr))))
+        else:
+            n = self.n_epochs - first_epoch if n_epochs is None else n_epochs
+            self._check(self._lib.gal_synth_execute_range(self._h, ctypes.c_void_p(int(iq_dev_ptr)), int(first_epoch), int(n)))
 
     def finish(self):
         st = np.zeros(self.n_slots, dtype=CHAN_STATE_DTYPE)

@@ -129,6 +129,16 @@ size_t gal_synth_output_bytes(const gal_synth_t *h);
  */
 int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
 
+/*
+ * The same for the epochs [first_epoch, first_epoch + n_epochs) of the planned batch only: iq_dev receives
+ * n_epochs * samples_per_epoch * 4 bytes.  The NCO walk always covers the whole plan (it is what yields the
+ * exact carrier state at first_epoch: 0.5 ms per 1199 epochs x 12 SVs), the synthesis only the range -- this is
+ * how ONE scenario is cut into contiguous epoch ranges for several GPUs without any exchange (bench.py --shard
+ * scenario): every rank plans the whole scenario and executes its own range.  gal_synth_finish returns the state
+ * at the end of the PLAN, not of the range.
+ */
+int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch, int32_t n_epochs);
+
 /* Wait for the stream, check the chain self-check, return the end-of-batch channel state (host,
  * n_slots entries, may be NULL) and statistics (may be NULL). */
 int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats);

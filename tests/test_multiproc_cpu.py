@@ -55,3 +55,60 @@ def test_two_rank_weak_scaling_split(pkg):
     a = pkg.shard.rank_workload(0, 2, 3, 4, 2600)
     b = pkg.shard.rank_workload(1, 2, 3, 4, 2600)
     assert a.shape == b.shape and a.tobytes() != b.tobytes()
+
+
+def _worker_strong(rank, world, port, q):
+    """One scenario cut into epoch ranges: each rank evaluates its range with the carrier state the chain has at
+    its first epoch (on the GPU the engine's own walker provides it; here the oracle is run over the preceding
+    epochs and its end state handed over, which is the same statement)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from __graft_entry__ import load_pkg
+    from oracle_binding import oracle_run
+
+    pkg = load_pkg()
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    params = pkg.shard.rank_workload(0, n_epochs=7, n_chan=3, n_slots=4, samples_per_epoch=2600)  # the SAME scenario
+    e0, ne = pkg.shard.epoch_range(rank, world, 7)
+    state = None
+    if e0 > 0:
+        _, state = oracle_run(params[:e0], 2600, 2.6e6)
+    mine = params[e0:e0 + ne].copy()
+    if e0 > 0:
+        mine["flags"][0, :] = 0  # continues from the carried state
+    iq, _ = oracle_run(mine, 2600, 2.6e6, state)
+    chk = int(iq.astype(np.int64).sum()) & 0xFFFFFFFF
+    dist.barrier()
+    el, total, chk_all = pkg.shard.reduce_report(dist, "cpu", 1.0, iq.size // 2, chk)
+    q.put((rank, e0, ne, total, chk_all))
+    dist.destroy_process_group()
+
+
+def test_two_rank_strong_scaling_split(pkg):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import oracle_run
+
+    for world, n in [(1, 7), (2, 7), (3, 7), (4, 10), (8, 1199)]:
+        r = [pkg.shard.epoch_range(k, world, n) for k in range(world)]
+        assert r[0][0] == 0 and sum(c for _, c in r) == n and all(r[k][0] + r[k][1] == r[k + 1][0] for k in range(world - 1))
+        assert max(c for _, c in r) - min(c for _, c in r) <= 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_strong, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 4, 4, 3)
+    full, _ = oracle_run(pkg.shard.rank_workload(0, 7, 3, 4, 2600), 2600, 2.6e6)
+    assert res[0][3] == res[1][3] == 7 * 2600
+    assert res[0][4] == res[1][4] == int(full.astype(np.int64).sum()) & 0xFFFFFFFF

@@ -293,6 +293,31 @@ def test_batch_without_any_channel(pkg):
     assert np.array_equal(np.concatenate([iq1, iq2]), iq)
 
 
+def test_epoch_ranges_of_one_plan(pkg):
+    """gal_synth_execute_range: one scenario cut into contiguous epoch ranges (how it shards over GPUs, bench.py
+    --shard scenario): each range synthesised on its own equals the corresponding slice of the full output; the
+    walker always covers the whole plan, so a range that starts mid-run gets the exact carrier state."""
+    import torch
+
+    n = 52000
+    p = pkg.workloads.make_synthetic(n_epochs=11, n_chan=14, n_slots=16, samples_per_epoch=n, seed=4321)  # 2 groups
+    ref_iq, _ = oracle_run(p, n, 2.6e6)
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
+        eng.plan(p)
+        for world in (1, 2, 3, 4):
+            parts = []
+            for r in range(world):
+                e0, ne = pkg.shard.epoch_range(r, world, p.shape[0])
+                out = torch.empty(ne * n * 2, dtype=torch.int16, device="cuda")
+                eng.execute(out.data_ptr(), e0, ne)
+                st, stats = eng.finish()
+                assert stats["chain_mismatch"] == 0
+                parts.append(out.cpu().numpy())
+            assert np.array_equal(np.concatenate(parts), ref_iq), world
+        with pytest.raises(pkg.GalSynthError):
+            eng.execute(out.data_ptr(), 10, 2)
+
+
 def test_call_sequence_is_checked(pkg):
     """plan / execute while a batch is in flight would race with the kernels still reading the plan: GAL_E_STATE."""
     import torch
