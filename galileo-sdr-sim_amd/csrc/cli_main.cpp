@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <getopt.h>
 #include <signal.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -171,15 +172,14 @@ int main(int argc, char *argv[])
     // device -> host on two streams of their own: two DMA engines share the link, and the copy of batch k runs
     // beside the front-end and the synthesis of batch k+1
     hipStream_t copy_stream[2];
-    hipEvent_t computed;
     hipStreamCreateWithFlags(&copy_stream[0], hipStreamNonBlocking);
     hipStreamCreateWithFlags(&copy_stream[1], hipStreamNonBlocking);
-    hipEventCreateWithFlags(&computed, hipEventDisableTiming);
 
     // writer thread: drains full slots in order
     std::mutex mu;
     std::condition_variable cv;
-    bool done = false, io_error = false;
+    bool done = false;
+    std::atomic<bool> io_error{false};  // written by the writer thread, read by the producer loop
     int next_write = 0;
     std::thread writer([&]() {
         for (;;) {
@@ -224,25 +224,26 @@ int main(int argc, char *argv[])
             rc = 1;
             break;
         }
+        // The IQ in d_iq[cur] is final only once gal_synth_finish() has returned: finish() may find the speculative
+        // carrier chain unverified (or the replay check unhappy) and synthesise the batch again.  The copies are
+        // therefore enqueued after it; they still run beside the front-end and the synthesis of the next batch.
+        if (gal_synth_finish(eng, state.data(), nullptr) != GAL_OK) {
+            fprintf(stderr, "\nERROR: %s\n", gal_synth_last_error());
+            rc = 1;
+            break;
+        }
         slot[cur].bytes = epoch_bytes * n;
-        hipEventRecord(computed, stream);
         {
             const size_t half = epoch_bytes * (size_t)((n + 1) / 2);
             const size_t part[2] = {half, slot[cur].bytes - half};
             size_t off = 0;
             for (int k = 0; k < 2; ++k) {
-                hipStreamWaitEvent(copy_stream[k], computed, 0);
                 if (part[k])
                     hipMemcpyAsync((char *)slot[cur].host + off, (const char *)d_iq[cur] + off, part[k],
                                    hipMemcpyDeviceToHost, copy_stream[k]);
                 hipEventRecord(slot[cur].copied[k], copy_stream[k]);
                 off += part[k];
             }
-        }
-        if (gal_synth_finish(eng, state.data(), nullptr) != GAL_OK) {
-            fprintf(stderr, "\nERROR: %s\n", gal_synth_last_error());
-            rc = 1;
-            break;
         }
         have_state = true;
         {
@@ -252,7 +253,7 @@ int main(int argc, char *argv[])
         cv.notify_all();
         cur ^= 1;
         emitted += n;
-        if (verbose || true) {
+        if (verbose || isatty(fileno(stderr))) {
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             fprintf(stderr, "\rTime into run = %4.1f - %4.1f", emitted / 10.0, el);
         }

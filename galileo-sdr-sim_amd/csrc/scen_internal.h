@@ -93,6 +93,8 @@ int sat_visible(const Ephemeris &eph, const GalTime &g, const double xyz[3], dou
 void compute_range(Range *rho, const Ephemeris &eph, const IonoUtc &iono, const GalTime &g, const double xyz[3]);
 
 // inav.cpp
+void inav_page_bits(const GalTime &g, const Ephemeris &eph, const IonoUtc &iono, int even_half[120], int odd_half[120]);
+unsigned int inav_crc24q(const int *bits, int len);
 void inav_page_symbols(const GalTime &g, const Ephemeris &eph, const IonoUtc &iono, int symbols[kSymPerPage]);
 void pack_symbols(const int symbols[kSymPerPage], uint32_t words[GAL_PAGE_WORDS]);
 

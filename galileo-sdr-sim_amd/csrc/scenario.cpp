@@ -333,6 +333,50 @@ int gal_scen_inav_page(gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t w
     return GAL_OK;
 }
 
+int gal_scen_inav_raw(gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t week, double sec, uint8_t bits[240])
+{
+    if (!s || !bits || svid < 1 || svid > kMaxSat) return scen_fail(GAL_E_INVAL, "gal_scen_inav_raw: bad argument");
+    const std::vector<Ephemeris> &list = s->nav.sv[svid - 1];
+    if (eph_index < 0 || eph_index >= (int)list.size()) return scen_fail(GAL_E_INVAL, "no such ephemeris record");
+    GalTime g;
+    g.week = week;
+    g.sec = sec;
+    int even_half[120], odd_half[120];
+    inav_page_bits(g, list[eph_index], s->nav.iono, even_half, odd_half);
+    for (int i = 0; i < 120; ++i) {
+        bits[i] = (uint8_t)even_half[i];
+        bits[120 + i] = (uint8_t)odd_half[i];
+    }
+    return GAL_OK;
+}
+
+uint32_t gal_scen_crc24q(const uint8_t *bits, int32_t len)
+{
+    if (!bits || len < 1 || len > 4096) return 0;
+    std::vector<int> b(bits, bits + len);
+    return inav_crc24q(b.data(), len);
+}
+
+int32_t gal_scen_eph_count(const gal_scen_t *s, int32_t svid)
+{
+    if (!s || svid < 1 || svid > kMaxSat) return 0;
+    return (int32_t)s->nav.sv[svid - 1].size();
+}
+
+int gal_scen_eph_info(const gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t *iodnav, int32_t *toe_week,
+                      double *toe_sec, double *toc_sec)
+{
+    if (!s || svid < 1 || svid > kMaxSat) return scen_fail(GAL_E_INVAL, "gal_scen_eph_info: bad argument");
+    const std::vector<Ephemeris> &list = s->nav.sv[svid - 1];
+    if (eph_index < 0 || eph_index >= (int)list.size()) return scen_fail(GAL_E_INVAL, "no such ephemeris record");
+    const Ephemeris &e = list[eph_index];
+    if (iodnav) *iodnav = e.iodnav;
+    if (toe_week) *toe_week = e.toe.week;
+    if (toe_sec) *toe_sec = e.toe.sec;
+    if (toc_sec) *toc_sec = e.toc.sec;
+    return GAL_OK;
+}
+
 int gal_scen_close(gal_scen_t *s)
 {
     delete s;

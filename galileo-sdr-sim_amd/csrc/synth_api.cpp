@@ -114,7 +114,13 @@ struct gal_synth {
 
 extern "C" {
 
-const char *gal_synth_version(void) { return "galsynth 0.1 (gfx950, HIP)"; }
+#ifdef GAL_TEST_HOOKS
+// libgalsynth_hooks.so: the same sources with the fault-injection hooks of the repair-path tests compiled in
+// (GAL_WALK_LEGS / GAL_WALK_TRANSLATE / GAL_WALK_PASSES environment variables).  Never shipped, never benchmarked.
+const char *gal_synth_version(void) { return "galsynth 0.2 (gfx950, HIP) +testhooks"; }
+#else
+const char *gal_synth_version(void) { return "galsynth 0.2 (gfx950, HIP)"; }
+#endif
 const char *gal_synth_last_error(void) { return g_err; }
 
 int gal_synth_device_count(void)
@@ -174,9 +180,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
     {
-        int use = 1;
-        if (const char *env = getenv("GAL_WALK_PRIORITY")) use = atoi(env);  // 0: everything on one stream
-        if (use) {
+        if (!(cfg->flags & GAL_CFG_SINGLE_STREAM)) {
             int least = 0, greatest = 0;
             hipStream_t ws = nullptr, as = nullptr;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
@@ -365,7 +369,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const int tiles = (nchunks + 63) / 64;
     // carrier-walk legs: ~8 per epoch so that (legs x channels) fills the chip
     int legs = 8;
+#ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_LEGS")) legs = atoi(env) > 0 ? atoi(env) : legs;
+#endif
     int Lc = (nchunks + legs - 1) / legs;
     if (Lc < 1) Lc = 1;
     const int W = (nchunks + Lc - 1) / Lc;
@@ -452,8 +458,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
     P.translate = 1;
-    // test hook: 0 = never translate, 2 = translate with one deliberately wrong shift (exercises the fallback)
+    P.tr_e0 = 0;
+    P.tr_e1 = E;
+#ifdef GAL_TEST_HOOKS
+    // 0 = never translate, 2 = translate with one deliberately wrong shift (exercises the fallback)
     if (const char *env = getenv("GAL_WALK_TRANSLATE")) P.translate = atoi(env);
+#endif
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
 
@@ -528,12 +538,20 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     if (first_epoch < 0 || n_epochs < 1 || first_epoch + n_epochs > h->P.E)
         return fail(GAL_E_INVAL, "gal_synth_execute_range: epochs [%d, %d) outside the planned batch of %d", first_epoch,
                     first_epoch + n_epochs, h->P.E);
-    h->range_e0 = first_epoch;
-    h->range_ne = n_epochs;
     if (h->in_flight)
         return fail(GAL_E_STATE, "gal_synth_execute while a batch is in flight: call gal_synth_finish first");
     if (((uintptr_t)iq_dev) & 15) return fail(GAL_E_INVAL, "iq_dev must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
+    // (the range is recorded only once every check has passed: finish()'s repair paths re-synthesise it)
+    h->range_e0 = first_epoch;
+    h->range_ne = n_epochs;
+    // TRANSLATED carrier legs are covered by k_synth's replay check, which works by induction from the chain root
+    // and therefore only vouches for epochs it actually replays.  Outside the executed range a leg is accepted
+    // through a genuine walk + bitwise stitch only (k_carr_scan: tr_e0 / tr_e1), so the carrier state a range
+    // starts from, and the end-of-plan state finish() returns, never rest on an unchecked translation.
+    // (the walker kernels take the plan by value; k_synth's device copy does not use these two fields)
+    h->P.tr_e0 = first_epoch;
+    h->P.tr_e1 = first_epoch + n_epochs;
     hipStream_t st = h->stream;
     const DevPlan *P = &h->P;
     // ws: the walker chain (the handle's high-priority stream, ordered after the caller's stream by an event)
@@ -554,7 +572,9 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     // runs beside the issue-bound synthesis of another).  gal_synth_finish() looks at the counter; in the rare
     // case that the chain was not verified by then it iterates further and repeats the synthesis.
     int n_passes = kDefaultPasses;
-    if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;  // test hook
+#ifdef GAL_TEST_HOOKS
+    if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;
+#endif
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, ws);
         galk_launch_carr_scan(P, ws);

@@ -57,7 +57,8 @@ struct DevPlan {
     int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
     long long *tpos;     // global sample index right after that tie step
     double *shift;       // pending translation (new anchor residual - walked anchor residual)
-    int translate;       // 1 normal; 0: always re-walk (fallback / tests); 2: test hook, see k_walk_carr
+    int translate;       // 1 normal; 0: always re-walk (the all-walked fallback); 2: GAL_TEST_HOOKS builds only
+    int tr_e0, tr_e1;    // legs of epochs outside [tr_e0, tr_e1) are never translated (gal_synth_execute_range)
 
     // checkpoints, one per chunk + end state
     double *cp_x;     // [E][S][CP1]

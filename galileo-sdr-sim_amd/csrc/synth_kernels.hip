@@ -33,6 +33,10 @@
 
 using namespace galnco;
 
+#ifdef GAL_TEST_HOOKS
+#define GAL_HOOK_BAD_LEG 5  // (slot 0, epoch 0, leg 5) receives a wrong translation when P.translate == 2
+#endif
+
 // ------------------------------------------------------------------------------------------------
 __global__ void k_prep(DevPlan P)
 {
@@ -251,7 +255,9 @@ __global__ void k_walk_carr(DevPlan P, int first)
             // binades step by step, so every state it produces is the old one plus the shift, bit for bit
             // (nco_walk.h: binade_margin; ties: WalkOut::tdir).  k_synth's replay check covers it.
             double dl = P.shift[li];
-            if (P.translate == 2 && li == 5) dl += 4.440892098500626e-16;  // TEST HOOK: a deliberately wrong shift
+#ifdef GAL_TEST_HOOKS
+            if (P.translate == 2 && li == GAL_HOOK_BAD_LEG) dl += 4.440892098500626e-16;  // a deliberately wrong shift
+#endif
             // an odd shift flips the first tie of the walk: from that wrap on the trajectory is off by dl2
             const int td = P.tdir[li];
             const bool flip = td != 0 && (d_residue_u52(dl) & 1);
@@ -635,7 +641,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
                     // same wrap event, only its residual moved: translate the leg instead of walking it again
                     // when the move is provably itinerary-preserving (k_walk_carr, dirty == 2)
                     const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
-                    const bool tr = P.translate && L.aw == o.nw &&
+                    const int el = i / P.W;
+                    const bool tr = P.translate && el >= P.tr_e0 && el < P.tr_e1 && L.aw == o.nw &&
                                     __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
                     P.anc_w[li] = o.nw;
                     P.anc_r[li] = nr;

@@ -19,6 +19,10 @@ EXPORTED_SYMBOLS = (
     "gal_scen_next",
     "gal_scen_close",
     "gal_scen_inav_page",
+    "gal_scen_inav_raw",
+    "gal_scen_crc24q",
+    "gal_scen_eph_count",
+    "gal_scen_eph_info",
 )
 
 
@@ -61,8 +65,21 @@ def load_library():
         lib.gal_scen_next.argtypes = [vp, ctypes.c_int32, vp]
         lib.gal_scen_close.argtypes = [vp]
         lib.gal_scen_inav_page.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, vp]
+        lib.gal_scen_inav_raw.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, vp]
+        lib.gal_scen_crc24q.argtypes = [vp, ctypes.c_int32]
+        lib.gal_scen_crc24q.restype = ctypes.c_uint32
+        lib.gal_scen_eph_count.argtypes = [vp, ctypes.c_int32]
+        lib.gal_scen_eph_info.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_double)]
         _lib = lib
     return _lib
+
+
+def crc24q(bits):
+    """CRC-24Q of a bit sequence as the page generator computes it (src/inav-msg.cpp:141-167)."""
+    b = np.ascontiguousarray(bits, dtype=np.uint8)
+    return int(load_library().gal_scen_crc24q(b.ctypes.data, int(b.size)))
 
 
 def parse_time(text):
@@ -121,6 +138,25 @@ class Scenario:
         if rc != 0:
             raise GalScenError(rc, self._lib.gal_scen_last_error().decode())
         return w
+
+    def inav_raw(self, svid, eph_index, week, sec):
+        """240 page bits before channel coding: even half (114 + 6 tail) then odd half (114 + 6 tail)."""
+        b = np.zeros(240, dtype=np.uint8)
+        rc = self._lib.gal_scen_inav_raw(self._h, int(svid), int(eph_index), int(week), float(sec), b.ctypes.data)
+        if rc != 0:
+            raise GalScenError(rc, self._lib.gal_scen_last_error().decode())
+        return b
+
+    def ephemerides(self, svid):
+        """[(iodnav, toe_week, toe_sec, toc_sec)] of `svid` in file order."""
+        out = []
+        for k in range(int(self._lib.gal_scen_eph_count(self._h, int(svid)))):
+            iod, wk = ctypes.c_int32(), ctypes.c_int32()
+            toe, toc = ctypes.c_double(), ctypes.c_double()
+            self._lib.gal_scen_eph_info(self._h, int(svid), k, ctypes.byref(iod), ctypes.byref(wk), ctypes.byref(toe),
+                                        ctypes.byref(toc))
+            out.append((iod.value, wk.value, toe.value, toc.value))
+        return out
 
     def close(self):
         if self._h:

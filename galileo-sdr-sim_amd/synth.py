@@ -12,6 +12,9 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libgalsynth.so")
+# the same sources built with -DGAL_TEST_HOOKS (fault injection for the repair-path tests; tests only)
+HOOKS_LIB_PATH = os.path.join(PKG_DIR, "libgalsynth_hooks.so")
+GAL_CFG_SINGLE_STREAM = 1
 
 GAL_CH_RESTART = 1
 GAL_PAGE_WORDS = 16
@@ -50,7 +53,8 @@ class _Cfg(ctypes.Structure):
         ("device", ctypes.c_int32),
         ("chunk_samples", ctypes.c_int32),
         ("max_walk_passes", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 3),
+        ("flags", ctypes.c_uint32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -95,20 +99,21 @@ EXPORTED_SYMBOLS = (
     "gal_tables_cs25",
 )
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """dlopen libgalsynth.so (built in-tree by build.py).  Raises if it is not there: no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(hooks=False):
+    """dlopen libgalsynth.so (built in-tree by build.py).  Raises if it is not there: no fallback.
+    hooks=True loads the GAL_TEST_HOOKS build instead (tests of the repair paths only)."""
+    if hooks in _libs:
+        return _libs[hooks]
+    path = HOOKS_LIB_PATH if hooks else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
             "%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
-            "The synthesis engine has no CPU fallback." % LIB_PATH
+            "The synthesis engine has no CPU fallback." % path
         )
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     lib.gal_synth_version.restype = ctypes.c_char_p
     lib.gal_synth_last_error.restype = ctypes.c_char_p
@@ -130,7 +135,7 @@ def load_library():
     for name in ("gal_tables_e1b", "gal_tables_e1c", "gal_tables_cos512", "gal_tables_sin512"):
         getattr(lib, name).restype = vp
     lib.gal_tables_cs25.restype = ctypes.c_uint32
-    _lib = lib
+    _libs[hooks] = lib
     return lib
 
 
@@ -173,11 +178,11 @@ class SynthEngine:
     """One handle per GPU / stream (gal_synth_t).  Thread-compatible, not thread-safe."""
 
     def __init__(self, sample_rate=2.6e6, samples_per_epoch=260000, n_slots=16, device=-1, chunk_samples=0,
-                 max_walk_passes=0):
-        self._lib = load_library()
+                 max_walk_passes=0, flags=0, test_hooks=False):
+        self._lib = load_library(hooks=test_hooks)
         self._h = ctypes.c_void_p()
         cfg = _Cfg(float(sample_rate), int(samples_per_epoch), int(n_slots), int(device), int(chunk_samples),
-                   int(max_walk_passes))
+                   int(max_walk_passes), int(flags))
         self._check(self._lib.gal_synth_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         self.sample_rate = float(sample_rate)
         self.samples_per_epoch = int(samples_per_epoch)

@@ -54,6 +54,18 @@ int gal_scen_close(gal_scen_t *s);
 int gal_scen_inav_page(gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t week, double sec,
                        uint32_t page_words[GAL_PAGE_WORDS]);
 
+
+/* The same page BEFORE channel coding (src/inav-msg.cpp:42-44 hands these two halves to generateFrame): bits[0..119]
+ * = even half (114 bits + 6 tail zeros), bits[120..239] = odd half, one bit per byte.  This is the layout of the
+ * recorded broadcast pages the reference holds under tv/<date>/<svid>.csv (tests/test_inav_kat.py). */
+int gal_scen_inav_raw(gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t week, double sec, uint8_t bits[240]);
+/* CRC-24Q as the page generator computes it (src/inav-msg.cpp:141-167) over `len` bits, one bit per byte. */
+uint32_t gal_scen_crc24q(const uint8_t *bits, int32_t len);
+/* Ephemeris records of `svid` in the opened file, in file order (the order epoch_matcher, src/rinex.cpp:4-44, walks). */
+int32_t gal_scen_eph_count(const gal_scen_t *s, int32_t svid);
+int gal_scen_eph_info(const gal_scen_t *s, int32_t svid, int32_t eph_index, int32_t *iodnav, int32_t *toe_week,
+                      double *toe_sec, double *toc_sec);
+
 #ifdef __cplusplus
 }
 #endif

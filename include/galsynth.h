@@ -77,9 +77,15 @@ typedef struct gal_synth_cfg {
     int32_t n_slots;            /* channel slots per epoch record row; reference MAX_CHAN = 16                 */
     int32_t device;             /* HIP device ordinal; -1 = current device                                     */
     int32_t chunk_samples;      /* 0 = auto (~1024); samples replayed by one lane (multiple of 4)              */
-    int32_t max_walk_passes;    /* 0 = default (32); cap on speculative carrier-walk passes before GAL_E_CHAIN */
-    int32_t reserved[3];
+    int32_t max_walk_passes;    /* 0 = default (64 + carrier legs in the plan); cap on speculative carrier-walk
+                                   passes before gal_synth_finish gives up with GAL_E_CHAIN                    */
+    uint32_t flags;             /* GAL_CFG_*                                                                   */
+    int32_t reserved[2];
 } gal_synth_cfg_t;
+
+/* gal_synth_cfg_t.flags */
+#define GAL_CFG_SINGLE_STREAM 1u /* enqueue every kernel on the handle's stream (no internal high-priority walker
+                                    streams): for callers that capture or serialise the stream themselves       */
 
 typedef struct gal_synth_stats {
     int32_t walk_passes;        /* carrier-walker passes the last execute needed                               */
@@ -140,7 +146,10 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
 int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch, int32_t n_epochs);
 
 /* Wait for the stream, check the chain self-check, return the end-of-batch channel state (host,
- * n_slots entries, may be NULL) and statistics (may be NULL). */
+ * n_slots entries, may be NULL) and statistics (may be NULL).  The IQ in iq_dev is FINAL ONLY AFTER THIS CALL HAS
+ * RETURNED GAL_OK: the carrier chain is evaluated speculatively, and if the speculation was not verified in time
+ * (or the replay check disagreed) finish() repeats the synthesis into iq_dev.  Do not enqueue copies out of
+ * iq_dev between execute() and finish(). */
 int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats);
 
 /* Diagnostics of the last gal_synth_finish(): carrier-chain legs evaluated by walking, legs accepted by

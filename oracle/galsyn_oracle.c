@@ -17,7 +17,7 @@
  * (every TU includes include/galileo-sdr.h:12-15 and include/structures.h:2), so oracle/_ref holds
  * only a dumper for include/constants.h (tables).  The loop itself is pinned end to end by the
  * reference's own output checksum recorded in BASELINE.md §2 (md5 7ab498dea29a96ff4c4729995d309222,
- * `-l -6,51,100 -t 2022/02/20,12:00:00 -d 10 -I 1`): tests/test_golden_g1.py feeds this oracle with the
+ * `-l -6,51,100 -t 2022/02/20,12:00:00 -d 10 -I 1`): tests/test_golden_scenarios.py feeds this oracle with the
  * host front-end's parameters for that scenario and requires the same md5.
  */
 #include <stdint.h>

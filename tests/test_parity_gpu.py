@@ -164,9 +164,9 @@ def test_invalid_batches_are_rejected(pkg):
 def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
     """With a single enqueued walker pass the chain is never verified in time: gal_synth_finish() must iterate
     from the host and redo the synthesis -- the result is still bit-exact."""
-    monkeypatch.setenv("GAL_WALK_PASSES", "1")
+    monkeypatch.setenv("GAL_WALK_PASSES", "1")  # honoured by the GAL_TEST_HOOKS build only
     p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=77)
-    iq, st, stats = _compare(pkg, p, 52000)
+    iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
     assert stats["walk_passes"] >= 2
 
 
@@ -241,8 +241,9 @@ def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
     k_synth's replay check; gal_synth_finish then redoes the chain with every leg walked and repeats the
     synthesis -- the caller still gets bit-exact IQ, and the fallback is counted."""
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=4, n_slots=8, samples_per_epoch=260000, seed=99)
-    monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")
-    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0) as eng:
+    monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")  # honoured by the GAL_TEST_HOOKS build only
+    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0, test_hooks=True) as eng:
+        assert b"testhooks" in eng._lib.gal_synth_version()
         iq, st, stats = eng.run_host(p)
         walked, translated, fallbacks = eng.walk_counts()
     ref_iq, ref_st = oracle_run(p, 260000, 2.6e6)
@@ -251,7 +252,43 @@ def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
     act = ref_st["prn"] > 0
     assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
     monkeypatch.setenv("GAL_WALK_TRANSLATE", "0")  # and the all-walked mode on its own
-    _compare(pkg, p, 260000)
+    _compare(pkg, p, 260000, test_hooks=True)
+    # the product library has no such hook: the same environment leaves it on the normal path
+    monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")
+    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0) as eng:
+        assert b"testhooks" not in eng._lib.gal_synth_version()
+        iq2, _, _ = eng.run_host(p)
+        assert eng.walk_counts()[2] == 0
+    assert np.array_equal(iq2, ref_iq)
+
+
+def test_range_execute_never_rests_on_an_unreplayed_translation(pkg, monkeypatch):
+    """gal_synth_execute_range replays (and therefore checks) only its own epochs, so a translated leg in front of
+    the range could not be caught by k_synth's self-check: such legs must be walked, never translated.  The test
+    hook would corrupt the translation of (slot 0, epoch 0, leg 5); a range that starts after epoch 0 must come
+    out bit-exact WITHOUT needing the fallback, and the end-of-plan state must be exact too."""
+    import torch
+
+    n = 260000
+    p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=4, n_slots=8, samples_per_epoch=n, seed=99)
+    ref_iq, ref_st = oracle_run(p, n, 2.6e6)
+    monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=8, device=0, test_hooks=True) as eng:
+        eng.plan(p)
+        for e0, ne in ((2, 3), (1, 5), (5, 1)):
+            out = torch.empty(ne * n * 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr(), e0, ne)
+            st, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0 and eng.walk_counts()[2] == 0
+            assert np.array_equal(out.cpu().numpy(), ref_iq[e0 * n * 2:(e0 + ne) * n * 2]), (e0, ne)
+            act = ref_st["prn"] > 0
+            assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+        # a range that contains the bad leg is replayed, caught and repaired
+        out = torch.empty(2 * n * 2, dtype=torch.int16, device="cuda")
+        eng.execute(out.data_ptr(), 0, 2)
+        eng.finish()
+        assert eng.walk_counts()[2] == 1
+        assert np.array_equal(out.cpu().numpy(), ref_iq[: 2 * n * 2])
 
 
 def test_randomised_soak(pkg):
@@ -340,11 +377,10 @@ def test_call_sequence_is_checked(pkg):
         assert np.array_equal(out.cpu().numpy(), ref_iq)
 
 
-def test_single_stream_mode(pkg, monkeypatch):
-    """GAL_WALK_PRIORITY=0: walkers and synthesis on the caller's stream (no internal high-priority stream)."""
-    monkeypatch.setenv("GAL_WALK_PRIORITY", "0")
+def test_single_stream_mode(pkg):
+    """GAL_CFG_SINGLE_STREAM: walkers and synthesis on the caller's stream (no internal high-priority stream)."""
     p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=606)
-    _compare(pkg, p, 52000)
+    _compare(pkg, p, 52000, flags=pkg.synth.GAL_CFG_SINGLE_STREAM)
 
 
 def test_two_handles_in_flight(pkg):
