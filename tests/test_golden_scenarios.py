@@ -57,6 +57,25 @@ def test_g3_default_start_time(pkg):
     assert sorted(rows["prn"][0][rows["prn"][0] > 0].tolist()) == REF["G3"]["prns"]
 
 
+def test_g4_reallocation_md5_equals_reference_output(pkg):
+    """65 s from 11:29:40: crosses the 30 s ephemeris / channel refresh twice (allocateChannel, src/channel.cpp:21-123,
+    called from src/galileo-sdr.cpp:545-562); md5 of the reference's own output file."""
+    rows = _scenario(pkg, start="2022/02/20,11:29:40", duration_s=65, iono_enable=False).all()
+    assert rows.shape == (649, 16)
+    iq, _ = oracle_run(rows, 260000, 2.6e6)
+    assert iq.nbytes == REF["G4"]["bytes"]
+    assert hashlib.md5(iq.tobytes()).hexdigest() == REF["G4"]["md5"]
+
+
+def test_g5_ten_satellites_md5_equals_reference_output(pkg):
+    """-l 45,10,100: 10 SVs, the most this navigation file yields."""
+    rows = pkg.Scenario(NAV, llh=(45, 10, 100), start="2022/02/20,12:00:00", duration_s=10, iono_enable=False).all()
+    assert rows.shape == (99, 16) and int((rows["prn"][0] > 0).sum()) == REF["G5"]["n_sv"]
+    iq, _ = oracle_run(rows, 260000, 2.6e6)
+    assert iq.nbytes == REF["G5"]["bytes"]
+    assert hashlib.md5(iq.tobytes()).hexdigest() == REF["G5"]["md5"]
+
+
 def test_invalid_start_time_is_an_error(pkg):
     import pytest
 

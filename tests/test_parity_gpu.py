@@ -409,3 +409,90 @@ def test_two_handles_in_flight(pkg):
     assert np.array_equal(oa.cpu().numpy(), ra) and np.array_equal(ob.cpu().numpy(), rb)
     ea.close()
     eb.close()
+
+
+def test_m_syn24_real_geometry(pkg):
+    """BASELINE config 4 at its real geometry (24 SVs in two 12-channel launches, 25 MS/s, 2 500 000 samples per
+    epoch), 4 epochs = 10 M samples: every sample against the oracle; chunking must not matter; a run split in two
+    calls with the carried state equals the single run."""
+    import torch
+
+    n, rate = 2500000, 25e6
+    p = pkg.workloads.m_syn24(n_epochs=4)
+    ref_iq, ref_st = oracle_run(p, n, rate)
+    outs = []
+    for chunk in (0, 2048):
+        with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=24, device=0, chunk_samples=chunk) as eng:
+            eng.plan(p)
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr())
+            st, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0 and stats["n_active_max"] == 24 and eng.walk_counts()[2] == 0
+            outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], ref_iq)
+    assert np.array_equal(outs[1], ref_iq)
+    act = ref_st["prn"] > 0
+    assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=24, device=0) as eng:
+        a, st_a, _ = eng.run_host(p[:3])
+        q = p[3:].copy()
+        q["flags"][0, :] = 0
+        b, st_b, _ = eng.run_host(q, st_a)
+    assert np.array_equal(np.concatenate([a, b]), ref_iq)
+    assert np.array_equal(st_b["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+
+
+def test_m_dyn_full_size_properties(pkg):
+    """BASELINE config 3 at full size (M-DYN: 2999 epochs x 260000 samples x 12 SVs, Doppler changing every epoch with
+    a 10 Hz circular track): the size-independent properties of test_full_size_properties --
+      * the first 6 and the LAST 4 epochs (the latter from the oracle restarted on the carried state of a split run)
+        equal the oracle;
+      * chunk 1040 (default) and 1024 give the same bytes;
+      * a run split 1500 + 1499 with the carried state equals the single run, end state included;
+      * the chain self-check is clean and the all-walked fallback is never needed."""
+    import torch
+
+    n, rate = 260000, 2.6e6
+    p = pkg.workloads.m_dyn()
+    E = p.shape[0]
+    assert E == 2999
+    outs = []
+    for chunk in (0, 1024):
+        with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0, chunk_samples=chunk) as eng:
+            eng.plan(p)
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr())
+            st, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0 and eng.walk_counts()[2] == 0
+            if chunk == 0:
+                state_full = st
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    del outs[1:]
+    ref_iq, _ = oracle_run(p[:6], n, rate)
+    assert np.array_equal(outs[0][: 6 * n * 2].cpu().numpy(), ref_iq)
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
+        eng.plan(p[:1500])
+        a = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(a.data_ptr())
+        st_a, _ = eng.finish()
+        q = p[1500:].copy()
+        q["flags"][0, :12] = 0
+        eng.plan(q, st_a)
+        b = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(b.data_ptr())
+        st_b, _ = eng.finish()
+        # state at epoch 2995 from a third plan, so that the oracle can replay the last 4 epochs on its own
+        eng.plan(q[:1495], st_a)
+        c = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(c.data_ptr())
+        st_c, _ = eng.finish()
+    assert torch.equal(outs[0][: a.numel()], a) and torch.equal(outs[0][a.numel():], b)
+    act = state_full["prn"] > 0
+    assert np.array_equal(st_b["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+    assert np.array_equal(st_b["page"][act], state_full["page"][act])
+    tail = p[2995:].copy()
+    tail["flags"][0, :12] = 0
+    ref_tail, ref_st = oracle_run(tail, n, rate, st_c)
+    assert np.array_equal(outs[0][2995 * n * 2:].cpu().numpy(), ref_tail)
+    assert np.array_equal(ref_st["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
