@@ -67,6 +67,7 @@ void init_tables()
 }
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
+constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
 constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare
 
 }  // namespace
@@ -99,7 +100,7 @@ struct gal_synth {
     bool in_flight = false;  // execute() enqueued, finish() not yet called
     int n_groups = 0;  // channel groups (each <= kKernelMaxChan) -> synth launches per execute
     std::vector<int> group_nch;
-    uint8_t *d_act = nullptr;  // [groups][E][S]
+    uint8_t *d_act = nullptr;  // [groups][E][kActRow]
     int *d_nact = nullptr;     // [groups][E]
     int nact_max = 0;
     uint32_t *last_iq = nullptr;
@@ -227,7 +228,10 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
             return bail(fail(GAL_E_DEVICE, "table upload failed"));
     }
     int lut[512];
-    for (int k = 0; k < 512; ++k) lut[k] = 2 * ((int)g_sin[k] * 65536 + (int)g_cos[k]);
+    // v = E1B d - E1C s is 0 or +-2 (src/galileo-sdr.cpp:520-525): the factor 2 lives in the table, the kernel
+    // multiplies by v / 2.  Entry = the int16 pair (2 cos, 2 sin), low half first: the layout of an output sample.
+    for (int k = 0; k < 512; ++k)
+        lut[k] = (int)(((uint32_t)(uint16_t)(int16_t)(2 * g_sin[k]) << 16) | (uint32_t)(uint16_t)(int16_t)(2 * g_cos[k]));
     if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     *out = h;
@@ -381,7 +385,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const int n_groups = nact_max == 0 ? 1 : (nact_max + kKernelMaxChan - 1) / kKernelMaxChan;
     h->n_groups = n_groups;
     h->group_nch.assign(n_groups, 0);
-    std::vector<uint8_t> act_g((size_t)n_groups * E * S, 0);
+    // per channel group: one 16-byte row per epoch (<= kKernelMaxChan positions, zero-padded; k_synth reads it as one word quad)
+    std::vector<uint8_t> act_g((size_t)n_groups * E * kActRow, 0);
     std::vector<int> nact_g((size_t)n_groups * E, 0);
     for (int e = 0; e < E; ++e) {
         const int n = nact_all[e];
@@ -391,7 +396,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         for (int g = 0; g < n_groups; ++g) {
             int m = n - k < per ? n - k : per;
             if (m < 0) m = 0;
-            for (int j = 0; j < m; ++j) act_g[((size_t)g * E + e) * S + j] = act_all[(size_t)e * S + k + j];
+            for (int j = 0; j < m; ++j) act_g[((size_t)g * E + e) * kActRow + j] = act_all[(size_t)e * S + k + j];
             nact_g[(size_t)g * E + e] = m;
             if (m > h->group_nch[g]) h->group_nch[g] = m;
             k += m;
@@ -414,7 +419,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
     const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4), o_pcur = take(ES * GAL_PAGE_WORDS * 4);
     const size_t o_flip = take(ES);
-    const size_t o_act = take((size_t)n_groups * ES), o_nact = take((size_t)n_groups * E * 4);
+    const size_t o_act = take((size_t)n_groups * E * kActRow), o_nact = take((size_t)n_groups * E * 4);
     const size_t o_pguess = take(ES * 8), o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmw = take(LEGS * S * 8),
                  o_clmr = take(LEGS * S * 8);
@@ -437,6 +442,13 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     DevPlan &P = h->P;
     P.E = E; P.S = S; P.N = N; P.R = R; P.nchunks = nchunks; P.CP1 = (int)CP1;
     P.blocks_per_epoch = (tiles + 3) / 4;
+    {
+        // chunks per code period, if the chunk length divides the period (to a hundredth of a sample) and the
+        // epoch holds whole classes; otherwise natural order
+        const double period = (double)GAL_CODE_LEN * h->cfg.sample_rate / 1.023e6;
+        const int cls = (int)std::floor(period / R + 0.5);
+        P.cls = (cls >= 2 && std::fabs(period - (double)cls * R) < 0.01 && nchunks % cls == 0) ? cls : 1;
+    }
     P.W = W; P.Lc = Lc; P.LEGS = (int)LEGS;
     P.delt = 1.0 / h->cfg.sample_rate;
     P.cs25 = kCS25;
@@ -510,13 +522,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 
 static int enqueue_synth(gal_synth *h, uint32_t *iq)
 {
-    const size_t ES = (size_t)h->P.E * h->P.S;
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
         HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
         return GAL_OK;
     }
     for (int g = 0; g < h->n_groups; ++g) {
-        const int rc = galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, h->d_act + (size_t)g * ES,
+        const int rc = galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, h->d_act + (size_t)g * h->P.E * kActRow,
                                          h->d_nact + (size_t)g * h->P.E, iq, h->range_e0, h->range_ne, h->stream);
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
     }

@@ -20,6 +20,8 @@ struct DevPlan {
     int nchunks;  // ceil(N / R)
     int CP1;      // checkpoint row stride = nchunks + 1 (last entry = end-of-epoch state)
     int blocks_per_epoch;
+    int cls;      // code-phase classes: chunk c is replayed by position (c % cls) * (nchunks / cls) + c / cls of its epoch
+                  // (k_synth: lanes of one wave then share their code phase); 1 = natural order
     int W;        // carrier-walk legs per epoch
     int Lc;       // chunks per leg (leg length = Lc * R samples)
     int LEGS;     // E * W
@@ -68,7 +70,7 @@ struct DevPlan {
     int *ctr;  // [CTR_COUNT]
 
     // tables
-    const int *lut;       // [512] 2 * (sin << 16 + cos)
+    const int *lut;       // [512] int16 pairs (2 cos, 2 sin), low half first
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 
@@ -76,6 +78,7 @@ struct DevPlan {
 // that rarely used pointers do not occupy SGPRs inside the sample loop)
 struct SynGeom {
     int S, N, R, nchunks, CP1, blocks_per_epoch;
+    int cls, per;  // lane order: position L of the epoch replays chunk (L % per) * cls + L / per, per = nchunks / cls
     int e0;  // first epoch of the executed range (the output buffer starts there)
 };
 

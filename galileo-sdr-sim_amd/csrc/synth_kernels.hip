@@ -761,9 +761,15 @@ __global__ void k_state_phase(DevPlan P)
 //     of all 64 lanes fall into the same group, so ~9 of 10 groups are fast.
 // Per-lane persistent state per channel: y = 2x, p (FP64) and one packed word
 //     st = ibit[8:0] | use_next_page[9] | sg[11:10] | sg_next[13:12],  sg = (data^sec) | sec<<1.
-// LDS: [NCH][512] half-chip stream words + 4 x 1024-entry LUT (zero / plus / zero / minus).
+// LDS: [NCH][512] half-chip stream words + 2 x 1024-entry carrier LUT (plain for positive, conjugate for negative
+// Doppler), entries = the int16 PAIR (2 cos, 2 sin).  A sample's contribution is
+//     (I, Q) += (2 cos, 2 sin) * v',   v' in {-1, 0, +1}  =  the SIGNED 2-bit window field of its half chip,
+// ONE v_pk_mad_u16 (both halves multiplied by the low half of v'): the sign and the zero case of
+// v = E1B d - E1C s (:520-525) cost nothing, and the accumulator IS the little-endian int16 I,Q word of the output
+// (:536-537) -- exact while |I|, |Q| < 32768, i.e. up to 65 channels of amplitude 500.
 #define SYN_BLOCK 256
 #define SYN_GROUP 16
+#define GAL_ACT_ROW 16  // bytes per epoch in the active-position lists (<= 12 entries used, zero-padded)
 #define STR_WORDS 512
 #define STR_PITCH 513  // LDS words per channel: one pad word (= word 0) so that "the next word" never wraps
 #ifndef SYN_WAVES
@@ -829,6 +835,13 @@ struct ChanGroup {  // live only inside one 16-sample group
 // sg * 0x55555555: 0, 0x5555.., 0xAAAA.., 0xFFFF.. = the XOR mask of the sign pair on all 16 half chips
 #define GAL_SIGN_MASK(sg) ((sg) * 0x55555555u)
 
+// (non-zero, negative-if-non-zero) bit pairs -> two's-complement 2-bit fields 00 / 01 / 11 = 0 / +1 / -1: the upper
+// bit survives only where the lower one is set
+__device__ __forceinline__ uint32_t window_signed(uint32_t w)
+{
+    return w & (((w & 0x55555555u) << 1) | 0x55555555u);
+}
+
 template <int J>
 __device__ __forceinline__ void group_begin_fast(const ChanState &c, ChanGroup &g, const uint32_t *s_str)
 {
@@ -836,7 +849,7 @@ __device__ __forceinline__ void group_begin_fast(const ChanState &c, ChanGroup &
     const uint32_t *wp = s_str + J * STR_PITCH + (ic0 >> 4);
     const uint32_t lo = wp[0], hi = wp[1];  // (the pad word makes wp[1] valid for the last word; ds_read2_b32)
     const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
-    g.W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)ic0 << 1) ^ mask;  // v_alignbit uses shift[4:0]
+    g.W = window_signed(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)ic0 << 1) ^ mask);  // v_alignbit uses shift[4:0]
     g.m = -2 * ic0;
 }
 
@@ -859,88 +872,94 @@ __device__ __forceinline__ void group_begin_slow(const ChanState &c, ChanGroup &
     const uint32_t sh = (uint32_t)(2 * jw) & 31u;
     const uint32_t keep = splice ? ((1u << sh) - 1u) : ~0u;
     const uint32_t tail = splice ? ((head ^ GAL_SIGN_MASK(sg_nxt)) << sh) : 0u;
-    g.W = (W & keep) | tail;
+    g.W = window_signed((W & keep) | tail);
     // a pending wrap is taken by the first sample, which switches m to mw like any other wrap
     g.mw = -2 * ic0 + (pend ? 0 : 16);
     g.m = g.mw - 16;
 }
 
-// One sample of one channel, src/galileo-sdr.cpp:509-532, branch-free.  Returns ip + (qp << 16).
-// cs2 = 2 * f_code * delt.  s_lut2 points at entry k = 0 of the first of FOUR 1024-entry tables indexed by
-// k in (-512, 512): table q = nz | neg << 1 holds  0, +LUT[k & 511], 0, -LUT[k & 511].  The two's-complement
-// mask of :509-510, the sign and the zero case of v are all folded into the LDS address.
-__device__ __forceinline__ int chan_step(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
-                                         const int sgn4, const int *s_lut2)
+typedef short gal_s2 __attribute__((ext_vector_type(2)));
+
+// acc.(I,Q) += entry.(I,Q) * v  as ONE v_pk_mad_u16 ... op_sel_hi:[1,0,1] (the compiler folds the splat of v into the
+// operand select).  Written with vector types, not asm: the scheduler must see the LDS latency of `entry`; the
+// empty asm keeps the four channels of a part one accumulate chain (re-associated into a tree it costs 5
+// instructions instead of 4).
+__device__ __forceinline__ void gal_acc(int &acc, const int entry, const int v)
 {
-    // --- chip lookup, :512-521: icode = (int)(2x); selector bits of that half chip
+    const gal_s2 t2 = __builtin_bit_cast(gal_s2, entry);
+    const gal_s2 v2 = {(short)v, (short)v};
+    const gal_s2 a2 = t2 * v2 + __builtin_bit_cast(gal_s2, acc);
+    acc = __builtin_bit_cast(int, a2);
+#ifdef GAL_ACC_CHAIN
+    asm("" : "+v"(acc));
+#endif
+}
+
+// One sample of one channel, src/galileo-sdr.cpp:509-532, branch-free:  (I, Q) += v' * (2 cos, 2 sin).
+// cs2 = 2 * f_code * delt.  lutb = LDS byte address of entry k = 0 of this channel's carrier table (plain table for
+// positive, conjugate table for negative Doppler: the phase is kept MIRRORED, see ChanState, so the reference's
+// k = (int)(511 carr_phase) is +-(int)(511 p)); each table holds entries k in (-512, 512) as LUT[k & 511] resp.
+// LUT[-k & 511], which is the two's-complement mask of :509-510.
+__device__ __forceinline__ void chan_step(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
+                                          const uint32_t lutb, int &acc)
+{
+    // --- chip lookup, :512-521: icode = (int)(2x); signed 2-bit field of that half chip
     const int ic = (int)c.y;
     int off;
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(ic), "v"(g.m));
-    const uint32_t q = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);  // v_bfe_u32 uses offset[4:0]
-    // --- carrier LUT, :509-510: trunc toward zero (mask, sign and zero folded into the table choice).  c.p is
-    //     the MIRRORED phase (see ChanState): (int)(511 p) = +-(int)(511 c.p), sgn4 = +-4 bytes per entry
+    const int v = __builtin_amdgcn_sbfe((int)g.W, (uint32_t)off, 2);  // v_bfe_i32 uses offset[4:0]
+    // --- carrier LUT, :509-510: trunc toward zero
     const int k = (int)(511.0 * c.p);
-    int a4;
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(a4) : "v"(k), "s"(sgn4));
+    uint32_t a;
     // (spelled in asm: the combiner otherwise re-associates the shift-add into shifts, masks and an add3)
-    asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(q), "v"(a4));
-    const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_lut2) + a4);
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(k), "s"(lutb));
+    const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
+    gal_acc(acc, t, v);
     // --- NCO updates, :528-532 (mirrored: IEEE addition and truncation are sign-symmetric)
     c.y = c.y + cs2;
     c.p = carr_step(c.p, __builtin_fabs(ds));
-    return t;
 }
 
 // The fast group body's version: no code wrap inside the group, and the mirrored phase is non-negative (phase and
 // step have the same sign, checked by the caller), so that `p += d; p -= (long)p` (:531-532) becomes
 // |p| = fract(|p| + |d|): for 0 <= x < 2, x - floor(x) is the reference's x - trunc(x) and the subtraction is
 // exact, hence the same bits with one instruction less.
-__device__ __forceinline__ int chan_step_fast(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
-                                              const int sgn4, const int *s_lut2)
+__device__ __forceinline__ void chan_step_fast(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
+                                               const uint32_t lutb, int &acc)
 {
     const int ic = (int)c.y;
     int off;
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(ic), "v"(g.m));
-    const uint32_t q = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);
+    const int v = __builtin_amdgcn_sbfe((int)g.W, (uint32_t)off, 2);
     const int k = (int)(511.0 * c.p);
-    int a4;  // signed byte offset of entry k in table 0
-    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(a4) : "v"(k), "s"(sgn4));
-    asm("v_lshl_add_u32 %0, %1, 12, %2" : "=v"(a4) : "v"(q), "v"(a4));
-    const int t = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(s_lut2) + a4);
+    uint32_t a;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(k), "s"(lutb));
+    const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
+    gal_acc(acc, t, v);
     c.y = c.y + cs2;
     c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));
-    return t;
 }
 
 // The same with the symbol advance of :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact);
 // the symbol counter is advanced in the group epilogue.
-__device__ __forceinline__ int chan_step_wrap(ChanState &c, ChanGroup &g, const double cs2, const double ds,
-                                              const int sgn4, const int *s_lut2)
+__device__ __forceinline__ void chan_step_wrap(ChanState &c, ChanGroup &g, const double cs2, const double ds,
+                                               const uint32_t lutb, int &acc)
 {
     const bool ge = c.y >= 8184.0;
     c.y = c.y - (ge ? 8184.0 : 0.0);
     g.m = ge ? g.mw : g.m;
-    return chan_step(c, g, cs2, ds, sgn4, s_lut2);
+    chan_step(c, g, cs2, ds, lutb, acc);
 }
 
-template <int J>
-__device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, const DevPlan *Pd, const uint8_t *act,
-                                          int e)
+__device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, const DevPlan *Pd, const int idx)
 {
     if (__builtin_expect(g.m == g.mw, 0)) {  // the code wrapped inside this group (once per 4 ms of signal)
-        const int idx = e * Pd->S + (int)act[J];
         c.st = sym_state(Pd, idx, (int)(c.st & 0x1ffu) + 1, (int)((c.st >> 9) & 1u));
     }
 }
 
 #define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define GAL_MAX_NCH 12
-// acc = Q*65536 + I with |I|,|Q| < 32768  ->  little-endian int16 pair I,Q (:536-537)
-// = (((acc) + 0x8000) & 0xffff0000) | ((acc) & 0xffff): the byte permute takes bytes 3,2 of the rounded sum and
-// bytes 1,0 of acc in one instruction
-#define GAL_PACK(acc) __builtin_amdgcn_perm((uint32_t)(acc) + 0x8000u, (uint32_t)(acc), 0x07060100u)
-#define GAL_UNPACK(w) ((int)((w) & 0xffff0000u) + (int)(short)((w) & 0xffffu))
-
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
 template <int NCH, bool ACC>
 __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_WAVES))) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
@@ -949,50 +968,141 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 {
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
     __shared__ uint32_t s_str[NCH * STR_PITCH];
-    __shared__ int s_lut[4 * 1024];  // table q = nz | neg<<1, entry k + 512: {0, +LUT, 0, -LUT}[q][k & 511]
-    const int *s_lut2 = s_lut + 512;
+    __shared__ int s_lut[2 * 1024];  // entry k + 512 of table 0: LUT[k & 511], of table 1: LUT[-k & 511]
 
     const int er = blockIdx.x / G.blocks_per_epoch;  // epoch relative to the executed range
     const int tg = blockIdx.x - er * G.blocks_per_epoch;
     const int e = G.e0 + er;
     const int tid = threadIdx.x;
-    const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
-    const uint8_t *act = act_all + (size_t)e * G.S;
 
-    for (int i = tid; i < 4 * 1024; i += SYN_BLOCK) {
-        const int q = i >> 10, v = Pd->lut[i & 511];
-        s_lut[i] = (q & 1) ? ((q & 2) ? -v : v) : 0;
-    }
-    for (int j = 0; j < nact; ++j) {
-        const int prn = Pd->prn[e * G.S + act[j]];
-        const uint32_t *src = Pd->str + (size_t)(prn - 1) * STR_WORDS;
-        for (int i = tid; i < STR_PITCH; i += SYN_BLOCK) s_str[j * STR_PITCH + i] = src[i & (STR_WORDS - 1)];
+    // Everything the block needs before its sample loop is fetched in a few WIDE phases (all loads of a phase are
+    // independent and in flight together): with one load per wait the ~60 dependent round trips to L2 / HBM of this
+    // prologue cost ~40 us per block, 5 % of its run time.
+    // ---- phase 0 (scalar): plan pointers, the epoch's active list (16-byte rows, zero-padded) and channel records
+    const int *const p_lut = Pd->lut;
+    const int *const p_prn = Pd->prn;
+    const uint32_t *const p_str = Pd->str;
+    const double *const p_cpx = Pd->cp_x, *const p_cpp = Pd->cp_p;
+    const uint32_t *const p_cpi = Pd->cp_ib;
+    const double *const p_cstep = Pd->cstep, *const p_dstep = Pd->dstep;
+    const uint32_t *const p_pcur = Pd->page_cur, *const p_pnext = Pd->page_next;
+    const uint32_t cs25 = Pd->cs25;
+    const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
+    const uint4 aw = *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW);
+    const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};
+    // slot index e * S + act[j] of position j (idle positions alias slot act[0]: loads stay in bounds, results unused)
+#define GAL_IX(j) const int ix##j = __builtin_amdgcn_readfirstlane(e * G.S + (int)((awv[(j) >> 2] >> (8 * ((j) & 3))) & 0xffu));
+    GAL_CH_LIST(GAL_IX)
+#undef GAL_IX
+    int ixs[GAL_MAX_NCH];
+#define GAL_IXS(j) ixs[j] = ix##j;
+    GAL_CH_LIST(GAL_IXS)
+#undef GAL_IXS
+
+    // ---- phase 1: LDS tables.  Per thread 2 stream words per channel + 8 LUT entries, all loads first, then the stores
+    {
+        uint32_t w0[NCH], w1[NCH];
+        int lv[2 * 1024 / SYN_BLOCK];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int prn = p_prn[ixs[j]];
+            prn = prn < 1 ? 1 : prn;  // idle position: any valid row, zeroed below
+            const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
+            w0[j] = src[tid];
+            w1[j] = src[tid + SYN_BLOCK];
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * 1024 / SYN_BLOCK; ++q) {
+            const int i = tid + q * SYN_BLOCK;
+            const int k = (i & 1023) - 512;
+            lv[q] = p_lut[((i >> 10) ? -k : k) & 511];
+        }
+        // idle positions (epochs with fewer than NCH active channels) run the same branch-free group code on an
+        // all-zero state and an all-zero stream: window 0 -> every field 0 -> no contribution; steps 0 keep the state
+        // at rest
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const bool on = j < nact;
+            s_str[j * STR_PITCH + tid] = on ? w0[j] : 0u;
+            s_str[j * STR_PITCH + tid + SYN_BLOCK] = on ? w1[j] : 0u;
+            if (tid == 0) s_str[j * STR_PITCH + STR_WORDS] = on ? w0[j] : 0u;  // pad word = word 0
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * 1024 / SYN_BLOCK; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
     }
     __syncthreads();
 
-    const int c = (tg * (SYN_BLOCK / 64) + (tid >> 6)) * 64 + (tid & 63);  // chunk index within the epoch
-    if (c >= G.nchunks) return;
+    // Position L of the epoch -> chunk c.  When the chunk length divides the code period (cls chunks per period),
+    // the positions are ordered by CODE-PHASE CLASS c % cls first: all chunks of a class start at the same code phase,
+    // so a wave (64 consecutive positions = 2-3 classes) meets a channel's code wrap in a group only if one of ITS
+    // classes is the one that wraps in this chunk -- about one wave in four instead of every wave, and when it does,
+    // many of its lanes need the slow body, not one in ten.
+    const int L = (tg * (SYN_BLOCK / 64) + (tid >> 6)) * 64 + (tid & 63);
+    if (L >= G.nchunks) return;
+    const int c = (L % G.per) * G.cls + L / G.per;  // (identity for cls == 1)
     const int n0 = c * G.R;
     int nsteps = G.N - n0;
     if (nsteps > G.R) nsteps = G.R;
 
     // Per-channel state as individually named scalars (macro-expanded), NOT arrays: hipcc turns small
     // per-thread arrays into wide vector registers and copies whole tuples around every conditional update.
+    // (The arrays below live only in this prologue, fully unrolled.)
 #define GAL_HI(x) ((uint32_t)(d2u(x) >> 32))
 #define GAL_MIRROR_BITS(p, ds) p = u2d(((uint64_t)(GAL_HI(p) ^ (GAL_HI(ds) & 0x80000000u)) << 32) | (uint32_t)d2u(p));
+    double yv[NCH], pv[NCH], csv[NCH], dsv[NCH];
+    uint32_t stv[NCH];
+    {
+        // ---- phase 2: the chunk's checkpoints (per lane) and the epoch's NCO steps (scalar)
+        double cx[NCH];
+        uint32_t cib[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const size_t cp = (size_t)ixs[j] * G.CP1 + c;
+            cx[j] = p_cpx[cp];
+            pv[j] = p_cpp[cp];
+            cib[j] = p_cpi[cp];  // ibit | flipped << 16
+            csv[j] = p_cstep[ixs[j]];
+            dsv[j] = p_dstep[ixs[j]];
+        }
+        // ---- phase 3: page words of the current and of the next symbol (sym_state, branch-free)
+        uint32_t wa[NCH], wb[NCH];
+        int ib[NCH], nx[NCH], nib[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            int b = (int)(cib[j] & 0xffffu), x = (int)(cib[j] >> 16);
+            const bool over = b >= GAL_N_SYM_PAGE;  // :497-506: next page
+            b = over ? 0 : b;
+            x = over ? 1 : x;
+            int nb = b + 1, nnx = x;
+            const bool over2 = nb >= GAL_N_SYM_PAGE;
+            nb = over2 ? 0 : nb;
+            nnx = over2 ? 1 : nnx;
+            const size_t po = (size_t)ixs[j] * GAL_PAGE_WORDS;
+            wa[j] = (x ? p_pnext : p_pcur)[po + (b >> 5)];
+            wb[j] = (nnx ? p_pnext : p_pcur)[po + (nb >> 5)];
+            ib[j] = b; nx[j] = x; nib[j] = nb;
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const bool on = j < nact;
+            const uint32_t d0 = (wa[j] >> (ib[j] & 31)) & 1u, s0b = (cs25 >> (ib[j] % 25)) & 1u;
+            const uint32_t d1 = (wb[j] >> (nib[j] & 31)) & 1u, s1b = (cs25 >> (nib[j] % 25)) & 1u;
+            const uint32_t sg = (d0 ^ s0b) | (s0b << 1), sgn = (d1 ^ s1b) | (s1b << 1);
+            stv[j] = on ? ((uint32_t)ib[j] | ((uint32_t)nx[j] << 9) | (sg << 10) | (sgn << 12)) : 0u;
+            csv[j] = on ? uniform_f64(2.0 * csv[j]) : 0.0;
+            dsv[j] = on ? uniform_f64(dsv[j]) : 0.0;
+            yv[j] = on ? 2.0 * cx[j] : 0.0;
+            double pm = pv[j];
+            GAL_MIRROR_BITS(pm, dsv[j])  // mirrored: see ChanState
+            pv[j] = on ? pm : 0.0;
+        }
+    }
 #define GAL_DECL(j)                                                                         \
     ChanState ch##j = {0.0, 0.0, 0u};                                                       \
     double cs##j = 0.0, ds##j = 0.0;                                                        \
-    if (j < NCH && j < nact) {                                                              \
-        const int idx = __builtin_amdgcn_readfirstlane(e * G.S + (int)act[j]);              \
-        const size_t cp = (size_t)idx * G.CP1 + c;                                          \
-        ch##j.y = 2.0 * Pd->cp_x[cp];                                                       \
-        ch##j.p = Pd->cp_p[cp]; /* mirrored below, once ds is known */                      \
-        const uint32_t v = Pd->cp_ib[cp]; /* ibit | flipped<<16 */                          \
-        cs##j = uniform_f64(2.0 * Pd->cstep[idx]);                                          \
-        ds##j = uniform_f64(Pd->dstep[idx]);                                                \
-        GAL_MIRROR_BITS(ch##j.p, ds##j)                                                     \
-        ch##j.st = sym_state(Pd, idx, (int)(v & 0xffffu), (int)(v >> 16));                  \
+    if (j < NCH) {                                                                          \
+        ch##j.y = yv[j < NCH ? j : 0]; ch##j.p = pv[j < NCH ? j : 0]; ch##j.st = stv[j < NCH ? j : 0]; \
+        cs##j = csv[j < NCH ? j : 0]; ds##j = dsv[j < NCH ? j : 0];                         \
     }
     GAL_CH_LIST(GAL_DECL)
 #undef GAL_DECL
@@ -1002,23 +1112,45 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #define GAL_CSMAX(j) if (j < NCH) csmax = cs##j > csmax ? cs##j : csmax;
     GAL_CH_LIST(GAL_CSMAX)
 #undef GAL_CSMAX
-    const double thr = uniform_f64(8184.0 - 16.0 * csmax);
+    // A part's group may take the FAST body iff none of its codes can reach the wrap within the group's 16 samples,
+    // i.e. y < 8184 - 16 csmax at the group start, and no mirrored phase is negative.  Instead of testing that per
+    // channel per group, every part keeps a per-lane COUNTDOWN sf = number of further groups for which it provably
+    // holds: y after i groups is y + 16 i cs up to ~1e-9 (65 groups of 16 roundings at ulp 2^-40), far inside the
+    // 2^-10 taken off the threshold and the 2^-30 taken off the reciprocal; fast groups leave p >= 0.  The countdown
+    // is recomputed after every slow group (which is correct whether or not a wrap occurs: being conservative
+    // costs time only).
+    const double thr2 = uniform_f64(8184.0 - 16.0 * csmax - 0.0009765625);
+    const double inv16 = uniform_f64(csmax > 0.0 ? (1.0 - 9.313225746154785e-10) / (16.0 * csmax) : 0.0);
+#define GAL_SF_DECL(j) [[maybe_unused]] int sf##j = 0;
+    GAL_CH_LIST(GAL_SF_DECL)
+#undef GAL_SF_DECL
 
+    // LDS byte address of s_lut[512] (entry k = 0 of the plain table), wave-uniform
+    typedef const __attribute__((address_space(3))) int *lds_int_ptr;
+    const uint32_t lut0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)(s_lut + 512));
     uint32_t *out = iq + (size_t)er * G.N + n0;  // iq holds the executed range only
     // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
     // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
     // bursts at 1.2x: tools/wrcal.hip).
     const bool vec_ok = ((((size_t)er * G.N + n0) & 15) == 0);
 
-// idle positions (j >= nact) run the same branch-free code on an all-zero state: window 0 gives a zero
-// contribution, steps 0 keep the state at rest -- no per-channel branch inside the group
-#define GAL_NEAR(j) if (j < NCH && j < nact) near |= (ch##j.y >= thr) | ((int)GAL_HI(ch##j.p) < 0);
-#define GAL_BEGIN_F(j) if (j < NCH && j < nact) group_begin_fast<j>(ch##j, gr##j, s_str);
-#define GAL_BEGIN_S(j) if (j < NCH && j < nact) group_begin_slow<j>(ch##j, gr##j, s_str);
-#define GAL_SGN4(j) const int sg4##j = 4 + (((int)(d2u(ds##j) >> 32) >> 31) & -8); /* +-4, scalar ALU */
-#define GAL_STEP_F(j) if (j < NCH) acc += chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, s_lut2);
-#define GAL_STEP_S(j) if (j < NCH) acc += chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, s_lut2);
-#define GAL_END(j) if (j < NCH && j < nact) group_end<j>(ch##j, gr##j, Pd, act, e);
+// (no `j < nact` tests inside the group loop: see the zero-filled stream rows above)
+#define GAL_ROOM(j) if (j < NCH) { const double r = thr2 - ch##j.y; room = r < room ? r : room; negp |= (int)GAL_HI(ch##j.p); }
+#define GAL_SAFE(a, b, c, d)                                                     \
+    if (a < NCH) {                                                               \
+        double room = 1048576.0;                                                 \
+        int negp = 0;                                                            \
+        GAL_ROOM(a) GAL_ROOM(b) GAL_ROOM(c) GAL_ROOM(d)                          \
+        const int n = (int)(room * inv16); /* room < 0 -> n <= 0 */              \
+        sf##a = negp < 0 ? 0 : n;                                                \
+    }
+#define GAL_BEGIN_F(j) if (j < NCH) group_begin_fast<j>(ch##j, gr##j, s_str);
+#define GAL_BEGIN_S(j) if (j < NCH) group_begin_slow<j>(ch##j, gr##j, s_str);
+/* LDS byte address of entry k = 0 of the channel's table: plain (ds >= 0) or conjugate (ds < 0); scalar ALU */
+#define GAL_SGN4(j) const uint32_t sg4##j = lut0 + (((uint32_t)(d2u(ds##j) >> 32) >> 31) << 12);
+#define GAL_STEP_F(j) if (j < NCH) chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
+#define GAL_STEP_S(j) if (j < NCH) chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
+#define GAL_END(j) if (j < NCH) group_end(ch##j, gr##j, Pd, ix##j);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
 // (all NCO chains first, all accumulates last) and spills hundreds of values
 #define GAL_PIN(a, b, c, d)                                                                              \
@@ -1032,9 +1164,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     if (a < NCH) {                                                               \
         ChanGroup gr##a = {0u, 0, 1}, gr##b = {0u, 0, 1};                        \
         ChanGroup gr##c = {0u, 0, 1}, gr##d = {0u, 0, 1};                        \
-        bool near = (GSZ != SYN_GROUP);                                          \
-        GAL_NEAR(a) GAL_NEAR(b) GAL_NEAR(c) GAL_NEAR(d)                          \
+        const bool near = (GSZ != SYN_GROUP) | (sf##a < 1);                      \
         if (__builtin_amdgcn_ballot_w64(near) == 0) {                            \
+            sf##a -= 1;                                                          \
             GAL_BEGIN_F(a) GAL_BEGIN_F(b) GAL_BEGIN_F(c) GAL_BEGIN_F(d)          \
             GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
             _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
@@ -1055,6 +1187,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 o[u] = acc;                                                      \
             }                                                                    \
             GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)                          \
+            if (GSZ == SYN_GROUP) { GAL_SAFE(a, b, c, d) }                       \
         }                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                       \
     }
@@ -1062,28 +1195,30 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // Balanced parts: a part with a single channel has no ILP to hide its FP64/LDS latency, so 5, 6, 7, 9 and 10
 // channels are cut 3+2, 3+3, 4+3, 3+3+3 and 4+3+3 instead of 4+1, 4+2, 4+3, 4+4+1 and 4+4+2 (positions >= NCH
 // are compiled out; 10 and 11 serve as the dummies).
-#define GAL_ALL_PARTS                                                                            \
-    if constexpr (NCH == 5) { GAL_PART(0, 1, 2, 11) GAL_PART(3, 4, 10, 11) }                      \
-    else if constexpr (NCH == 6) { GAL_PART(0, 1, 2, 11) GAL_PART(3, 4, 5, 11) }                  \
-    else if constexpr (NCH == 9) { GAL_PART(0, 1, 2, 11) GAL_PART(3, 4, 5, 11) GAL_PART(6, 7, 8, 11) } \
-    else if constexpr (NCH == 10) { GAL_PART(0, 1, 2, 3) GAL_PART(4, 5, 6, 11) GAL_PART(7, 8, 9, 11) } \
-    else { GAL_PART(0, 1, 2, 3) GAL_PART(4, 5, 6, 7) GAL_PART(8, 9, 10, 11) }
+#define GAL_FOR_PARTS(M)                                                                         \
+    if constexpr (NCH == 5) { M(0, 1, 2, 11) M(3, 4, 10, 11) }                                    \
+    else if constexpr (NCH == 6) { M(0, 1, 2, 11) M(3, 4, 5, 11) }                                \
+    else if constexpr (NCH == 9) { M(0, 1, 2, 11) M(3, 4, 5, 11) M(6, 7, 8, 11) }                 \
+    else if constexpr (NCH == 10) { M(0, 1, 2, 3) M(4, 5, 6, 11) M(7, 8, 9, 11) }                 \
+    else { M(0, 1, 2, 3) M(4, 5, 6, 7) M(8, 9, 10, 11) }
+#define GAL_ALL_PARTS GAL_FOR_PARTS(GAL_PART)
+
+    GAL_FOR_PARTS(GAL_SAFE)
 
     int s0 = 0;
     for (; s0 + SYN_GROUP <= nsteps; s0 += SYN_GROUP) {
         constexpr int GSZ = SYN_GROUP;
-        int o[SYN_GROUP];
-        if (ACC) {
+        int o[SYN_GROUP];  // the int16 pairs I,Q of the group's samples, as they go to memory
+        if (ACC) {  // second and later channel groups of a sample (> 12 active channels): continue from what is stored
             if (vec_ok) {
 #pragma unroll
                 for (int q = 0; q < SYN_GROUP / 4; ++q) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(out + s0 + 4 * q);
-                    o[4 * q] = GAL_UNPACK(v.x); o[4 * q + 1] = GAL_UNPACK(v.y);
-                    o[4 * q + 2] = GAL_UNPACK(v.z); o[4 * q + 3] = GAL_UNPACK(v.w);
+                    o[4 * q] = (int)v.x; o[4 * q + 1] = (int)v.y; o[4 * q + 2] = (int)v.z; o[4 * q + 3] = (int)v.w;
                 }
             } else {
 #pragma unroll
-                for (int u = 0; u < SYN_GROUP; ++u) o[u] = GAL_UNPACK(out[s0 + u]);
+                for (int u = 0; u < SYN_GROUP; ++u) o[u] = (int)out[s0 + u];
             }
         } else {
 #pragma unroll
@@ -1094,23 +1229,25 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #pragma unroll
             for (int q = 0; q < SYN_GROUP / 4; ++q)
                 *reinterpret_cast<uint4 *>(out + s0 + 4 * q) =
-                    make_uint4(GAL_PACK(o[4 * q]), GAL_PACK(o[4 * q + 1]), GAL_PACK(o[4 * q + 2]), GAL_PACK(o[4 * q + 3]));
+                    make_uint4((uint32_t)o[4 * q], (uint32_t)o[4 * q + 1], (uint32_t)o[4 * q + 2], (uint32_t)o[4 * q + 3]);
         } else {
 #pragma unroll
-            for (int u = 0; u < SYN_GROUP; ++u) out[s0 + u] = GAL_PACK(o[u]);
+            for (int u = 0; u < SYN_GROUP; ++u) out[s0 + u] = (uint32_t)o[u];
         }
     }
     for (; s0 < nsteps; ++s0) {  // ragged tail: groups of one sample
         constexpr int GSZ = 1;
         int o[1];
-        o[0] = ACC ? GAL_UNPACK(out[s0]) : 0;
+        o[0] = ACC ? (int)out[s0] : 0;
         GAL_ALL_PARTS
-        out[s0] = GAL_PACK(o[0]);
+        out[s0] = (uint32_t)o[0];
     }
 #undef GAL_ALL_PARTS
+#undef GAL_FOR_PARTS
+#undef GAL_SAFE
+#undef GAL_ROOM
 #undef GAL_PART
 #undef GAL_PIN
-#undef GAL_NEAR
 #undef GAL_SGN4
 #undef GAL_BEGIN_F
 #undef GAL_BEGIN_S
@@ -1118,16 +1255,25 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_STEP_S
 #undef GAL_END
 
-    // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit.
+    // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit (all loads first).
     {
+        const double *const q_cpx = Pd->cp_x, *const q_cpp = Pd->cp_p;
+        const uint32_t *const q_cpi = Pd->cp_ib;
+        double ex[NCH], ep[NCH];
+        uint32_t ei[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const size_t cp = (size_t)ixs[j] * G.CP1 + c + 1;
+            ex[j] = q_cpx[cp];
+            ep[j] = q_cpp[cp];
+            ei[j] = q_cpi[cp];
+        }
         int bad = 0;
 #define GAL_CHECK(j)                                                                  \
     if (j < NCH && j < nact) {                                                        \
-        const int idx = e * G.S + (int)act[j];                                        \
-        const size_t cp = (size_t)idx * G.CP1 + c + 1;                                \
-        const uint32_t v = Pd->cp_ib[cp];                                             \
-        bad += d2u(ch##j.y) != d2u(2.0 * Pd->cp_x[cp]);                               \
-        { double pm = Pd->cp_p[cp]; GAL_MIRROR_BITS(pm, ds##j)                            \
+        const uint32_t v = ei[j < NCH ? j : 0];                                       \
+        bad += d2u(ch##j.y) != d2u(2.0 * ex[j < NCH ? j : 0]);                        \
+        { double pm = ep[j < NCH ? j : 0]; GAL_MIRROR_BITS(pm, ds##j)                 \
           bad += ch##j.p != pm; } /* numeric: the mirrored form may leave -0.0 for +0.0 */ \
         bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
     }
@@ -1139,10 +1285,10 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         if (c == 0 && e > 0) {
 #define GAL_LINK(j)                                                                                  \
     if (j < NCH && j < nact) {                                                                       \
-        const int idx = e * G.S + (int)act[j];                                                       \
+        const int idx = ix##j;                                                                       \
         if (!(Pd->flags[idx] & GAL_CH_RESTART)) {                                                    \
-            const double p_in = Pd->cp_p[(size_t)idx * G.CP1];                                       \
-            const double p_prev = Pd->cp_p[(size_t)(idx - G.S) * G.CP1 + G.nchunks];                 \
+            const double p_in = q_cpp[(size_t)idx * G.CP1];                                          \
+            const double p_prev = q_cpp[(size_t)(idx - G.S) * G.CP1 + G.nchunks];                    \
             bad += d2u(p_in) != d2u(p_prev);                                                         \
         }                                                                                            \
     }
@@ -1202,6 +1348,8 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     SynGeom G;
     G.e0 = e0;
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1; G.blocks_per_epoch = P->blocks_per_epoch;
+    G.cls = P->cls > 0 ? P->cls : 1;
+    G.per = P->nchunks / G.cls;
     switch (nch) {
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq); break;
         GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first():
+    """On the GPU box: bring torch's HIP runtime up BEFORE the first engine library is dlopen()ed.  torch ships its
+    own ROCm runtime; initialising it after libgalsynth.so AND the GAL_TEST_HOOKS build had both been loaded made
+    torch.cuda report 'No HIP GPUs are available' (order-dependent; seen when test_parity_gpu.py ran on its own)."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def pkg():
     from __graft_entry__ import load_pkg

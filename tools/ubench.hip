@@ -10,12 +10,16 @@
 template <int OP>
 __global__ __launch_bounds__(256) void k(double *out, double seed, int iters)
 {
-    double a[CHAINS];
-    int ia[CHAINS];
+    double a[CHAINS], b2[CHAINS];
+    int ia[CHAINS], ib[CHAINS];
+    __shared__ int lds[4096];
+    lds[threadIdx.x] = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < CHAINS; ++j) {
         a[j] = seed + j * 0.125 + threadIdx.x * 1e-6;
         ia[j] = threadIdx.x + j;
+        ib[j] = j;
+        b2[j] = 0.0;
     }
     const double c = seed * 1e-3;
     const double cs = __builtin_bit_cast(double, ((uint64_t)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(uint64_t, c) >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint64_t, c)));
@@ -45,11 +49,34 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, int iters)
             if (OP == 19) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(ia[j]) : "v"(i));
             if (OP == 20) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(ia[j]) : "v"(i));
             if (OP == 21) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(ia[j]) : "v"(i), "s"(si));
+            if (OP == 22) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(ia[j]));
+            if (OP == 23) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(ia[j]) : "s"(si), "v"(i));
+            if (OP == 24) asm volatile("v_alignbit_b32 %0, %0, %0, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 25) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(ia[j]) : "s"(si), "v"(i));
+            if (OP == 26) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(ia[j]) : "s"(si), "v"(i));
+            if (OP == 27) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(ia[j]), "+v"(ib[j]) : "v"(i) : "vcc");
+            if (OP == 28) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(ia[j]) : "s"(si));
+            if (OP == 29) asm volatile("v_bfe_u32 %0, %0, 4, 2" : "+v"(ia[j]));
+            if (OP == 30) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[j]) : "s"(cs));
+            if (OP == 31) asm volatile("v_add_f64 %0, %1, %2" : "=v"(b2[j]) : "v"(a[j]), "s"(cs));
+            if (OP == 32) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 33) asm volatile("v_and_b32 %0, 0x3000, %0" : "+v"(ia[j]));
+            if (OP == 34) asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 35) asm volatile("v_mov_b32 %0, %1" : "=v"(ia[j]) : "v"(i));
+            if (OP == 36) asm volatile("v_add_u32 %0, %1, %0" : "+v"(ia[j]) : "s"(si));
+            if (OP == 37) asm volatile("v_cvt_i32_f64 %0, %1\n v_lshlrev_b32 %0, 1, %0" : "=v"(ia[j]) : "v"(a[j]));
+            if (OP == 38) asm volatile("v_fract_f64 %0, %1" : "=v"(b2[j]) : "v"(a[j]));
+            if (OP == 39) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(a[j]) : "v"(ia[j]));
+            if (OP == 40) asm volatile("ds_read_b32 %0, %1" : "=v"(ib[j]) : "v"(ia[j]));
+            if (OP == 41) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 42) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(ia[j]) : "v"(i));
+            if (OP == 43) asm volatile("v_add_f64 %0, %0, %1 \n v_fract_f64 %0, %0" : "+v"(a[j]) : "s"(cs));
         }
     }
     double s = 0;
 #pragma unroll
-    for (int j = 0; j < CHAINS; ++j) s += a[j] + ia[j];
+    for (int j = 0; j < CHAINS; ++j) s += a[j] + ia[j] + ib[j] + b2[j];
+    if (OP == 40) asm volatile("s_waitcnt lgkmcnt(0)");
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -90,9 +117,22 @@ int main()
     const double r15 = run<15>("v_add_f64 sgpr", d), r16 = run<16>("v_lshl_add_u32", d), r17 = run<17>("v_bfe_u32", d);
     const double r18 = run<18>("v_mul_i32_i24 s", d), r19 = run<19>("v_mul_lo_u32", d), r20 = run<20>("v_add3_u32", d);
     const double r21 = run<21>("v_perm_b32", d);
+    struct { const char *n; double v; } more[] = {
+        {"v_lshlrev_b32 imm", run<22>("v_lshlrev_b32 imm", d)}, {"v_and_or_b32", run<23>("v_and_or_b32", d)},
+        {"v_alignbit_b32", run<24>("v_alignbit_b32", d)}, {"v_mad_u32_u24", run<25>("v_mad_u32_u24", d)},
+        {"v_bfi_b32", run<26>("v_bfi_b32", d)}, {"add_co+addc (2)", run<27>("add_co+addc", d)},
+        {"v_lshl_add_u32 sgpr", run<28>("v_lshl_add_u32 sgpr", d)}, {"v_bfe_u32 imm", run<29>("v_bfe_u32 imm", d)},
+        {"v_mul_f64 sgpr", run<30>("v_mul_f64 sgpr", d)}, {"v_add_f64 sgpr, dst!=src", run<31>("v_add_f64 sgpr dst!=src", d)},
+        {"v_mul_u32_u24", run<32>("v_mul_u32_u24", d)}, {"v_and_b32 literal", run<33>("v_and_b32 literal", d)},
+        {"v_lshl_or_b32", run<34>("v_lshl_or_b32", d)}, {"v_mov_b32", run<35>("v_mov_b32", d)},
+        {"v_add_u32 sgpr", run<36>("v_add_u32 sgpr", d)}, {"cvt_i32_f64+lshlrev (2)", run<37>("cvt+lshlrev", d)},
+        {"v_fract_f64 dst!=src", run<38>("v_fract_f64 dst!=src", d)}, {"v_ldexp_f64", run<39>("v_ldexp_f64", d)},
+        {"ds_read_b32", run<40>("ds_read_b32", d)}, {"v_sub_u32", run<41>("v_sub_u32", d)}, {"v_xor_b32", run<42>("v_xor_b32", d)},
+        {"add_f64 sgpr + fract (2)", run<43>("add_f64+fract", d)}};
     printf("\nrelative to v_add_u32 (= 1 issue slot):\n");
     printf("  v_add_f64 sgpr   %.2f\n  v_lshl_add_u32   %.2f\n  v_bfe_u32        %.2f\n  v_mul_i32_i24 s  %.2f\n  v_mul_lo_u32     %.2f\n  v_add3_u32       %.2f\n  v_perm_b32       %.2f\n",
            r15 / ref, r16 / ref, r17 / ref, r18 / ref, r19 / ref, r20 / ref, r21 / ref);
     for (int i = 1; i < 15; ++i) printf("  %-16s %.2f\n", names[i], r[i] / ref);
+    for (auto &m : more) printf("  %-26s %.2f\n", m.n, m.v / ref);
     return 0;
 }
