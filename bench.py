@@ -80,6 +80,144 @@ def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
     }
 
 
+def leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp, steps=8):
+    """SURVEY.md 8(d), second timing: the same pass PLUS the device->host copy of the IQ into pinned memory (what a
+    caller that hands over HOST buffers pays; PCIe-inclusive, never the headline).  Double-buffered as in the CLI:
+    the copy of step k runs beside the synthesis of step k+1."""
+    depth = len(engines)
+    host = [torch.empty(outs[0].numel(), dtype=torch.int16, pin_memory=True) for _ in range(depth)]
+    copy_stream = torch.cuda.Stream()
+    copied = [None] * depth
+
+    def run(n):
+        inflight = [False] * depth
+        for k in range(n + depth):
+            j = k % depth
+            if inflight[j]:
+                engines[j].finish()  # IQ final only after finish()
+                copy_stream.wait_stream(streams[j])
+                with torch.cuda.stream(copy_stream):
+                    host[j].copy_(outs[j], non_blocking=True)
+                    copied[j] = torch.cuda.Event()
+                    copied[j].record(copy_stream)
+                inflight[j] = False
+            if k < n:
+                if copied[j] is not None:
+                    copied[j].synchronize()  # the device buffer is free again
+                engines[j].execute(outs[j].data_ptr(), e_first, e_count)
+                inflight[j] = True
+        copy_stream.synchronize()
+
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(e_count * n_samp * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "d2h_GBps": round(4.0 * e_count * n_samp * steps / dt / 1e9, 1), "steps": steps,
+            "what": "execute + finish + copy into pinned host memory, double-buffered (PCIe-inclusive)"}
+
+
+def leg_file_sink(seconds=120):
+    """SURVEY.md 8(d), third timing: the drop-in itself -- the CLI with the reference's option surface on the RINEX
+    scenario of BASELINE configs[0/1] (9 SVs with this navigation file), RINEX parsing, geodesy and I/NAV included,
+    writing the ishort stream to /dev/null and to a tmpfs file."""
+    import re
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "galileo-sdr-sim_amd", "galileo-sdr-sim")
+    nav = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
+    if not (os.path.exists(exe) and os.path.exists(nav)):
+        return None
+    out = {}
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    for name, sink in (("dev_null", "/dev/null"), ("tmpfs_file", os.path.join(tmpdir, "galbench_%d.ishort" % os.getpid()))):
+        try:
+            t0 = time.perf_counter()
+            res = subprocess.run([exe, "-e", nav, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", str(seconds), "-U", "1",
+                                  "-b", "1", "-o", sink], capture_output=True, text=True, timeout=300)
+            wall = time.perf_counter() - t0
+            m = re.search(r"Process time = ([0-9.]+)", res.stderr)
+            n_samples = (int(seconds * 10 + 0.5) - 1) * 260000
+            if res.returncode != 0 or not m:
+                out[name] = {"error": (res.stderr or res.stdout)[-200:]}
+                continue
+            # %.2f of the CLI's own line is too coarse for a 0.1 s run: use its Msamples/s figure
+            m2 = re.search(r"\(([0-9.]+) Msamples/s", res.stderr)
+            out[name] = {"value": float(m2.group(1)) if m2 else round(n_samples / float(m.group(1)) / 1e6, 1), "unit": "Msamples/s",
+                         "process_time_s": float(m.group(1)), "wall_s_incl_startup": round(wall, 3),
+                         "bytes": n_samples * 4}
+        finally:
+            if sink != "/dev/null" and os.path.exists(sink):
+                os.remove(sink)
+    out["what"] = ("galileo-sdr-sim -e 20feb2022.rnx -l -6,51,100 -t 2022/02/20,12:00:00 -d %d -o <sink>: front-end + HIP + D2H + "
+                   "write; value from the CLI's own 'Process time' line (as the reference prints it), wall time includes "
+                   "HIP start-up and pinned allocations" % seconds)
+    return out
+
+
+def leg_config(torch, pkg, workload, epochs, steps, local_rank):
+    """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
+    bounded epoch count), pipelined like the headline."""
+    n_samp, rate, n_slots, n_chan = 260000, 2.6e6, 16, 12
+    if workload == "syn24":
+        n_samp, rate, n_slots, n_chan = 2500000, 25e6, 24, 24
+    params = pkg.shard.rank_workload(0, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate,
+                                     dyn_track=(workload == "dyn"))
+    engines, outs = [], []
+    for _ in range(2):
+        eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank)
+        st = torch.cuda.Stream()
+        eng.set_stream(st.cuda_stream)
+        eng.plan(params)
+        engines.append(eng)
+        outs.append(torch.empty(epochs * n_samp * 2, dtype=torch.int16, device="cuda"))
+
+    def run(n):
+        stats = []
+        for k in range(n + 2):
+            j = k % 2
+            if k >= 2:
+                stats.append(engines[j].finish()[1])
+            if k < n:
+                engines[j].execute(outs[j].data_ptr())
+        return stats
+
+    run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(x["chain_mismatch"] == 0 for x in stats)
+    for e in engines:
+        e.close()
+    value = epochs * n_samp * steps / dt / 1e6
+    return {"value": round(value, 1), "unit": "Msamples/s", "x_realtime": round(value * 1e6 / rate, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "epochs": epochs, "channels": n_chan, "samples_per_epoch": n_samp, "steps": steps,
+            "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3)}
+
+
+def profiled_kernel_ms():
+    """Average k_synth<12,false> duration in the newest committed rocprofv3 --kernel-trace --stats summary of this
+    bench command (profiles/*_bench_kernel_stats.csv); not live: bench.py cannot run rocprofv3 on itself."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.csv")))
+    if not files:
+        return None, None
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            if "k_synth" in r["Name"] and "12" in r["Name"]:
+                return round(float(r["AverageNs"]) / 1e6, 4), os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def measured_traffic():
     """HBM bytes per k_synth launch from the newest committed PMC summary (rocprofv3 --pmc WRITE_SIZE /
     FETCH_SIZE passes, profiles/*_pmc_k_synth.json); None if there is none.  bench.py cannot run
@@ -118,6 +256,8 @@ def main():
                     "headline); 'scenario' = ONE scenario cut into contiguous epoch ranges, every rank walks the whole "
                     "NCO chain and synthesises its own range (strong scaling, no exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-headline legs (kernel + D2H, CLI file "
+                    "sink, M-DYN, M-SYN24) that the default 1-GPU run reports under e2e / configs")
     args = ap.parse_args()
 
     import torch
@@ -217,6 +357,8 @@ def main():
         traffic, traffic_src = measured_traffic() if (args.epochs == 1199 and args.workload == "syn12" and args.channels == 12
                                                           and e_count == args.epochs) else (None, None)
         achieved = 4.0 * samples_per_step / (avg_synth_ms * 1e-3) / 1e9 if avg_synth_ms > 0 else 0.0
+        step_ms = elapsed / args.steps * 1e3
+        prof_ms, prof_src = profiled_kernel_ms() if traffic is not None else (None, None)
         line = {
             "metric": METRIC,
             "value": round(value, 3),
@@ -229,7 +371,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "f64 phase NCO -> int32 accumulate -> int16 IQ",
+            "dtype": "f64 (NCO phases) + int16x2 (packed accumulate) -> int16 IQ",
             "data": "synthetic",
             "config": {
                 "workload": {"syn12": "M-SYN12: static-geometry 12-SV E1B/C", "syn24": "M-SYN24: 24-SV E1B/C",
@@ -251,16 +393,35 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "frac_uses": "avg_kernel_ms: HIP events around k_synth on its stream inside the timed region; with two "
+                             "handles in flight the interval contains the overlap with the other handle's kernel",
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_is_live": False,
                 "avg_kernel_ms": round(avg_synth_ms, 4),
-                "note": "kernel duration inside the pipelined timed region (a walker of the next step co-runs)",
+                "rocprof_avg_kernel_ms": prof_ms,
+                "rocprof_source": prof_src,
+                "rocprof_is_live": False,
+                "step_derived": {"ms": round(step_ms, 4), "achieved": round(4.0 * samples_per_step / (step_ms * 1e-3) / 1e9, 2),
+                                 "frac": round(4.0 * samples_per_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "standalone_kernel_ms": round(solo_ms, 4) if solo_ms else None,
                 "standalone_achieved": round(4.0 * samples_per_step / (solo_ms * 1e-3) / 1e9, 2) if solo_ms else None,
+                "standalone_frac": round(4.0 * samples_per_step / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if solo_ms else None,
                 "avg_walk_ms": round(ms_walk / args.steps, 4),
                 "algorithmic_bytes_per_launch": 4 * samples_per_step,
             },
         }
+        default_run = (world == 1 and args.workload == "syn12" and args.epochs == 1199 and args.channels == 12 and not strong)
+        if default_run and not args.no_extras:
+            # untimed-for-headline legs (kernel-only above, kernel + D2H and the file sink here; configs 3/4)
+            line["e2e"] = {"kernel_plus_d2h": leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp)}
+            for eng in engines:
+                eng.close()
+            del outs[:], out
+            torch.cuda.empty_cache()
+            line["e2e"]["file_sink"] = leg_file_sink()
+            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 6, local_rank),
+                               "syn24": leg_config(torch, pkg, "syn24", 600, 4, local_rank)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
         line["x_realtime"] = round(value * 1e6 / rate, 2)

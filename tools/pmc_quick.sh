@@ -4,8 +4,8 @@ export TMPDIR=/tmp
 tag=$1
 out=gpurun_out/pmcq_$tag
 mkdir -p $out
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $out/p1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline 1 > $out/p1.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/p2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline 1 > $out/p2.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $out/p1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 > $out/p1.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $out/p2 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 > $out/p2.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)

@@ -7,7 +7,7 @@ tag=${1:-rXX}
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline 1"
+cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1"
 i=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
             "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" "WRITE_SIZE" "FETCH_SIZE"; do
