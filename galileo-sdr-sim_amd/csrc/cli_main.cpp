@@ -10,12 +10,14 @@
 // ((int)(10 d + 0.5) - 1) * 260000 * 4 bytes (src/galileo-sdr.cpp:438,536-542); default name
 // galileosim.ishort, "-" = stdout.  Errors print a message and exit(1); success exits 0.
 //
-// Pipeline: host front-end (libgalscen) produces a batch of epochs -> gal_synth_plan/execute on the GPU ->
-// asynchronous copy into one of two pinned buffers -> a writer thread streams it to the sink while the
-// GPU already synthesises the next batch.
+// Pipeline of three threads: a producer runs the host front-end (libgalscen: orbits, ranges, I/NAV pages) up to two
+// batches ahead -> the main thread plans and executes each batch on the GPU and, after gal_synth_finish(), enqueues
+// the copy into one of two pinned buffers -> a writer thread streams full buffers to the sink.  In steady state the
+// run time is that of the slowest stage: the device->host copy for /dev/null, the write for a file.
 #include <hip/hip_runtime.h>
 #include <getopt.h>
 #include <signal.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -25,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -47,8 +50,11 @@ void usage(const char *prog)
            "  -t <date,time>   Scenario start time YYYY/MM/DD,hh:mm:ss\n"
            "  -d <duration>    Duration [sec]\n"
            "  -I <x>           Disable ionospheric delay\n"
+           "  -T <date,time>   Overwrite TOC and TOE to scenario start time (use `now` for the current time)\n"
+           "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (default 7533, 0 = off)\n"
+           "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
            "  -v               Verbose\n"
-           "  -U/-b/-a/-G/-p/-n/-g/-i/-T  accepted for compatibility (file sink only)\n",
+           "  -U/-b/-a/-G/-p/-n/-g/-i     accepted for compatibility (file sink only)\n",
            prog);
 }
 
@@ -76,17 +82,30 @@ int main(int argc, char *argv[])
     sc.duration_s = 300.0;
     sc.iono_enable = 1;
     sc.n_slots = GAL_MAX_CHAN;
-    bool verbose = false;
+    bool verbose = false, have_batch = false, udp_given = false, realtime = false;
     int batch_epochs = 128;
+    sc.udp_port = GAL_SCEN_UDP_PORT;  // the reference always listens for position updates (src/galileo-sdr.cpp:185)
 
     int opt;
-    while ((opt = getopt(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:r")) != -1) {
         switch (opt) {
         case 'e': snprintf(navfile, sizeof(navfile), "%s", optarg); break;
         case 'o': snprintf(outfile, sizeof(outfile), "%s", optarg); break;
         case 'u': snprintf(umfile, sizeof(umfile), "%s", optarg); break;
         case 'l': sscanf(optarg, "%lf,%lf,%lf", &sc.llh[0], &sc.llh[1], &sc.llh[2]); break;
-        case 'T':  // TOC/TOE overwrite is not supported; treated as -t
+        case 'T':  // -t plus: overwrite TOC / TOE so that the file is valid at that time (src/main.cpp:237-257)
+            sc.time_overwrite = 1;
+            if (strncmp(optarg, "now", 3) == 0) {
+                time_t timer;
+                time(&timer);
+                const struct tm *gmt = gmtime(&timer);
+                sc.start[0] = gmt->tm_year + 1900; sc.start[1] = gmt->tm_mon + 1; sc.start[2] = gmt->tm_mday;
+                sc.start[3] = gmt->tm_hour; sc.start[4] = gmt->tm_min;
+                sc.start_sec = (double)gmt->tm_sec;
+                sc.have_start = 1;
+                break;
+            }
+            /* fall through */
         case 't':
             if (sscanf(optarg, "%d/%d/%d,%d:%d:%lf", &sc.start[0], &sc.start[1], &sc.start[2], &sc.start[3],
                        &sc.start[4], &sc.start_sec) != 6) {
@@ -98,7 +117,9 @@ int main(int argc, char *argv[])
         case 'd': sc.duration_s = atof(optarg); break;
         case 'I': sc.iono_enable = 0; break;
         case 'v': verbose = true; break;
-        case 'B': batch_epochs = atoi(optarg); break;
+        case 'B': batch_epochs = atoi(optarg); have_batch = true; break;
+        case 'P': sc.udp_port = atoi(optarg); udp_given = true; break;
+        case 'r': realtime = true; break;
         case 'n': case 'g': case 'G': case 'a': case 'p': case 'i': case 'U': case 'b': break;
         case ':':
         case '?':
@@ -115,13 +136,21 @@ int main(int argc, char *argv[])
         printf("[+] File sink not specified. Using galileosim.ishort\n");
         snprintf(outfile, sizeof(outfile), "galileosim.ishort");
     }
+    if (realtime && !have_batch) batch_epochs = 1;  // paced output: position updates take effect within 0.1 s
     if (batch_epochs < 1) batch_epochs = 1;
     sc.nav_file = navfile;
     sc.motion_file = umfile[0] ? umfile : nullptr;
     sc.verbose = 1;
 
     gal_scen_t *scen = nullptr;
-    if (gal_scen_open(&sc, &scen) != GAL_OK) {
+    int orc = gal_scen_open(&sc, &scen);
+    if (orc == GAL_E_IO && sc.udp_port > 0 && !udp_given && strstr(gal_scen_last_error(), "UDP")) {
+        // the default port is taken (another instance): the reference would exit; carry on without the listener
+        fprintf(stderr, "WARNING: %s; continuing without run-time position updates\n", gal_scen_last_error());
+        sc.udp_port = 0;
+        orc = gal_scen_open(&sc, &scen);
+    }
+    if (orc != GAL_OK) {
         fprintf(stderr, "%s\n", gal_scen_last_error());
         exit(1);
     }
@@ -201,15 +230,58 @@ int main(int argc, char *argv[])
 
     signal(SIGINT, on_sigint);
     const auto t_start = std::chrono::steady_clock::now();
-    std::vector<gal_chan_epoch_t> rows((size_t)batch_epochs * sc.n_slots);
+    // producer: front-end rows, kRowBufs batches deep
+    constexpr int kRowBufs = 3;
+    struct RowBuf {
+        std::vector<gal_chan_epoch_t> rows;
+        int n = 0;  // epochs in it; < 0: front-end error, 0 with `last`: end of the scenario
+        bool ready = false;
+    };
+    RowBuf rb[kRowBufs];
+    for (auto &b : rb) b.rows.resize((size_t)batch_epochs * sc.n_slots);
+    std::mutex rmu;
+    std::condition_variable rcv;
+    bool consumer_gone = false;
+    std::string scen_error;
+    long produced_epochs = 0;
+    std::thread producer([&]() {
+        int w = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(rmu);
+                rcv.wait(lk, [&] { return !rb[w].ready || consumer_gone; });
+                if (consumer_gone) return;
+            }
+            if (realtime) {  // FIFO-style pacing (the reference: src/fifo.cpp + src/galileo-sdr.cpp:570-595): epoch k is
+                             // produced no earlier than k * 0.1 s after the start, so that position updates are current
+                std::this_thread::sleep_until(t_start + std::chrono::milliseconds(100) * produced_epochs);
+            }
+            const int n = g_stop ? 0 : gal_scen_next(scen, batch_epochs, rb[w].rows.data());
+            if (n > 0) produced_epochs += n;
+            {
+                std::lock_guard<std::mutex> lk(rmu);
+                if (n < 0) scen_error = gal_scen_last_error();
+                rb[w].n = n;
+                rb[w].ready = true;
+            }
+            rcv.notify_all();
+            if (n <= 0) return;
+            w = (w + 1) % kRowBufs;
+        }
+    });
     std::vector<gal_chan_state_t> state(sc.n_slots);
     memset(state.data(), 0, sizeof(gal_chan_state_t) * sc.n_slots);
     bool have_state = false;
-    int emitted = 0, cur = 0, rc = 0;
-    while (emitted < total && !g_stop && !io_error) {
-        const int n = gal_scen_next(scen, batch_epochs, rows.data());
+    int emitted = 0, cur = 0, rc = 0, r = 0;
+    while (emitted < total && !io_error) {
+        {
+            std::unique_lock<std::mutex> lk(rmu);
+            rcv.wait(lk, [&] { return rb[r].ready; });
+        }
+        const int n = rb[r].n;
+        const gal_chan_epoch_t *rows_ptr = rb[r].rows.data();
         if (n < 0) {
-            fprintf(stderr, "\nERROR: %s\n", gal_scen_last_error());
+            fprintf(stderr, "\nERROR: %s\n", scen_error.c_str());
             rc = 1;
             break;
         }
@@ -218,12 +290,18 @@ int main(int argc, char *argv[])
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !slot[cur].full; });
         }
-        if (gal_synth_plan(eng, rows.data(), n, have_state ? state.data() : nullptr) != GAL_OK ||
+        if (gal_synth_plan(eng, rows_ptr, n, have_state ? state.data() : nullptr) != GAL_OK ||
             gal_synth_execute(eng, d_iq[cur]) != GAL_OK) {
             fprintf(stderr, "\nERROR: %s\n", gal_synth_last_error());
             rc = 1;
             break;
         }
+        {  // plan() has uploaded the rows: the producer may refill this buffer
+            std::lock_guard<std::mutex> lk(rmu);
+            rb[r].ready = false;
+        }
+        rcv.notify_all();
+        r = (r + 1) % kRowBufs;
         // The IQ in d_iq[cur] is final only once gal_synth_finish() has returned: finish() may find the speculative
         // carrier chain unverified (or the replay check unhappy) and synthesise the batch again.  The copies are
         // therefore enqueued after it; they still run beside the front-end and the synthesis of the next batch.
@@ -258,6 +336,12 @@ int main(int argc, char *argv[])
             fprintf(stderr, "\rTime into run = %4.1f - %4.1f", emitted / 10.0, el);
         }
     }
+    {
+        std::lock_guard<std::mutex> lk(rmu);
+        consumer_gone = true;
+    }
+    rcv.notify_all();
+    producer.join();
     {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return !slot[0].full && !slot[1].full; });

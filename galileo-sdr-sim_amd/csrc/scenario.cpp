@@ -9,6 +9,12 @@
 // The page a channel would install if its symbol counter wraps inside an epoch depends only on that
 // epoch's receive time, the channel's ephemeris and the iono/UTC block (src/galileo-sdr.cpp:502-505),
 // so it is generated here per epoch and shipped in the record (page_next).
+#include <arpa/inet.h>
+#include <fcntl.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -63,12 +69,45 @@ struct gal_scen {
     int current_eph[kMaxSat];
     int allocated[kMaxSat];
     std::vector<Channel> chan;
+    int udp_fd = -1;         // run-time position updates (cfg.udp_port)
+    bool have_live = false;
+    double xyz_live[3];
+    int live_updates = 0;
+
+    ~gal_scen()
+    {
+        if (udp_fd >= 0) close(udp_fd);
+    }
 };
 
 namespace {
 
+// src/galileo-sdr.cpp:443-448: the position of an epoch is whatever the location listener received last
+// (include/socket.h:165-180: 3 doubles lat, lon [deg], height [m] per datagram); polled, never blocking
+void poll_live_position(gal_scen *s)
+{
+    if (s->udp_fd < 0) return;
+    double llh[3];
+    bool got = false;
+    for (;;) {
+        double buf[3];
+        const ssize_t n = recv(s->udp_fd, buf, sizeof(buf), MSG_DONTWAIT);
+        if (n != (ssize_t)sizeof(buf)) break;
+        memcpy(llh, buf, sizeof(llh));
+        got = true;
+    }
+    if (!got) return;
+    if (s->cfg.verbose) fprintf(stdout, "Location Update: %f,%f,%f\n", llh[0], llh[1], llh[2]);
+    llh[0] = llh[0] / kR2D;
+    llh[1] = llh[1] / kR2D;
+    llh_to_ecef(llh, s->xyz_live);
+    s->have_live = true;
+    s->live_updates++;
+}
+
 const double *position(const gal_scen *s, int iumd)
 {
+    if (s->have_live) return s->xyz_live;
     if (!s->motion.empty()) return s->motion[iumd < (int)s->motion.size() ? iumd : (int)s->motion.size() - 1].v;
     return s->xyz0;
 }
@@ -197,6 +236,10 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
         const Ephemeris &e = s->nav.sv[sv][n - 2];
         if (e.valid == 1 && e.toc.sec > gmax.sec) gmax = e.toc;
     }
+    if (cfg->time_overwrite && !cfg->have_start) {
+        delete s;
+        return scen_fail(GAL_E_INVAL, "time_overwrite (-T) needs a start time");
+    }
     if (cfg->have_start) {
         CalTime t0;
         t0.y = cfg->start[0]; t0.m = cfg->start[1]; t0.d = cfg->start[2];
@@ -209,7 +252,23 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
         }
         t0.sec = floor(t0.sec);
         cal_to_gal(t0, &s->g0);
-        if (gal_diff(s->g0, gmin) < 0.0 || gal_diff(gmax, s->g0) < 0.0) {
+        if (cfg->time_overwrite) {
+            // src/gnss-time.cpp:105-137.  (The reference walks its per-satellite vectors with the two indices
+            // swapped and so runs off their ends; what it sets out to do -- and what gps-sdr-sim, its ancestor,
+            // does -- is shift EVERY record, which is what happens here.)
+            GalTime gt;
+            gt.week = s->g0.week;
+            gt.sec = (double)(((int)(s->g0.sec)) / 7200) * 7200.0;
+            const double dsec = gal_diff(gt, gmin);
+            s->nav.iono.wnt = gt.week;
+            s->nav.iono.tot = (int)gt.sec;
+            for (int sv = 0; sv < kMaxSat; ++sv)
+                for (Ephemeris &e : s->nav.sv[sv])
+                    if (e.valid == 1) {
+                        e.toc.sec = e.toc.sec + dsec;  // incGalTime: seconds only, the week is left alone
+                        e.toe.sec = e.toe.sec + dsec;
+                    }
+        } else if (gal_diff(s->g0, gmin) < 0.0 || gal_diff(gmax, s->g0) < 0.0) {
             CalTime a, b;
             gal_to_cal(gmin, &a);
             gal_to_cal(gmax, &b);
@@ -235,6 +294,20 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
     allocate_channels(s, s->grx, s->xyz0);
     s->grx.sec = s->grx.sec + kEpochDt;
     s->iumd = 1;
+    if (cfg->udp_port > 0) {
+        s->udp_fd = socket(AF_INET, SOCK_DGRAM, 0);
+        struct sockaddr_in addr;
+        memset(&addr, 0, sizeof(addr));
+        addr.sin_family = AF_INET;
+        addr.sin_port = htons((uint16_t)cfg->udp_port);
+        addr.sin_addr.s_addr = INADDR_ANY;
+        if (s->udp_fd < 0 || bind(s->udp_fd, (struct sockaddr *)&addr, sizeof(addr)) < 0) {
+            const int port = cfg->udp_port;
+            delete s;
+            return scen_fail(GAL_E_IO, "cannot listen for position updates on UDP port %d (the reference exits here too: "
+                                       "one instance per port)", port);
+        }
+    }
     *out = s;
     return GAL_OK;
 }
@@ -257,6 +330,7 @@ int32_t gal_scen_next(gal_scen_t *s, int32_t max_epochs, gal_chan_epoch_t *rows)
     while (produced < max_epochs && s->iumd < s->numd) {
         gal_chan_epoch_t *row = rows + (size_t)produced * S;
         memset(row, 0, sizeof(gal_chan_epoch_t) * S);
+        poll_live_position(s);
         const double *xyz = position(s, s->iumd);
         for (int i = 0; i < S; ++i) {
             Channel &c = s->chan[i];

@@ -38,7 +38,9 @@ class _Cfg(ctypes.Structure):
         ("iono_enable", ctypes.c_int32),
         ("n_slots", ctypes.c_int32),
         ("verbose", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("time_overwrite", ctypes.c_int32),
+        ("udp_port", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -94,7 +96,7 @@ class Scenario:
     """Sequential producer of [n_epochs, n_slots] gal_chan_epoch_t rows."""
 
     def __init__(self, nav_file, llh=(42.3601, -71.0589, 2.0), start=None, duration_s=300.0, iono_enable=True,
-                 n_slots=16, motion_file=None, verbose=False):
+                 n_slots=16, motion_file=None, verbose=False, time_overwrite=False, udp_port=0):
         self._lib = load_library()
         cfg = _Cfg()
         cfg.nav_file = os.fsencode(nav_file)
@@ -109,6 +111,8 @@ class Scenario:
         cfg.iono_enable = 1 if iono_enable else 0
         cfg.n_slots = int(n_slots)
         cfg.verbose = 1 if verbose else 0
+        cfg.time_overwrite = 1 if time_overwrite else 0
+        cfg.udp_port = int(udp_port)
         self._keep = cfg
         self._h = ctypes.c_void_p()
         rc = self._lib.gal_scen_open(ctypes.byref(cfg), ctypes.byref(self._h))

@@ -32,8 +32,15 @@ typedef struct gal_scen_cfg {
     int32_t iono_enable;      /* 0 with -I (src/main.cpp:300); 1 = the obliquity model the reference build runs */
     int32_t n_slots;          /* channel slots per row; reference MAX_CHAN = 16                              */
     int32_t verbose;          /* print the reference's allocation lines to stderr (src/channel.cpp:101)      */
-    int32_t reserved[4];
+    int32_t time_overwrite;   /* -T : shift TOC / TOE of every ephemeris record (and the UTC reference time) so that
+                                 the file becomes valid at the requested start (src/gnss-time.cpp:105-137)          */
+    int32_t udp_port;         /* > 0: listen on this UDP port for run-time position updates, 3 doubles lat [deg],
+                                 lon [deg], height [m] per datagram -- the reference's locations_thread on port 7533
+                                 (include/socket.h:165-180), read once per epoch (src/galileo-sdr.cpp:443-448)      */
+    int32_t reserved[2];
 } gal_scen_cfg_t;
+
+#define GAL_SCEN_UDP_PORT 7533 /* the reference's port (include/socket.h:169) */
 
 typedef struct gal_scen gal_scen_t;
 
