@@ -267,6 +267,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the synthesis engine has no CPU fallback")
+    # GAL_BENCH_DEVICE / GAL_BENCH_BACKEND: rehearsal of the N > 1 launch path on a box with ONE GPU (every rank on the
+    # same device, gloo instead of RCCL for the barrier and the report reductions) -- exercises rank_workload /
+    # epoch_range / reduce_report / gal_synth_execute_range together on real hardware; says nothing about scaling
+    if os.environ.get("GAL_BENCH_DEVICE"):
+        local_rank = int(os.environ["GAL_BENCH_DEVICE"])
+    backend = os.environ.get("GAL_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -275,7 +281,10 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from __graft_entry__ import load_pkg
 
@@ -349,7 +358,8 @@ def main():
     v32 = out.view(torch.int32)
     for a in range(0, v32.numel(), 1 << 28):  # in pieces: the int64 widening of a 60 GB output is 120 GB
         chk = (chk + int(v32[a:a + (1 << 28)].to(torch.int64).sum().item())) & 0xFFFFFFFF
-    elapsed, total_samples, chk = pkg.shard.reduce_report(dist, "cuda", elapsed, samples_per_step * args.steps, chk)
+    elapsed, total_samples, chk = pkg.shard.reduce_report(dist, "cuda" if backend == "nccl" else "cpu", elapsed,
+                                                          samples_per_step * args.steps, chk)
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
@@ -365,6 +375,8 @@ def main():
             "unit": "Msamples/s",
             "x_realtime": round(value / 2.6, 2),
             "n_gpus": world,
+            **({"rehearsal": "all %d ranks on GPU %d, backend %s: launch-path check, NOT a scaling measurement" % (
+                world, local_rank, backend)} if os.environ.get("GAL_BENCH_DEVICE") and world > 1 else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -44,3 +44,46 @@ def test_cli_stdout_sink():
                         "-"], capture_output=True)
     assert r.returncode == 0
     assert hashlib.md5(r.stdout).hexdigest() == REF["G1"]["md5"]
+
+
+@pytest.mark.gpu
+def test_cli_realtime_pacing_and_live_position(tmp_path):
+    """-r paces the output to real time (the reference's FIFO hand-over, src/fifo.cpp, src/galileo-sdr.cpp:570-595);
+    a position datagram on the -P port moves the receiver for the epochs that follow (include/socket.h:165-180).
+    Which epoch sees the update depends on wall-clock time, so only the frame of the result is checked exactly: the
+    epochs before the update are the static scenario's, the tail is not, the length is unchanged."""
+    import socket
+    import struct
+    import threading
+    import time
+
+    import numpy as np
+
+    s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    static = tmp_path / "static.ishort"
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "3", "-P", "0", "-o", str(static)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def send_later():
+        time.sleep(1.5)
+        tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        tx.sendto(struct.pack("<3d", -6.01, 51.01, 400.0), ("127.0.0.1", port))
+
+    live = tmp_path / "live.ishort"
+    th = threading.Thread(target=send_later)
+    t0 = time.perf_counter()
+    th.start()
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "3", "-r", "-P", str(port), "-o",
+                        str(live)], capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    th.join()
+    assert r.returncode == 0, r.stderr
+    assert wall >= 2.7  # 29 epochs of 0.1 s, paced
+    a = np.fromfile(str(static), dtype=np.int16).reshape(29, -1)
+    b = np.fromfile(str(live), dtype=np.int16).reshape(29, -1)
+    same = [bool(np.array_equal(a[e], b[e])) for e in range(29)]
+    assert all(same[:8]) and not any(same[-5:]), same
