@@ -53,6 +53,7 @@ void usage(const char *prog)
            "  -T <date,time>   Overwrite TOC and TOE to scenario start time (use `now` for the current time)\n"
            "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (default 7533, 0 = off)\n"
            "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
+           "  -C               CBOC(6,1,1/11) sub-carrier of the E1 OS ICD instead of the reference's BOC(1,1) (opt-in)\n"
            "  -v               Verbose\n"
            "  -U/-b/-a/-G/-p/-n/-g/-i     accepted for compatibility (file sink only)\n",
            prog);
@@ -82,12 +83,12 @@ int main(int argc, char *argv[])
     sc.duration_s = 300.0;
     sc.iono_enable = 1;
     sc.n_slots = GAL_MAX_CHAN;
-    bool verbose = false, have_batch = false, udp_given = false, realtime = false;
+    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false;
     int batch_epochs = 128;
     sc.udp_port = GAL_SCEN_UDP_PORT;  // the reference always listens for position updates (src/galileo-sdr.cpp:185)
 
     int opt;
-    while ((opt = getopt(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:r")) != -1) {
+    while ((opt = getopt(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC")) != -1) {
         switch (opt) {
         case 'e': snprintf(navfile, sizeof(navfile), "%s", optarg); break;
         case 'o': snprintf(outfile, sizeof(outfile), "%s", optarg); break;
@@ -120,6 +121,7 @@ int main(int argc, char *argv[])
         case 'B': batch_epochs = atoi(optarg); have_batch = true; break;
         case 'P': sc.udp_port = atoi(optarg); udp_given = true; break;
         case 'r': realtime = true; break;
+        case 'C': cboc = true; break;
         case 'n': case 'g': case 'G': case 'a': case 'p': case 'i': case 'U': case 'b': break;
         case ':':
         case '?':
@@ -176,6 +178,7 @@ int main(int argc, char *argv[])
     cfg.samples_per_epoch = 260000;
     cfg.n_slots = sc.n_slots;
     cfg.device = getenv("GAL_DEVICE") ? atoi(getenv("GAL_DEVICE")) : -1;
+    if (cboc) cfg.flags |= GAL_CFG_CBOC;
     gal_synth_t *eng = nullptr;
     if (gal_synth_create(&cfg, &eng) != GAL_OK) {
         fprintf(stderr, "ERROR: %s\n", gal_synth_last_error());

@@ -209,7 +209,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
                       hipHostMallocDefault) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
 
-    if (hipMalloc((void **)&h->d_lut, 512 * sizeof(int)) != hipSuccess ||
+    if (hipMalloc((void **)&h->d_lut, 2 * 512 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_str, 50 * 512 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&h->d_plan, sizeof(DevPlan)) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "table allocation failed"));
@@ -227,11 +227,22 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         if (hipMemcpy(h->d_str, str.data(), str.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(GAL_E_DEVICE, "table upload failed"));
     }
-    int lut[512];
+    int lut[2 * 512];
     // v = E1B d - E1C s is 0 or +-2 (src/galileo-sdr.cpp:520-525): the factor 2 lives in the table, the kernel
     // multiplies by v / 2.  Entry = the int16 pair (2 cos, 2 sin), low half first: the layout of an output sample.
-    for (int k = 0; k < 512; ++k)
-        lut[k] = (int)(((uint32_t)(uint16_t)(int16_t)(2 * g_sin[k]) << 16) | (uint32_t)(uint16_t)(int16_t)(2 * g_cos[k]));
+    auto pair = [](int c, int s) {
+        return (int)(((uint32_t)(uint16_t)(int16_t)(2 * s) << 16) | (uint32_t)(uint16_t)(int16_t)(2 * c));
+    };
+    if (cfg->flags & GAL_CFG_CBOC) {
+        // CBOC(6,1,1/11): TA = lround(alpha LUT), TB = lround(beta LUT) (the same expressions as the oracle's)
+        const double alpha = std::sqrt(10.0 / 11.0), beta = std::sqrt(1.0 / 11.0);
+        for (int k = 0; k < 512; ++k) {
+            lut[k] = pair((int)std::lround(alpha * (double)g_cos[k]), (int)std::lround(alpha * (double)g_sin[k]));
+            lut[512 + k] = pair((int)std::lround(beta * (double)g_cos[k]), (int)std::lround(beta * (double)g_sin[k]));
+        }
+    } else {
+        for (int k = 0; k < 512; ++k) lut[k] = lut[512 + k] = pair(g_cos[k], g_sin[k]);
+    }
     if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     *out = h;
@@ -480,6 +491,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.ctr = (int *)(base + o_ctr);
 
     P.lut = h->d_lut; P.str = h->d_str;
+    P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
 
     // ---- upload (synchronous: after plan() the batch is resident in HBM).  A start phase of -0.0 is
     // canonicalised to +0.0 (see carr_step in nco_walk.h).

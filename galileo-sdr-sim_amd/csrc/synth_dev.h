@@ -70,7 +70,8 @@ struct DevPlan {
     int *ctr;  // [CTR_COUNT]
 
     // tables
-    const int *lut;       // [512] int16 pairs (2 cos, 2 sin), low half first
+    const int *lut;       // [512] int16 pairs (2 cos, 2 sin), low half first; CBOC: [2][512] = 2 TA, 2 TB
+    int signal;           // 0 BOC(1,1) (the reference), 1 CBOC(6,1,1/11) (GAL_CFG_CBOC)
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 

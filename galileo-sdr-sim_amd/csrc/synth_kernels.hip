@@ -958,17 +958,54 @@ __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, cons
     }
 }
 
+// ---- CBOC(6,1,1/11), opt-in (GAL_CFG_CBOC).  The E1 OS ICD's composite sub-carrier
+//     e_B (alpha sc_A + beta sc_B) - e_C (alpha sc_A - beta sc_B),   alpha = sqrt(10/11), beta = sqrt(1/11),
+// discretised the way the reference discretises its BOC(1,1) (src/gal-sig.cpp:198-213: the first half of a
+// sub-carrier period is negative): sc_A from (int)(2 x), sc_B from (int)(12 x).  With B = E1B chip x data and
+// C = E1C chip x secondary, exactly one of (B - C), (B + C) is non-zero per sample, so a channel contributes
+//     sc_A (B - C) TA[k]   or   sc_B (B + C) TB[k],      TA = lround(alpha LUT), TB = lround(beta LUT)
+// -- integer arithmetic like the reference's (:520-525); the reference itself has no CBOC, the oracle's CBOC mode
+// (oracle/galsyn_oracle.c) is the definition this is bit-exact against.  One plain per-sample loop, no windows:
+// about 3.5x the instructions of the BOC(1,1) path.  lutb: LDS byte address of entry k = 0 of the channel's A table
+// (plain or conjugate); the B tables follow 8 KB later.
+template <int J>
+__device__ __forceinline__ void chan_step_cboc(ChanState &c, const double cs2, const double ds, const uint32_t lutb,
+                                               const uint32_t str0, const DevPlan *Pd, const int idx, int &acc)
+{
+    if (c.y >= 8184.0) {  // :491-507, checked before use
+        c.y = c.y - 8184.0;
+        c.st = sym_state(Pd, idx, (int)(c.st & 0x1ffu) + 1, (int)((c.st >> 9) & 1u));
+    }
+    const int h = (int)c.y;           // half chip = (int)(2 x)
+    const int i12 = (int)(6.0 * c.y);  // BOC(6,1) half period = (int)(12 x): 6 y and 12 x are the same real number
+    // (str0: LDS byte address of the stream rows)
+    const uint32_t w = *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)(str0 + (uint32_t)(J * STR_PITCH + (h >> 4)) * 4u);
+    // stream field of half chip h: bit0 = E1B ^ E1C chip, bit1 = E1C chip ^ (h & 1); sg = (data ^ sec) | sec << 1
+    const uint32_t f = ((w >> ((h & 15) * 2)) ^ (c.st >> 10)) & 3u;
+    const uint32_t nz = f & 1u;  // B != C: the (B - C) term, else the (B + C) term
+    const uint32_t sign = nz ? (f >> 1) : ((f >> 1) ^ 1u ^ ((uint32_t)(h ^ i12) & 1u));
+    const int k = (int)(511.0 * c.p);
+    const uint32_t a = lutb + (nz ? 0u : 8192u) + (uint32_t)(k << 2);
+    const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
+    gal_acc(acc, t, sign ? -1 : 1);
+    c.y = c.y + cs2;
+    c.p = carr_step(c.p, __builtin_fabs(ds));
+}
+
 #define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define GAL_MAX_NCH 12
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
-template <int NCH, bool ACC>
+// SIG: 0 = BOC(1,1) as the reference generates it, 1 = CBOC(6,1,1/11) (see chan_step_cboc)
+template <int NCH, bool ACC, int SIG = 0>
 __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_WAVES))) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
                                                      const uint8_t *__restrict__ act_all,
                                                      const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
 {
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
     __shared__ uint32_t s_str[NCH * STR_PITCH];
-    __shared__ int s_lut[2 * 1024];  // entry k + 512 of table 0: LUT[k & 511], of table 1: LUT[-k & 511]
+    // entry k + 512 of table 0: LUT[k & 511], of table 1: LUT[-k & 511]; CBOC: the same pair for TA, then for TB
+    constexpr int LUT_TABLES = SIG == 1 ? 4 : 2;
+    __shared__ int s_lut[LUT_TABLES * 1024];
 
     const int er = blockIdx.x / G.blocks_per_epoch;  // epoch relative to the executed range
     const int tg = blockIdx.x - er * G.blocks_per_epoch;
@@ -1002,7 +1039,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // ---- phase 1: LDS tables.  Per thread 2 stream words per channel + 8 LUT entries, all loads first, then the stores
     {
         uint32_t w0[NCH], w1[NCH];
-        int lv[2 * 1024 / SYN_BLOCK];
+        int lv[LUT_TABLES * 1024 / SYN_BLOCK];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             int prn = p_prn[ixs[j]];
@@ -1012,10 +1049,10 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             w1[j] = src[tid + SYN_BLOCK];
         }
 #pragma unroll
-        for (int q = 0; q < 2 * 1024 / SYN_BLOCK; ++q) {
+        for (int q = 0; q < LUT_TABLES * 1024 / SYN_BLOCK; ++q) {
             const int i = tid + q * SYN_BLOCK;
             const int k = (i & 1023) - 512;
-            lv[q] = p_lut[((i >> 10) ? -k : k) & 511];
+            lv[q] = p_lut[((i >> 11) << 9) + ((((i >> 10) & 1) ? -k : k) & 511)];
         }
         // idle positions (epochs with fewer than NCH active channels) run the same branch-free group code on an
         // all-zero state and an all-zero stream: window 0 -> every field 0 -> no contribution; steps 0 keep the state
@@ -1028,7 +1065,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             if (tid == 0) s_str[j * STR_PITCH + STR_WORDS] = on ? w0[j] : 0u;  // pad word = word 0
         }
 #pragma unroll
-        for (int q = 0; q < 2 * 1024 / SYN_BLOCK; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
+        for (int q = 0; q < LUT_TABLES * 1024 / SYN_BLOCK; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
     }
     __syncthreads();
 
@@ -1106,6 +1143,54 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     }
     GAL_CH_LIST(GAL_DECL)
 #undef GAL_DECL
+    // LDS byte address of s_lut[512] (entry k = 0 of the plain table), wave-uniform
+    typedef const __attribute__((address_space(3))) int *lds_int_ptr;
+    // (cast first, offset second: the generic-pointer offset in between is not always folded away by the compiler)
+    const uint32_t lut0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)s_lut + 512u * 4u);
+    uint32_t *out = iq + (size_t)er * G.N + n0;  // iq holds the executed range only
+    // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
+    // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
+    // bursts at 1.2x: tools/wrcal.hip, DESIGN.md §5).
+    const bool vec_ok = ((((size_t)er * G.N + n0) & 15) == 0);
+
+    if constexpr (SIG == 1) {
+        // ---- CBOC: plain per-sample loop, four samples per 16-byte store
+#define GAL_SGN4(j) [[maybe_unused]] const uint32_t sg4##j = lut0 + (((uint32_t)(d2u(ds##j) >> 32) >> 31) << 12);
+        GAL_CH_LIST(GAL_SGN4)
+#undef GAL_SGN4
+        typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+        const uint32_t str0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32_ptr)s_str);
+#define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j>(ch##j, cs##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
+        int s0 = 0;
+        for (; s0 + 4 <= nsteps; s0 += 4) {
+            int o[4];
+            if (ACC) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = (int)out[s0 + u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int acc = o[u];
+                GAL_CH_LIST(GAL_STEP_C)
+                o[u] = acc;
+            }
+            if (vec_ok && ((s0 & 3) == 0)) {
+                *reinterpret_cast<uint4 *>(out + s0) = make_uint4((uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) out[s0 + u] = (uint32_t)o[u];
+            }
+        }
+        for (; s0 < nsteps; ++s0) {
+            int acc = ACC ? (int)out[s0] : 0;
+            GAL_CH_LIST(GAL_STEP_C)
+            out[s0] = (uint32_t)acc;
+        }
+#undef GAL_STEP_C
+    } else {
     // one threshold for all channels: y below it cannot reach the wrap within 16 samples (the code rates of
     // the channels differ by parts per million, so the largest step serves all)
     double csmax = 0.0;
@@ -1124,15 +1209,6 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #define GAL_SF_DECL(j) [[maybe_unused]] int sf##j = 0;
     GAL_CH_LIST(GAL_SF_DECL)
 #undef GAL_SF_DECL
-
-    // LDS byte address of s_lut[512] (entry k = 0 of the plain table), wave-uniform
-    typedef const __attribute__((address_space(3))) int *lds_int_ptr;
-    const uint32_t lut0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)(s_lut + 512));
-    uint32_t *out = iq + (size_t)er * G.N + n0;  // iq holds the executed range only
-    // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
-    // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
-    // bursts at 1.2x: tools/wrcal.hip, DESIGN.md §5).
-    const bool vec_ok = ((((size_t)er * G.N + n0) & 15) == 0);
 
 // (no `j < nact` tests inside the group loop: see the zero-filled stream rows above)
 #define GAL_ROOM(j) if (j < NCH) { const double r = thr2 - ch##j.y; room = r < room ? r : room; negp |= (int)GAL_HI(ch##j.p); }
@@ -1255,6 +1331,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_STEP_S
 #undef GAL_END
 
+    }  // SIG == 0
+
     // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit (all loads first).
     {
         const double *const q_cpx = Pd->cp_x, *const q_cpp = Pd->cp_p;
@@ -1340,7 +1418,7 @@ extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
     hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(64), 0, st, *P);
 }
 
-template <bool ACC>
+template <bool ACC, int SIG>
 static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact,
                           uint32_t *iq, int e0, int ne, hipStream_t st)
 {
@@ -1351,7 +1429,7 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     G.cls = P->cls > 0 ? P->cls : 1;
     G.per = P->nchunks / G.cls;
     switch (nch) {
-#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq); break;
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC, SIG>), grid, block, 0, st, Pd, G, act, nact, iq); break;
         GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
         GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
 #undef GAL_CASE
@@ -1363,6 +1441,9 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
 extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
                                  const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st)
 {
-    return accumulate ? launch_synth_t<true>(P, Pd, nch, act, nact, iq, e0, ne, st)
-                      : launch_synth_t<false>(P, Pd, nch, act, nact, iq, e0, ne, st);
+    if (P->signal == 1)
+        return accumulate ? launch_synth_t<true, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
+                          : launch_synth_t<false, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
+    return accumulate ? launch_synth_t<true, 0>(P, Pd, nch, act, nact, iq, e0, ne, st)
+                      : launch_synth_t<false, 0>(P, Pd, nch, act, nact, iq, e0, ne, st);
 }

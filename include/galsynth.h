@@ -84,6 +84,11 @@ typedef struct gal_synth_cfg {
 } gal_synth_cfg_t;
 
 /* gal_synth_cfg_t.flags */
+#define GAL_CFG_CBOC 2u          /* opt-in: CBOC(6,1,1/11) composite sub-carrier of the E1 OS ICD instead of the BOC(1,1)
+                                    the reference generates (src/gal-sig.cpp:198-233).  The reference has no such
+                                    mode: the definition (integer tables TA = lround(sqrt(10/11) LUT), TB =
+                                    lround(sqrt(1/11) LUT), sub-carriers from (int)(2 x) and (int)(12 x)) is
+                                    oracle/galsyn_oracle.c's CBOC mode, against which the GPU path is bit-exact      */
 #define GAL_CFG_SINGLE_STREAM 1u /* enqueue every kernel on the handle's stream (no internal high-priority walker
                                     streams): for callers that capture or serialise the stream themselves       */
 

@@ -20,6 +20,7 @@
  * `-l -6,51,100 -t 2022/02/20,12:00:00 -d 10 -I 1`): tests/test_golden_scenarios.py feeds this oracle with the
  * host front-end's parameters for that scenario and requires the same md5.
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +45,10 @@ typedef struct {
 static int o_cos[512], o_sin[512];
 static char o_cs25[25];
 static int o_tables_ready = 0;
+/* CBOC(6,1,1/11) opt-in mode (NOT in the reference, which generates BOC(1,1) only, src/gal-sig.cpp:198-233):
+ * integer carrier tables scaled by alpha = sqrt(10/11) and beta = sqrt(1/11) of the E1 OS ICD's composite
+ * sub-carrier, so that the accumulation stays integer like the reference's (src/galileo-sdr.cpp:520-525). */
+static int o_cosA[512], o_sinA[512], o_cosB[512], o_sinB[512];
 
 static void o_init_tables(void)
 {
@@ -58,6 +63,15 @@ static void o_init_tables(void)
     }
     for (k = 0; k < 512; k++) o_sin[k] = o_cos[(k - 128) & 511];
     for (k = 0; k < 25; k++) o_cs25[k] = (char)((kCS25 >> k) & 1u);
+    {
+        const double alpha = sqrt(10.0 / 11.0), beta = sqrt(1.0 / 11.0);
+        for (k = 0; k < 512; k++) {
+            o_cosA[k] = (int)lround(alpha * (double)o_cos[k]);
+            o_sinA[k] = (int)lround(alpha * (double)o_sin[k]);
+            o_cosB[k] = (int)lround(beta * (double)o_cos[k]);
+            o_sinB[k] = (int)lround(beta * (double)o_sin[k]);
+        }
+    }
     o_tables_ready = 1;
 }
 
@@ -97,10 +111,13 @@ static long o_get_nanos(void)
 /*
  * Returns 0, or -1 on a malformed batch.  clock_read != 0 reproduces the reference's per-sample
  * get_nanos() (src/galileo-sdr.cpp:485) for the timed CPU baseline.
+ * signal: 0 = BOC(1,1), the reference's loop, statement for statement; 1 = CBOC(6,1,1/11), see o_cosA above.  Always
+ * called with a literal, so that each mode is compiled as its own loop.
  */
-int gal_oracle_run(const gal_chan_epoch_t *params, int n_epochs, int n_slots, int samples_per_epoch,
-                   double sample_rate, const gal_chan_state_t *state_in, int16_t *iq_out,
-                   gal_chan_state_t *state_out, int clock_read)
+static inline __attribute__((always_inline)) int o_run(const gal_chan_epoch_t *params, int n_epochs, int n_slots,
+                                                       int samples_per_epoch, double sample_rate,
+                                                       const gal_chan_state_t *state_in, int16_t *iq_out,
+                                                       gal_chan_state_t *state_out, int clock_read, const int signal)
 {
     ochan_t *chan;
     int e, i, isamp;
@@ -174,8 +191,21 @@ int gal_oracle_run(const gal_chan_epoch_t *params, int n_epochs, int n_slots, in
                     databit = chan[i].page[chan[i].ibit] > 0 ? -1 : 1;
                     secCode = o_cs25[chan[i].ibit % 25] > 0 ? -1 : 1;
 
+                    if (signal == 0) {
                     ip = (E1B_chip * databit - E1C_chip * secCode) * cosPh;
                     qp = (E1B_chip * databit - E1C_chip * secCode) * sinPh;
+                    } else {
+                        /* E1 OS ICD: e_B (alpha sc_A + beta sc_B) - e_C (alpha sc_A - beta sc_B).  The expanded code
+                         * arrays already carry sc_A = (icode odd ? +1 : -1) (sboc); sc_B is discretised the same way
+                         * from (int)(12 x): first half of a BOC(6,1) period negative.  sc_A sc_B turns a value that
+                         * carries sc_A into one that carries sc_B. */
+                        const int k = ((int)(511 * chan[i].carr_phase)) & 511;
+                        const int i12 = (int)(chan[i].code_phase * 12.0);
+                        const int ab = ((icode ^ i12) & 1) ? -1 : 1;            /* sc_A * sc_B */
+                        const int Ba = E1B_chip * databit, Ca = E1C_chip * secCode; /* with sc_A */
+                        ip = (Ba - Ca) * o_cosA[k] + ab * (Ba + Ca) * o_cosB[k];
+                        qp = (Ba - Ca) * o_sinA[k] + ab * (Ba + Ca) * o_sinB[k];
+                    }
 
                     i_acc += ip;
                     q_acc += qp;
@@ -204,6 +234,30 @@ int gal_oracle_run(const gal_chan_epoch_t *params, int n_epochs, int n_slots, in
     (void)sink;
     free(chan);
     return 0;
+}
+
+int gal_oracle_run(const gal_chan_epoch_t *params, int n_epochs, int n_slots, int samples_per_epoch,
+                   double sample_rate, const gal_chan_state_t *state_in, int16_t *iq_out,
+                   gal_chan_state_t *state_out, int clock_read)
+{
+    return o_run(params, n_epochs, n_slots, samples_per_epoch, sample_rate, state_in, iq_out, state_out, clock_read, 0);
+}
+
+/* The CBOC(6,1,1/11) opt-in mode of the engine (GAL_CFG_CBOC): defined HERE, not by the reference. */
+int gal_oracle_run_cboc(const gal_chan_epoch_t *params, int n_epochs, int n_slots, int samples_per_epoch,
+                        double sample_rate, const gal_chan_state_t *state_in, int16_t *iq_out,
+                        gal_chan_state_t *state_out)
+{
+    return o_run(params, n_epochs, n_slots, samples_per_epoch, sample_rate, state_in, iq_out, state_out, 0, 1);
+}
+
+void gal_oracle_cboc_tables(int *cosA, int *sinA, int *cosB, int *sinB)
+{
+    o_init_tables();
+    memcpy(cosA, o_cosA, sizeof(o_cosA));
+    memcpy(sinA, o_sinA, sizeof(o_sinA));
+    memcpy(cosB, o_cosB, sizeof(o_cosB));
+    memcpy(sinB, o_sinB, sizeof(o_sinB));
 }
 
 /* Expanded tables, for checking against oracle/_ref's dump of the reference header. */

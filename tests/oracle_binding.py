@@ -22,6 +22,10 @@ def oracle_lib():
         lib.gal_oracle_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         lib.gal_oracle_run.restype = ctypes.c_int
+        lib.gal_oracle_run_cboc.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.gal_oracle_run_cboc.restype = ctypes.c_int
+        lib.gal_oracle_cboc_tables.argtypes = [ctypes.c_void_p] * 4
         lib.gal_oracle_tables.argtypes = [ctypes.c_void_p] * 3
         lib.gal_oracle_codegen.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         _lib = lib
@@ -36,18 +40,24 @@ def _dtypes():
     return pkg.CHAN_EPOCH_DTYPE, pkg.CHAN_STATE_DTYPE
 
 
-def oracle_run(params, samples_per_epoch, sample_rate, state_in=None, clock_read=False):
+def oracle_run(params, samples_per_epoch, sample_rate, state_in=None, clock_read=False, cboc=False):
     """CPU restatement of reference src/galileo-sdr.cpp:481-539 over [n_epochs, n_slots] records.
-    Returns (iq int16 [n_epochs*N*2], state_out)."""
+    Returns (iq int16 [n_epochs*N*2], state_out).  cboc=True: the CBOC(6,1,1/11) opt-in mode, which the reference
+    does not have (defined by the oracle itself)."""
     ep_dt, st_dt = _dtypes()
     p = np.ascontiguousarray(params, dtype=ep_dt)
     n_epochs, n_slots = p.shape
     iq = np.zeros(n_epochs * samples_per_epoch * 2, dtype=np.int16)
     st_out = np.zeros(n_slots, dtype=st_dt)
     st_in = None if state_in is None else np.ascontiguousarray(state_in, dtype=st_dt)
-    rc = oracle_lib().gal_oracle_run(p.ctypes.data, n_epochs, n_slots, samples_per_epoch, float(sample_rate),
-                                     st_in.ctypes.data if st_in is not None else None, iq.ctypes.data,
-                                     st_out.ctypes.data, int(bool(clock_read)))
+    if cboc:
+        rc = oracle_lib().gal_oracle_run_cboc(p.ctypes.data, n_epochs, n_slots, samples_per_epoch, float(sample_rate),
+                                              st_in.ctypes.data if st_in is not None else None, iq.ctypes.data,
+                                              st_out.ctypes.data)
+    else:
+        rc = oracle_lib().gal_oracle_run(p.ctypes.data, n_epochs, n_slots, samples_per_epoch, float(sample_rate),
+                                         st_in.ctypes.data if st_in is not None else None, iq.ctypes.data,
+                                         st_out.ctypes.data, int(bool(clock_read)))
     if rc != 0:
         raise RuntimeError("oracle rejected the batch (rc=%d)" % rc)
     return iq, st_out
@@ -59,6 +69,12 @@ def oracle_tables():
     cs = np.zeros(25, dtype=np.int8)
     oracle_lib().gal_oracle_tables(cos.ctypes.data, sin.ctypes.data, cs.ctypes.data)
     return cos, sin, cs
+
+
+def oracle_cboc_tables():
+    t = [np.zeros(512, dtype=np.int32) for _ in range(4)]
+    oracle_lib().gal_oracle_cboc_tables(*[x.ctypes.data for x in t])
+    return t
 
 
 def oracle_codegen(prn, e1c):
