@@ -964,8 +964,8 @@ __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, cons
 // sub-carrier period is negative): sc_A from (int)(2 x), sc_B from (int)(12 x).  With B = E1B chip x data and
 // C = E1C chip x secondary, exactly one of (B - C), (B + C) is non-zero per sample, so a channel contributes
 //     sc_A (B - C) TA[k]   or   sc_B (B + C) TB[k],      TA = lround(alpha LUT), TB = lround(beta LUT)
-// -- integer arithmetic like the reference's (:520-525); the reference itself has no CBOC, the oracle's CBOC mode
-// (oracle/galsyn_oracle.c) is the definition this is bit-exact against.  One plain per-sample loop, no windows:
+// -- integer arithmetic like the reference's (:520-525); the reference itself has no CBOC: include/galsynth.h
+// (GAL_CFG_CBOC) carries the definition, the test suite's CPU checker restates it.  One plain per-sample loop, no windows:
 // about 3.5x the instructions of the BOC(1,1) path.  lutb: LDS byte address of entry k = 0 of the channel's A table
 // (plain or conjugate); the B tables follow 8 KB later.
 template <int J>

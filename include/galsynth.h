@@ -84,11 +84,15 @@ typedef struct gal_synth_cfg {
 } gal_synth_cfg_t;
 
 /* gal_synth_cfg_t.flags */
-#define GAL_CFG_CBOC 2u          /* opt-in: CBOC(6,1,1/11) composite sub-carrier of the E1 OS ICD instead of the BOC(1,1)
-                                    the reference generates (src/gal-sig.cpp:198-233).  The reference has no such
-                                    mode: the definition (integer tables TA = lround(sqrt(10/11) LUT), TB =
-                                    lround(sqrt(1/11) LUT), sub-carriers from (int)(2 x) and (int)(12 x)) is
-                                    oracle/galsyn_oracle.c's CBOC mode, against which the GPU path is bit-exact      */
+#define GAL_CFG_CBOC 2u          /* opt-in: CBOC(6,1,1/11), the composite sub-carrier of the E1 OS ICD, instead of the
+                                    BOC(1,1) the reference generates (src/gal-sig.cpp:198-233; the reference has no such
+                                    mode).  Definition, per channel and sample, with x = code phase in chips,
+                                    B = E1B chip x data symbol, C = E1C chip x secondary code (all +-1), sc_A = +1 if
+                                    (int)(2 x) is odd else -1 (the reference's sboc convention), sc_B likewise from
+                                    (int)(12 x), k = ((int)(511 carr_phase)) & 511:
+                                        I += sc_A (B - C) TAcos[k] + sc_B (B + C) TBcos[k]      (Q with the sin tables)
+                                    TA = lround(sqrt(10/11) x cosTable512 / sinTable512), TB = lround(sqrt(1/11) x ...);
+                                    everything else (wrap, symbol, page, NCO updates, int16 store) as src/galileo-sdr.cpp:481-539 */
 #define GAL_CFG_SINGLE_STREAM 1u /* enqueue every kernel on the handle's stream (no internal high-priority walker
                                     streams): for callers that capture or serialise the stream themselves       */
 
