@@ -255,6 +255,8 @@ def main():
                     help="N > 1: 'scenarios' = one independent scenario per rank (weak scaling, the default and the "
                     "headline); 'scenario' = ONE scenario cut into contiguous epoch ranges, every rank walks the whole "
                     "NCO chain and synthesises its own range (strong scaling, no exchange)")
+    ap.add_argument("--signal", default="boc11", choices=["boc11", "cboc"], help="boc11 = the reference's signal (headline); "
+                    "cboc = the opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-headline legs (kernel + D2H, CLI file "
                     "sink, M-DYN, M-SYN24) that the default 1-GPU run reports under e2e / configs")
@@ -302,7 +304,7 @@ def main():
     engines, outs, streams = [], [], []
     for k in range(depth):
         eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
-                              chunk_samples=args.chunk)
+                              chunk_samples=args.chunk, flags=pkg.synth.GAL_CFG_CBOC if args.signal == "cboc" else 0)
         st = torch.cuda.Stream()
         eng.set_stream(st.cuda_stream)
         eng.plan(params)  # inputs resident in HBM before the timed region
@@ -423,7 +425,11 @@ def main():
                 "algorithmic_bytes_per_launch": 4 * samples_per_step,
             },
         }
-        default_run = (world == 1 and args.workload == "syn12" and args.epochs == 1199 and args.channels == 12 and not strong)
+        default_run = (world == 1 and args.workload == "syn12" and args.epochs == 1199 and args.channels == 12 and not strong
+                       and args.signal == "boc11")
+        if args.signal == "cboc":
+            line["config"]["signal"] = "CBOC(6,1,1/11), opt-in mode (not the reference's signal, not the headline)"
+            args.no_cpu_baseline = True
         if default_run and not args.no_extras:
             # untimed-for-headline legs (kernel-only above, kernel + D2H and the file sink here; configs 3/4)
             line["e2e"] = {"kernel_plus_d2h": leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp)}
