@@ -68,7 +68,7 @@ void init_tables()
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
-constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare
+constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare (17 us of no-op launches)
 
 }  // namespace
 
@@ -589,11 +589,11 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     galk_launch_prep(P, ws);
     HIP_TRY(hipEventRecord(h->ev_prep, ws));
     galk_launch_carr_guess(P, ws);
-    // Speculative carrier walk: kDefaultPasses passes are enqueued back to back (each is a no-op once the
-    // chain is verified -- 2 normally suffice), then the synthesis kernel, all asynchronously: the host does
-    // not wait here, so several handles can be kept in flight (the latency-bound walk of one batch then
-    // runs beside the issue-bound synthesis of another).  gal_synth_finish() looks at the counter; in the rare
-    // case that the chain was not verified by then it iterates further and repeats the synthesis.
+    // Speculative carrier walk: kDefaultPasses passes are enqueued back to back (walk + stitch, then the translations,
+    // whose stitch is skipped), then the synthesis kernel, all asynchronously: the host does not wait here, so several
+    // handles can be kept in flight (the latency-bound walk of one batch then runs beside the issue-bound synthesis
+    // of another).  gal_synth_finish() looks at the counter; in the rare case that the chain was not verified by then
+    // it iterates further and repeats the synthesis.
     int n_passes = kDefaultPasses;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;
@@ -604,7 +604,8 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
         if (pass == 0) {
             // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on
             // the carrier chain: they run on a second stream beside the carrier passes and join before k_synth
-            // (enqueued after the first carrier pass: the carrier chain is the critical path)
+            // (enqueued after the first carrier pass: the carrier chain is the critical path, and every launch
+            // call in front of it delays it by the 5-8 us the call takes)
             HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
             galk_launch_walk_code(P, h->aux_stream);
             galk_launch_pages(P, h->aux_stream);

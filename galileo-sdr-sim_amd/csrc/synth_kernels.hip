@@ -96,65 +96,76 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return u2d(((uint64_t)hi << 32) | lo);
 }
 
-// k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start and the ideal last wrap before it.
-// One wave per slot, 64 epochs per round trip: (1) the short sequential phase recurrence runs out of
-// registers (v_readlane with literal lanes, no LDS permutes on the serial path); (2) every lane predicts the
-// last wrap inside its own epoch in closed form; (3) a wave-wide "last one that speaks" scan turns those into
-// the last wrap (or chain root) at or before every epoch start.
-__global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
+// k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start and the ideal last wrap before it -- first guesses
+// for the speculative stitcher, nothing here has to be exact.  One 256-thread block per slot, one epoch per thread
+// (tiles of 256 epochs with a carry): (1) the phase recurrence p <- frac(p + N d_e), restarted at (re)allocations, is a
+// segmented prefix sum of the fractional advances (round 1 walked the epochs one by one in a single wave: 0.08 ms of
+// the 0.5 ms a lone handle waits for its walker chain); (2) every thread predicts the last wrap inside its own epoch
+// in closed form; (3) a "last one that speaks" scan turns those into the last wrap (or chain root) at or before every
+// epoch start.
+// 256 threads = one wave per SIMD: beside a running k_synth (which fills every SIMD's register file) a block can start
+// as soon as ONE synthesis block retires; a 1024-thread block would have to wait for an entirely empty CU
+#define GUESS_THREADS 256
+__device__ __forceinline__ double guess_reduce(double x, double d)
+{
+    // the reference keeps the phase in (-1, 1) with the sign of the step it was last wrapped with (:531-532)
+    x = x - __builtin_trunc(x);
+    if (x != 0.0 && d != 0.0 && ((x < 0.0) != (d < 0.0))) x += d < 0.0 ? -1.0 : 1.0;
+    return x;
+}
+
+__global__ __launch_bounds__(GUESS_THREADS) void k_carr_guess(DevPlan P)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
+    __shared__ double s_v[GUESS_THREADS], s_r[GUESS_THREADS];
+    __shared__ int s_f[GUESS_THREADS], s_kind[GUESS_THREADS];
+    __shared__ long long s_w[GUESS_THREADS];
     const int s = blockIdx.x;
-    const int lane = threadIdx.x;
-    double p = 0.0;  // wave-uniform running phase
-    // carry of the event scan: kind 0 nothing yet, 1 defined, 2 chain broken
-    int c_kind = 0;
+    const int t = threadIdx.x;
+    const double start0 = P.state_in[s].carr_phase;
+    double c_val = 0.0;  // unreduced phase after the last epoch of the previous tile
+    int c_kind = 0;      // carry of the event scan: kind 0 nothing yet, 1 defined, 2 chain broken
     long long c_w = 0;
     double c_r = 0.0;
-    const double start0 = P.state_in[s].carr_phase;
-    // the loads of round r+1 are issued before round r is processed (the rounds are serial, the loads are not)
-    int n_prn = 0;
-    uint32_t n_fl = 0;
-    double n_p0 = 0.0, n_ds = 0.0;
-    {
-        const int idx0 = (lane < P.E ? lane : 0) * P.S + s;
-        n_prn = lane < P.E ? P.prn[idx0] : 0;
-        n_fl = P.flags[idx0];
-        n_p0 = P.p0[idx0];
-        n_ds = P.dstep[idx0];
-    }
-    for (int base = 0; base < P.E; base += 64) {
-        const int e = base + lane;
+    for (int base = 0; base < P.E; base += GUESS_THREADS) {
+        const int e = base + t;
         const bool in = e < P.E;
-        const int prn = n_prn;
-        const uint32_t fl = n_fl;
-        const double p0 = (fl & GAL_CH_RESTART) ? n_p0 : start0;
-        const double ds_raw = n_ds;
-        {
-            const int en = e + 64;
-            const int idxn = (en < P.E ? en : 0) * P.S + s;
-            n_prn = en < P.E ? P.prn[idxn] : 0;
-            n_fl = P.flags[idxn];
-            n_p0 = P.p0[idxn];
-            n_ds = P.dstep[idxn];
-        }
+        const int idx = (in ? e : 0) * P.S + s;
+        const int prn = in ? P.prn[idx] : 0;
+        const uint32_t fl = P.flags[idx];
+        const double ds_raw = P.dstep[idx];
         const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
+        const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
         const double d = eff_step(ds_raw);  // mean advance of the rounded chain (nco_walk.h)
-        const double adv = prn > 0 ? (double)P.N * d : 0.0;  // idle epochs leave the phase alone
-        const int rs = reset ? 1 : 0;
-        double mine = 0.0;
-        // branch-free on purpose: the only dependent chain per step is select -> add -> trunc -> sub on the
-        // wave-uniform phase; the lane reads (v_readlane with literal lanes) do not depend on it
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            const double a_k = readlane_f64(adv, k);
-            const double p0_k = readlane_f64(p0, k);
-            p = __builtin_amdgcn_readlane(rs, k) ? p0_k : p;
-            mine = (k == lane) ? p : mine;
-            p = p + a_k;
-            p = p - __builtin_trunc(p);
+        double adv = prn > 0 ? (double)P.N * d : 0.0;  // idle epochs leave the phase alone
+        adv = adv - __builtin_trunc(adv);
+        // ---- (1) inclusive segmented sum: value after epoch e, counted from the last restart
+        s_v[t] = reset ? p0 + adv : adv;
+        s_f[t] = reset ? 1 : 0;
+        __syncthreads();
+        for (int off = 1; off < GUESS_THREADS; off <<= 1) {
+            double v2 = 0.0;
+            int f2 = 0;
+            const bool take = t >= off && s_f[t] == 0;
+            if (take) {
+                v2 = s_v[t - off];
+                f2 = s_f[t - off];
+            }
+            __syncthreads();
+            if (take) {
+                s_v[t] += v2;
+                s_f[t] = f2;
+            }
+            __syncthreads();
         }
-        // the last event up to the END of my epoch: a wrap inside it, else its root, else nothing
+        // unreduced phase at the START of my epoch: what the epoch before left (or the carry of the previous tile)
+        double before = c_val;
+        if (t > 0) before = s_f[t - 1] ? s_v[t - 1] : c_val + s_v[t - 1];
+        const double mine = reset ? p0 : guess_reduce(before, d);
+        const double tile_end = s_f[GUESS_THREADS - 1] ? s_v[GUESS_THREADS - 1] : c_val + s_v[GUESS_THREADS - 1];
+        __syncthreads();
+        c_val = tile_end - __builtin_trunc(tile_end);  // (only the fraction matters; keeps the sums small)
+        // ---- (2) the last event up to the END of my epoch: a wrap inside it, else its root, else nothing
         int kind = 0;
         long long w = 0;
         double r = 0.0;
@@ -172,18 +183,36 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
                 r = mine;
             }
         }
-        // "the last one that speaks" before my epoch: a ballot names the speakers, the highest one below my lane
-        // is the source -- one cross-lane read per word instead of a 6-step shuffle scan
-        const uint64_t spk = __builtin_amdgcn_ballot_w64(kind != 0);
-        const uint64_t below = spk & ((1ull << lane) - 1ull);
-        const int src = below ? 63 - __builtin_clzll(below) : 0;
-        int xk = __shfl(kind, src);
-        long long xw = __shfl(w, src);
-        double xr = __shfl(r, src);
-        if (!below) {  // nobody in this round before me: what the previous rounds left
-            xk = c_kind;
-            xw = c_w;
-            xr = c_r;
+        // ---- (3) "the last one that speaks": inclusive scan, then look at the thread before me
+        s_kind[t] = kind;
+        s_w[t] = w;
+        s_r[t] = r;
+        __syncthreads();
+        for (int off = 1; off < GUESS_THREADS; off <<= 1) {
+            int k2 = 0;
+            long long w2 = 0;
+            double r2 = 0.0;
+            const bool take = t >= off && s_kind[t] == 0;
+            if (take) {
+                k2 = s_kind[t - off];
+                w2 = s_w[t - off];
+                r2 = s_r[t - off];
+            }
+            __syncthreads();
+            if (take) {
+                s_kind[t] = k2;
+                s_w[t] = w2;
+                s_r[t] = r2;
+            }
+            __syncthreads();
+        }
+        int xk = c_kind;
+        long long xw = c_w;
+        double xr = c_r;
+        if (t > 0 && s_kind[t - 1] != 0) {
+            xk = s_kind[t - 1];
+            xw = s_w[t - 1];
+            xr = s_r[t - 1];
         }
         if (in && prn > 0) {
             P.pguess[(size_t)s * P.E + e] = mine;
@@ -191,12 +220,12 @@ __global__ __launch_bounds__(64) void k_carr_guess(DevPlan P)
             P.gss_w[(size_t)s * P.E + e] = use_root ? (long long)e * P.N : xw;
             P.gss_r[(size_t)s * P.E + e] = use_root ? mine : xr;
         }
-        if (spk) {  // wave-uniform: the last speaker of this round is the carry of the next
-            const int last = 63 - __builtin_clzll(spk);
-            c_kind = __shfl(kind, last);
-            c_w = __shfl(w, last);
-            c_r = __shfl(r, last);
+        if (s_kind[GUESS_THREADS - 1] != 0) {  // block-uniform: the last speaker of this tile is the carry of the next
+            c_kind = s_kind[GUESS_THREADS - 1];
+            c_w = s_w[GUESS_THREADS - 1];
+            c_r = s_r[GUESS_THREADS - 1];
         }
+        __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk
@@ -685,47 +714,62 @@ __global__ void k_carr_publish(DevPlan P)
 
 // Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88: the page
 // changes only at a (re)allocation or when the symbol counter wrapped inside the previous epoch.
-// One wave per slot, 64 epochs per round trip; `src` encodes where the page comes from:
-//   -1: state_in,  2*e: page_next of epoch e,  2*e+1: page_init of epoch e.
-__global__ __launch_bounds__(64) void k_pages(DevPlan P)
+// `src` encodes where the page comes from:  -1: state_in,  2*e: page_next of epoch e,  2*e+1: page_init of epoch e.
+// Every active epoch e leaves ONE event for the epochs after it -- 2e if its counter wrapped, else 2e+1 if it was
+// (re)allocated -- so the page of epoch e is page_init(e) if it restarts, else the last event before it: a block-wide
+// "last one that speaks" scan, one epoch per thread (round 1 walked the epochs serially in one wave: 0.13 ms on the
+// critical path of a lone handle).
+__global__ __launch_bounds__(GUESS_THREADS) void k_pages(DevPlan P)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
+    __shared__ int s_ev[GUESS_THREADS];
     const int s = blockIdx.x;
-    const int lane = threadIdx.x;
-    int cur = -1;  // wave-uniform
-    for (int base = 0; base < P.E; base += 64) {
-        const int e = base + lane;
+    const int t = threadIdx.x;
+    int carry = -1;  // block-uniform: last event of the tiles before
+    for (int base = 0; base < P.E; base += GUESS_THREADS) {
+        const int e = base + t;
         const bool in = e < P.E;
         const int idx = (in ? e : 0) * P.S + s;
         const int prn = in ? P.prn[idx] : 0;
-        const int restart = (P.flags[idx] & GAL_CH_RESTART) ? 1 : 0;
-        const int flip = P.flip_in[idx];
-        int mine = -1;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            if (__builtin_amdgcn_readlane(prn, k) > 0) {  // wave-uniform
-                if (__builtin_amdgcn_readlane(restart, k)) cur = 2 * (base + k) + 1;
-                if (k == lane) mine = cur;
-                if (__builtin_amdgcn_readlane(flip, k)) cur = 2 * (base + k);
-            }
+        const bool restart = prn > 0 && (P.flags[idx] & GAL_CH_RESTART);
+        const bool flip = prn > 0 && P.flip_in[idx] != 0;
+        const int ev = flip ? 2 * e : (restart ? 2 * e + 1 : -2);  // -2: says nothing
+        s_ev[t] = ev;
+        __syncthreads();
+        for (int off = 1; off < GUESS_THREADS; off <<= 1) {
+            int v2 = -2;
+            const bool take = t >= off && s_ev[t] == -2;
+            if (take) v2 = s_ev[t - off];
+            __syncthreads();
+            if (take) s_ev[t] = v2;
+            __syncthreads();
         }
+        int before = carry;
+        if (t > 0 && s_ev[t - 1] != -2) before = s_ev[t - 1];
+        const int mine = restart ? 2 * e + 1 : before;
         if (in && prn > 0) {
             const uint32_t *src = mine < 0 ? P.state_in[s].page
                                   : (mine & 1) ? P.params[(size_t)(mine >> 1) * P.S + s].page_init
                                                : P.page_next + ((size_t)(mine >> 1) * P.S + s) * GAL_PAGE_WORDS;
             uint32_t *dst = P.page_cur + (size_t)idx * GAL_PAGE_WORDS;
+            uint32_t w[GAL_PAGE_WORDS];
 #pragma unroll
-            for (int w = 0; w < GAL_PAGE_WORDS; ++w) dst[w] = src[w];
+            for (int k = 0; k < GAL_PAGE_WORDS; ++k) w[k] = src[k];
+#pragma unroll
+            for (int k = 0; k < GAL_PAGE_WORDS; ++k) dst[k] = w[k];
         }
+        const int last = s_ev[GUESS_THREADS - 1];
+        __syncthreads();
+        if (last != -2) carry = last;
     }
     // end-of-batch state for the next call
-    if (lane < GAL_PAGE_WORDS) {
-        const uint32_t *src = cur < 0 ? P.state_in[s].page
-                              : (cur & 1) ? P.params[(size_t)(cur >> 1) * P.S + s].page_init
-                                          : P.page_next + ((size_t)(cur >> 1) * P.S + s) * GAL_PAGE_WORDS;
-        P.state_out[s].page[lane] = src[lane];
+    if (t < GAL_PAGE_WORDS) {
+        const uint32_t *src = carry < 0 ? P.state_in[s].page
+                              : (carry & 1) ? P.params[(size_t)(carry >> 1) * P.S + s].page_init
+                                            : P.page_next + ((size_t)(carry >> 1) * P.S + s) * GAL_PAGE_WORDS;
+        P.state_out[s].page[t] = src[t];
     }
-    if (lane == 0) {
+    if (t == 0) {
         const int prn = P.prn[(P.E - 1) * P.S + s];
         P.state_out[s].prn = prn > 0 ? prn : 0;
         P.state_out[s].reserved = 0;
@@ -1393,7 +1437,7 @@ extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 
 extern "C" void galk_launch_carr_guess(const DevPlan *P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_carr_guess, dim3(P->S), dim3(64), 0, st, *P);
+    hipLaunchKernelGGL(k_carr_guess, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
 }
 
 extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st)
@@ -1415,7 +1459,7 @@ extern "C" void galk_launch_state_phase(const DevPlan *P, hipStream_t st)
 
 extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(64), 0, st, *P);
+    hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
 }
 
 template <bool ACC, int SIG>
