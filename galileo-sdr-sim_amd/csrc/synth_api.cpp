@@ -89,7 +89,9 @@ struct gal_synth {
     // tables in HBM
     int *d_lut = nullptr;
     uint32_t *d_str = nullptr;   // [50][512] half-chip streams (2 bits per BOC half chip)
-    DevPlan *d_plan = nullptr;   // device copy of P (the hot kernel reads rarely used fields through it)
+    DevPlan *d_plan = nullptr;   // device copy of P, inside the arena (the hot kernel reads rarely used fields through it)
+    char *h_up = nullptr;        // pinned staging buffer of plan(): the arena's upload region, byte for byte
+    size_t h_up_bytes = 0;
 
     // arena for the planned batch
     void *arena = nullptr;
@@ -110,6 +112,7 @@ struct gal_synth {
     int *h_ctr = nullptr;  // pinned
     int64_t legs_walked = 0, legs_translated = 0, n_fallbacks = 0;  // last finish(): carrier legs walked / translated
     gal_chan_state_t *h_state = nullptr;  // pinned [S]
+    bool state_fetched = false;           // h_state holds the state of the batch in flight
     gal_synth_stats_t stats{};
 };
 
@@ -210,8 +213,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
 
     if (hipMalloc((void **)&h->d_lut, 2 * 512 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&h->d_str, 50 * 512 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&h->d_plan, sizeof(DevPlan)) != hipSuccess)
+        hipMalloc((void **)&h->d_str, 50 * 512 * sizeof(uint32_t)) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "table allocation failed"));
     {
         // per PRN 8184 BOC half chips x 2 bits: bit 2h = (E1B ^ E1C) chip, bit 2h+1 = E1C chip ^ (h & 1)
@@ -258,7 +260,7 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->own_iq) hipFree(h->own_iq);
     if (h->d_lut) hipFree(h->d_lut);
     if (h->d_str) hipFree(h->d_str);
-    if (h->d_plan) hipFree(h->d_plan);
+    if (h->h_up) hipHostFree(h->h_up);
     if (h->h_ctr) hipHostFree(h->h_ctr);
     if (h->h_state) hipHostFree(h->h_state);
     for (auto &e : h->ev)
@@ -423,21 +425,28 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         off = align_up(off + bytes, 256);
         return o;
     };
+    // upload region (ONE host->device copy from the handle's pinned staging buffer): the device copy of the plan,
+    // the epoch records, the start state, the active lists
+    const size_t o_plan = take(sizeof(DevPlan));
     const size_t o_params = take(ES * sizeof(gal_chan_epoch_t));
     const size_t o_state_in = take(sizeof(gal_chan_state_t) * S);
+    const size_t o_act = take((size_t)n_groups * E * kActRow), o_nact = take((size_t)n_groups * E * 4);
+    const size_t up_bytes = off;
+    // zeroed region (ONE memset): checkpoints, first guesses, leg records that are read before they are written
+    const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
+    const size_t o_pguess = take(ES * 8);
+    const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmr = take(LEGS * S * 8);
+    const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
+    const size_t zero_end = off;
+    const size_t o_clmw = take(LEGS * S * 8);  // "no claim" = -1
     const size_t o_state_out = take(sizeof(gal_chan_state_t) * S);
     const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
     const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
     const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4), o_pcur = take(ES * GAL_PAGE_WORDS * 4);
     const size_t o_flip = take(ES);
-    const size_t o_act = take((size_t)n_groups * E * kActRow), o_nact = take((size_t)n_groups * E * 4);
-    const size_t o_pguess = take(ES * 8), o_gssw = take(ES * 8), o_gssr = take(ES * 8);
-    const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmw = take(LEGS * S * 8),
-                 o_clmr = take(LEGS * S * 8);
-    const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
+    const size_t o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
-    const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ctr = take(CTR_COUNT * 4);
 
     const size_t total = off;
@@ -449,7 +458,16 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", total);
         h->arena_bytes = total;
     }
+    if (up_bytes > h->h_up_bytes) {
+        if (h->h_up) hipHostFree(h->h_up);
+        h->h_up = nullptr;
+        h->h_up_bytes = 0;
+        if (hipHostMalloc((void **)&h->h_up, up_bytes + up_bytes / 2, hipHostMallocDefault) != hipSuccess)
+            return fail(GAL_E_NOMEM, "pinned staging allocation of %zu bytes failed", up_bytes);
+        h->h_up_bytes = up_bytes + up_bytes / 2;
+    }
     char *base = (char *)h->arena;
+    h->d_plan = (DevPlan *)(base + o_plan);
     DevPlan &P = h->P;
     P.E = E; P.S = S; P.N = N; P.R = R; P.nchunks = nchunks; P.CP1 = (int)CP1;
     P.blocks_per_epoch = (tiles + 3) / 4;
@@ -493,35 +511,30 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
 
-    // ---- upload (synchronous: after plan() the batch is resident in HBM).  A start phase of -0.0 is
-    // canonicalised to +0.0 (see carr_step in nco_walk.h).
+    // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
+    // goes over in one copy; one memset clears what must start at zero; one sync at the end: after plan() the batch
+    // is resident in HBM.  (Round 1 issued 4 pageable copies and 11 memsets one by one: 0.2 ms per plan, a quarter of
+    // a per-epoch call.)  A start phase of -0.0 is canonicalised to +0.0 (see carr_step in nco_walk.h).
     {
-        std::vector<gal_chan_epoch_t> up(params, params + ES);
-        for (auto &r : up)
-            if (r.carr_phase0 == 0.0) r.carr_phase0 = 0.0;
-        HIP_TRY(hipMemcpy(base + o_params, up.data(), ES * sizeof(gal_chan_epoch_t), hipMemcpyHostToDevice));
+        char *up = h->h_up;
+        memset(up, 0, up_bytes);
+        memcpy(up + o_plan, &P, sizeof(DevPlan));
+        gal_chan_epoch_t *rows = (gal_chan_epoch_t *)(up + o_params);
+        memcpy(rows, params, ES * sizeof(gal_chan_epoch_t));
+        for (size_t i = 0; i < ES; ++i)
+            if (rows[i].carr_phase0 == 0.0) rows[i].carr_phase0 = 0.0;
+        gal_chan_state_t *st = (gal_chan_state_t *)(up + o_state_in);
+        if (state_in) memcpy(st, state_in, sizeof(gal_chan_state_t) * S);
+        for (int i = 0; i < S; ++i)
+            if (st[i].carr_phase == 0.0) st[i].carr_phase = 0.0;
+        memcpy(up + o_act, act_g.data(), act_g.size());
+        memcpy(up + o_nact, nact_g.data(), nact_g.size() * sizeof(int));
+        hipStream_t st_up = h->stream;
+        HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
+        HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
+        HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
+        HIP_TRY(hipStreamSynchronize(st_up));
     }
-    std::vector<gal_chan_state_t> st(S);
-    memset(st.data(), 0, sizeof(gal_chan_state_t) * S);
-    if (state_in) memcpy(st.data(), state_in, sizeof(gal_chan_state_t) * S);
-    for (auto &c : st)
-        if (c.carr_phase == 0.0) c.carr_phase = 0.0;
-    HIP_TRY(hipMemcpy(base + o_state_in, st.data(), sizeof(gal_chan_state_t) * S, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + o_act, act_g.data(), act_g.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + o_nact, nact_g.data(), nact_g.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(base + o_cpx, 0, ES * CP1 * 8));
-    HIP_TRY(hipMemset(base + o_cpp, 0, ES * CP1 * 8));
-    HIP_TRY(hipMemset(base + o_cpi, 0, ES * CP1 * 4));
-    HIP_TRY(hipMemset(base + o_pguess, 0, ES * 8));
-    HIP_TRY(hipMemset(base + o_ancw, 0, LEGS * S * 8));
-    HIP_TRY(hipMemset(base + o_ancr, 0, LEGS * S * 8));
-    HIP_TRY(hipMemset(base + o_clmw, 0xff, LEGS * S * 8));
-    HIP_TRY(hipMemset(base + o_clmr, 0, LEGS * S * 8));
-    HIP_TRY(hipMemset(base + o_pend, 0, LEGS * S * 8));
-    HIP_TRY(hipMemset(base + o_ver, 0, LEGS * S));
-    HIP_TRY(hipMemset(base + o_dirty, 0, LEGS * S));
-
-    HIP_TRY(hipMemcpy(h->d_plan, &P, sizeof(DevPlan), hipMemcpyHostToDevice));
     h->nact_max = nact_max;
     memset(&h->stats, 0, sizeof(h->stats));
     h->stats.n_epochs = E;
@@ -619,6 +632,10 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
         HIP_TRY(hipStreamWaitEvent(st, h->ev_walk, 0));
     }
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
+    // the end-of-batch state is final once the walkers are (it does not depend on k_synth): fetch it now, beside the
+    // synthesis, so that finish() has it without another round trip (its repair paths fetch it again)
+    HIP_TRY(hipMemcpyAsync(h->h_state, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost, st));
+    h->state_fetched = true;
     HIP_TRY(hipEventRecord(h->ev[1], st));
     int rc = enqueue_synth(h, (uint32_t *)iq_dev);
     if (rc) return rc;
@@ -660,6 +677,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
             HIP_TRY(hipStreamSynchronize(st));
         }
         HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
+        h->state_fetched = false;
         galk_launch_state_phase(P, st);
         HIP_TRY(hipEventRecord(h->ev[1], st));
         int rc = enqueue_synth(h, h->last_iq);
@@ -694,6 +712,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
             HIP_TRY(hipMemcpyAsync(ctr_walk, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         } while (ctr_walk[CTR_UNVERIFIED] != 0);
+        h->state_fetched = false;
         galk_launch_state_phase(P, st);
         HIP_TRY(hipEventRecord(h->ev[1], st));
         int rc = enqueue_synth(h, h->last_iq);
@@ -716,7 +735,9 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     h->legs_translated = ctr_end[CTR_SHIFTS];
     if (stats) *stats = h->stats;
     if (state_out) {
-        HIP_TRY(hipMemcpy(state_out, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost));
+        if (!h->state_fetched)
+            HIP_TRY(hipMemcpy(h->h_state, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost));
+        memcpy(state_out, h->h_state, sizeof(gal_chan_state_t) * P->S);
     }
     if (h->stats.chain_mismatch != 0)
         return fail(GAL_E_CHAIN, "replay kernel disagreed with the NCO walker at %d chunk boundaries",
