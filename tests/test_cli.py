@@ -87,3 +87,29 @@ def test_cli_realtime_pacing_and_live_position(tmp_path):
     b = np.fromfile(str(live), dtype=np.int16).reshape(29, -1)
     same = [bool(np.array_equal(a[e], b[e])) for e in range(29)]
     assert all(same[:8]) and not any(same[-5:]), same
+
+
+@pytest.mark.gpu
+def test_cli_time_overwrite(pkg, tmp_path):
+    """-T <date,time>: TOC / TOE overwrite (src/main.cpp:237-257, src/gnss-time.cpp:105-137) through the whole CLI:
+    a start two and a half years after the navigation file is an error with -t and a valid run with -T, whose bytes
+    are the oracle's on the front-end's rows."""
+    import numpy as np
+
+    from oracle_binding import oracle_run
+
+    when = "2024/10/08,09:30:00"
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", when, "-d", "2", "-P", "0", "-o", str(tmp_path / "x.ishort")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid start time" in r.stderr
+    out = tmp_path / "t.ishort"
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", when, "-d", "2", "-P", "0", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = pkg.Scenario(NAV, llh=(-6, 51, 100), start=when, duration_s=2, time_overwrite=True).all()
+    ref_iq, _ = oracle_run(rows, 260000, 2.6e6)
+    assert np.array_equal(np.fromfile(str(out), dtype=np.int16), ref_iq)
+    # -T now: the current time is always acceptable
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", "now", "-d", "1", "-P", "0", "-o", "/dev/null"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
