@@ -113,70 +113,103 @@ void llh_to_ecef(const double llh[3], double xyz[3])
     xyz[2] = ((1.0 - e2) * n + llh[2]) * slat;
 }
 
+namespace {
+
+// seconds from `ref` to `t`, folded into half a week either side
+double folded_interval(double t, double ref)
+{
+    double dt = t - ref;
+    if (dt > kSecHalfWeek) dt -= kSecWeek;
+    else if (dt < -kSecHalfWeek) dt += kSecWeek;
+    return dt;
+}
+
+// Eccentric anomaly by the fixed-point form of Newton's iteration, stopped at 1e-14 or 500 rounds.  `denom` is
+// 1 - e cos(E) evaluated at the iterate BEFORE the last update -- the value the range-rate terms are built on.
+struct Anomaly {
+    double E;
+    double denom;
+};
+
+Anomaly eccentric_anomaly(double mean, double ecc)
+{
+    Anomaly a;
+    a.E = mean;
+    a.denom = 0;
+    double previous = a.E + 1.0;
+    for (int round = 0; fabs(a.E - previous) > 1.0E-14 && round < 500; ++round) {
+        previous = a.E;
+        a.denom = 1.0 - ecc * cos(previous);
+        a.E = a.E + (mean - previous + ecc * sin(previous)) / a.denom;
+    }
+    return a;
+}
+
+// (base + first) + second: the harmonic corrections are added one after the other, in this order
+inline double plus2(double base, double first, double second) { return base + first + second; }
+
+// position and velocity in the orbital plane
+struct InPlane {
+    double x, y, xdot, ydot;
+};
+
+// rotate by inclination and (Earth-fixed) longitude of the ascending node; node_rate turns the frame
+void to_earth_fixed(const InPlane &q, double incl, double incl_rate, double node, double node_rate, double pos[3],
+                    double vel[3])
+{
+    const double si = sin(incl), ci = cos(incl);
+    const double sn = sin(node), cn = cos(node);
+    pos[0] = q.x * cn - q.y * ci * sn;
+    pos[1] = q.x * sn + q.y * ci * cn;
+    pos[2] = q.y * si;
+    const double cross = q.ydot * ci - q.y * si * incl_rate;
+    vel[0] = -node_rate * pos[1] + q.xdot * cn - cross * sn;
+    vel[1] = node_rate * pos[0] + q.xdot * sn + cross * cn;
+    vel[2] = q.y * ci * incl_rate + q.ydot * si;
+}
+
+}  // namespace
+
+// Broadcast-ephemeris satellite state (OS SIS ICD 5.1.1 user algorithm) with the rates needed for the range rate,
+// evaluated in the operation order of the reference's satpos() (src/geodesy.cpp:161-273): the doubles feed the NCO
+// parameters and through them the int16 IQ, so the expression trees are not free.
 void sat_state(const Ephemeris &eph, const GalTime &g, double pos[3], double vel[3], double clk[2])
 {
-    double tk = g.sec - eph.toe.sec;
-    if (tk > kSecHalfWeek) tk -= kSecWeek;
-    else if (tk < -kSecHalfWeek) tk += kSecWeek;
+    const double t_orbit = folded_interval(g.sec, eph.toe.sec);
+    const double mean = eph.m0 + eph.n * t_orbit;
+    const Anomaly an = eccentric_anomaly(mean, eph.ecc);
+    const double sinE = sin(an.E), cosE = cos(an.E);
+    const double E_rate = eph.n / an.denom;
+    const double clock_rel = -4.442807633E-10 * eph.ecc * eph.sqrta * sinE;
 
-    const double mk = eph.m0 + eph.n * tk;
-    double ek = mk;
-    double ekold = ek + 1.0;
-    double one_m_ecos = 0;
-    int iter = 0;
-    while ((fabs(ek - ekold) > 1.0E-14) && iter < 500) {
-        iter++;
-        ekold = ek;
-        one_m_ecos = 1.0 - eph.ecc * cos(ekold);
-        ek = ek + (mk - ekold + eph.ecc * sin(ekold)) / one_m_ecos;
-    }
-    const double sek = sin(ek);
-    const double cek = cos(ek);
-    const double ekdot = eph.n / one_m_ecos;
-    const double relativistic = -4.442807633E-10 * eph.ecc * eph.sqrta * sek;
+    // argument of latitude before corrections, and the second harmonics all corrections are expressed in
+    const double phi = atan2(eph.sq1e2 * sinE, cosE - eph.ecc) + eph.aop;
+    const double phi_rate = eph.sq1e2 * E_rate / an.denom;
+    const double s2 = sin(2.0 * phi), c2 = cos(2.0 * phi);
 
-    const double pk = atan2(eph.sq1e2 * sek, cek - eph.ecc) + eph.aop;
-    const double pkdot = eph.sq1e2 * ekdot / one_m_ecos;
-    const double s2pk = sin(2.0 * pk);
-    const double c2pk = cos(2.0 * pk);
+    const double lat_arg = plus2(phi, eph.cus * s2, eph.cuc * c2);
+    const double s_lat = sin(lat_arg), c_lat = cos(lat_arg);
+    const double lat_rate = phi_rate * (1.0 + 2.0 * (eph.cus * c2 - eph.cuc * s2));
 
-    const double uk = pk + eph.cus * s2pk + eph.cuc * c2pk;
-    const double suk = sin(uk);
-    const double cuk = cos(uk);
-    const double ukdot = pkdot * (1.0 + 2.0 * (eph.cus * c2pk - eph.cuc * s2pk));
+    const double radius = plus2(eph.A * an.denom, eph.crc * c2, eph.crs * s2);
+    const double radius_rate = eph.A * eph.ecc * sinE * E_rate + 2.0 * phi_rate * (eph.crs * c2 - eph.crc * s2);
 
-    const double rk = eph.A * one_m_ecos + eph.crc * c2pk + eph.crs * s2pk;
-    const double rkdot = eph.A * eph.ecc * sek * ekdot + 2.0 * pkdot * (eph.crs * c2pk - eph.crc * s2pk);
+    const double incl = plus2(eph.inc0 + eph.idot * t_orbit, eph.cic * c2, eph.cis * s2);
+    const double incl_rate = eph.idot + 2.0 * phi_rate * (eph.cis * c2 - eph.cic * s2);
 
-    const double ik = eph.inc0 + eph.idot * tk + eph.cic * c2pk + eph.cis * s2pk;
-    const double sik = sin(ik);
-    const double cik = cos(ik);
-    const double ikdot = eph.idot + 2.0 * pkdot * (eph.cis * c2pk - eph.cic * s2pk);
+    InPlane q;
+    q.x = radius * c_lat;
+    q.y = radius * s_lat;
+    q.xdot = radius_rate * c_lat - q.y * lat_rate;
+    q.ydot = radius_rate * s_lat + q.x * lat_rate;
 
-    const double xpk = rk * cuk;
-    const double ypk = rk * suk;
-    const double xpkdot = rkdot * cuk - ypk * ukdot;
-    const double ypkdot = rkdot * suk + xpk * ukdot;
+    const double node = eph.omg0 + t_orbit * eph.omgkdot - kOmegaEarth * eph.toe.sec;
+    to_earth_fixed(q, incl, incl_rate, node, eph.omgkdot, pos, vel);
 
-    const double ok = eph.omg0 + tk * eph.omgkdot - kOmegaEarth * eph.toe.sec;
-    const double sok = sin(ok);
-    const double cok = cos(ok);
-
-    pos[0] = xpk * cok - ypk * cik * sok;
-    pos[1] = xpk * sok + ypk * cik * cok;
-    pos[2] = ypk * sik;
-
-    const double tmp = ypkdot * cik - ypk * sik * ikdot;
-    vel[0] = -eph.omgkdot * pos[1] + xpkdot * cok - tmp * sok;
-    vel[1] = eph.omgkdot * pos[0] + xpkdot * sok + tmp * cok;
-    vel[2] = ypk * cik * ikdot + ypkdot * sik;
-
-    // clock, referenced to toc
-    tk = g.sec - eph.toc.sec;
-    if (tk > kSecHalfWeek) tk -= kSecWeek;
-    else if (tk < -kSecHalfWeek) tk += kSecWeek;
-    clk[0] = eph.af0 + tk * (eph.af1 + tk * eph.af2) + relativistic - eph.bgd_e5b;
-    clk[1] = eph.af1 + 2.0 * tk * eph.af2;
+    // satellite clock, referenced to toc
+    const double t_clock = folded_interval(g.sec, eph.toc.sec);
+    clk[0] = eph.af0 + t_clock * (eph.af1 + t_clock * eph.af2) + clock_rel - eph.bgd_e5b;
+    clk[1] = eph.af1 + 2.0 * t_clock * eph.af2;
 }
 
 int sat_visible(const Ephemeris &eph, const GalTime &g, const double xyz[3], double elv_mask_deg, double azel[2])
