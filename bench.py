@@ -243,9 +243,11 @@ def main():
     ap.add_argument("--epochs", type=int, default=1199, help="epochs per step (default: the 120 s scenario)")
     ap.add_argument("--channels", type=int, default=12)
     ap.add_argument("--chunk", type=int, default=0, help="samples per lane (0 = auto)")
-    ap.add_argument("--workload", default="syn12", choices=["syn12", "syn24", "dyn"],
+    ap.add_argument("--workload", default="syn12", choices=["syn12", "syn24", "dyn", "locations"],
                     help="syn12 = headline M-SYN12 (BASELINE configs[1] size); syn24 = config 4 geometry (24 SVs, "
-                    "25 MS/s); dyn = config 3 (12 SVs, Doppler from a 10 Hz circular track)")
+                    "25 MS/s); dyn = config 3 (12 SVs, Doppler from a 10 Hz circular track); locations = config 5 "
+                    "literally: rank r simulates static site r of 8 for 300 s from tests/golden/20feb2022.rnx through "
+                    "the real host front-end (7-10 SVs per site, so the ranks' work differs)")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4],
                     help="engine handles in flight: 2 = software pipeline, the NCO walk of step k+1 (latency "
                     "bound, on the handle's high-priority stream) runs beside the synthesis kernel of step k (issue "
@@ -297,8 +299,15 @@ def main():
         args.channels = 24
     # each rank: an independent scenario of identical size (different seed)
     strong = args.shard == "scenario"
-    params = pkg.shard.rank_workload(0 if strong else rank, args.epochs, n_chan=args.channels, n_slots=n_slots,
-                                     samples_per_epoch=n_samp, sample_rate=rate, dyn_track=(args.workload == "dyn"))
+    site = None
+    if args.workload == "locations":
+        nav = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
+        params, site = pkg.shard.rank_location_scenario(pkg.Scenario, nav, 0 if strong else rank)
+        args.epochs = params.shape[0]
+        args.channels = int((params["prn"] > 0).sum(axis=1).max())
+    else:
+        params = pkg.shard.rank_workload(0 if strong else rank, args.epochs, n_chan=args.channels, n_slots=n_slots,
+                                         samples_per_epoch=n_samp, sample_rate=rate, dyn_track=(args.workload == "dyn"))
     e_first, e_count = pkg.shard.epoch_range(rank, world, args.epochs) if strong else (0, args.epochs)
     depth = args.pipeline
     engines, outs, streams = [], [], []
@@ -386,10 +395,12 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64 (NCO phases) + int16x2 (packed accumulate) -> int16 IQ",
-            "data": "synthetic",
+            "data": "synthetic" if args.workload != "locations" else "broadcast ephemerides of tests/golden/20feb2022.rnx through the host front-end (no measured IQ exists for this path)",
             "config": {
                 "workload": {"syn12": "M-SYN12: static-geometry 12-SV E1B/C", "syn24": "M-SYN24: 24-SV E1B/C",
-                             "dyn": "M-DYN: 12-SV E1B/C, 10 Hz circular user motion"}[args.workload]
+                             "dyn": "M-DYN: 12-SV E1B/C, 10 Hz circular user motion",
+                             "locations": "config 5: static site per rank from 20feb2022.rnx (rank 0: %s, %d SVs), 300 s"
+                             % (site, args.channels)}[args.workload]
                 + (", ONE scenario of %d epochs x %d samples @%.1f MS/s cut into epoch ranges over the ranks" if strong
                    else ", %d epochs x %d samples @%.1f MS/s per GPU (one independent scenario per rank)") % (
                     args.epochs, n_samp, rate / 1e6),

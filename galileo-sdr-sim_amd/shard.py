@@ -18,6 +18,27 @@ def rank_workload(rank, n_epochs, n_chan=12, n_slots=16, samples_per_epoch=26000
                                     seed=workloads.SEED + rank, dyn_track=dyn_track)
 
 
+# BASELINE config 5, literally: "8 independent static locations x 300 s sharded across 8 x MI355X".  Eight receiver sites
+# (lat [deg], lon [deg], height [m]); rank r simulates LOCATIONS[r % 8] from the navigation file through the real host
+# front-end (RINEX -> orbits -> ranges -> I/NAV), so the ranks see different satellites and different SV counts.
+LOCATIONS = (
+    (-6.0, 51.0, 100.0),     # the survey's anchor site (Indian Ocean)
+    (45.0, 10.0, 100.0),     # northern Italy: 10 SVs with 20feb2022.rnx
+    (0.0, 0.0, 100.0),       # Gulf of Guinea
+    (60.0, 25.0, 100.0),     # Helsinki
+    (42.3601, -71.0589, 2.0),  # the reference's default (src/main.cpp:179-196)
+    (35.274, 137.014, 100.0),  # the reference's usage example
+    (-33.9, 18.4, 50.0),     # Cape Town
+    (52.0, 4.4, 10.0),       # Delft
+)
+
+
+def rank_location_scenario(scenario_cls, nav_file, rank, duration_s=300.0, start="2022/02/20,12:00:00", n_slots=16):
+    """[n_epochs, n_slots] rows of the static scenario rank `rank` owns in the config-5 split (host front-end)."""
+    llh = LOCATIONS[rank % len(LOCATIONS)]
+    return scenario_cls(nav_file, llh=llh, start=start, duration_s=duration_s, iono_enable=True, n_slots=n_slots).all(), llh
+
+
 def epoch_range(rank, world, n_epochs):
     """Contiguous epoch range [first, first + count) of ONE scenario for rank `rank` (strong scaling, SURVEY.md
     §8e-ii): every rank plans the whole scenario -- the NCO walk over all epochs is what gives it the exact

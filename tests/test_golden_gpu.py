@@ -171,3 +171,19 @@ def test_cli_user_motion_file_md5_equals_oracle(pkg, tmp_path):
     got = np.fromfile(str(out), dtype=np.int16)
     assert got.size == ref_iq.size == 199 * 520000
     assert np.array_equal(got, ref_iq)
+
+
+@pytest.mark.parametrize("rank", [1, 4, 5])
+def test_config5_location_scenarios_hip_equals_oracle(pkg, rank):
+    """BASELINE config 5's split (shard.rank_location_scenario: static site per rank from the RINEX file, 10 / 5 / 6 SVs
+    at these three sites), 40 s each: RINEX -> front-end -> HIP equals the oracle on the same rows; the full 300 s unit
+    is covered for site 0 by test_300s_static_scenario_hip_equals_oracle."""
+    rows, llh = pkg.shard.rank_location_scenario(pkg.Scenario, NAV, rank, duration_s=40.0)
+    assert rows.shape == (399, 16)
+    n_sv = int((rows["prn"][0] > 0).sum())
+    assert n_sv == {1: 10, 4: 5, 5: 6}[rank]
+    ref_iq, ref_st = oracle_run(rows, 260000, 2.6e6)
+    with pkg.SynthEngine(device=0) as eng:
+        iq, st, stats = eng.run_host(rows)
+    assert stats["chain_mismatch"] == 0 and stats["n_active_max"] == n_sv
+    assert hashlib.md5(iq.tobytes()).hexdigest() == hashlib.md5(ref_iq.tobytes()).hexdigest()

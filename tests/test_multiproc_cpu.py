@@ -112,3 +112,17 @@ def test_two_rank_strong_scaling_split(pkg):
     full, _ = oracle_run(pkg.shard.rank_workload(0, 7, 3, 4, 2600), 2600, 2.6e6)
     assert res[0][3] == res[1][3] == 7 * 2600
     assert res[0][4] == res[1][4] == int(full.astype(np.int64).sum()) & 0xFFFFFFFF
+
+
+def test_config5_locations_split(pkg):
+    """BASELINE config 5 literally: rank r owns static site r (shard.LOCATIONS) for the same duration; the sites see
+    different satellites, so the scenarios differ while their size in samples is the same."""
+    nav = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
+    rows = [pkg.shard.rank_location_scenario(pkg.Scenario, nav, r, duration_s=5.0)[0] for r in range(8)]
+    assert all(x.shape == (49, 16) for x in rows)
+    counts = [int((x["prn"][0] > 0).sum()) for x in rows]
+    assert counts == [9, 10, 9, 9, 5, 6, 6, 9]
+    assert len({x.tobytes() for x in rows}) == 8
+    # rank 8 wraps around to site 0
+    again, llh = pkg.shard.rank_location_scenario(pkg.Scenario, nav, 8, duration_s=5.0)
+    assert llh == pkg.shard.LOCATIONS[0] and again.tobytes() == rows[0].tobytes()
