@@ -22,6 +22,8 @@ void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_state_phase(const DevPlan *P, hipStream_t st);
+int galk_scanm_blocks(int legs);
+size_t galk_scanm_bytes(int S, int legs);
 int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
                       const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st);
 }
@@ -67,6 +69,7 @@ void init_tables()
 }
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
+constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block per slot stitches the carrier legs
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
 constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare (17 us of no-op launches)
 
@@ -448,6 +451,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
+    // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
+    const bool multi_scan = LEGS > (size_t)kScanSingleBlockLegs;
+    const size_t o_scanm = multi_scan ? take(galk_scanm_bytes(S, (int)LEGS)) : 0;
 
     const size_t total = off;
     if (total > h->arena_bytes) {
@@ -498,6 +504,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
     P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
+    P.scanm = multi_scan ? (void *)(base + o_scanm) : nullptr;
     P.translate = 1;
     P.tr_e0 = 0;
     P.tr_e1 = E;

@@ -59,6 +59,7 @@ struct DevPlan {
     int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
     long long *tpos;     // global sample index right after that tie step
     double *shift;       // pending translation (new anchor residual - walked anchor residual)
+    void *scanm;         // scratch of the multi-block stitch (long batches), null: single-block k_carr_scan
     int translate;       // 1 normal; 0: always re-walk (the all-walked fallback); 2: GAL_TEST_HOOKS builds only
     int tr_e0, tr_e1;    // legs of epochs outside [tr_e0, tr_e1) are never translated (gal_synth_execute_range)
 

@@ -691,6 +691,340 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
     if (t == 0 && s_rewalk) atomicAdd(&P.ctr[CTR_REWALK_NEXT], s_rewalk);
 }
 
+// ---- The same stitch as k_carr_scan for LONG batches, in 256-thread blocks.  k_carr_scan needs 16 waves and 72 KB of
+// LDS on ONE CU; beside a running k_synth (3 x 168 VGPRs per SIMD, 96 KB of LDS per CU) that means waiting for a CU to
+// drain completely, and with 2999 epochs the walker chain of the next step then takes longer than the synthesis it is
+// supposed to hide behind (2.9 ms against 2.5 ms).  Here the legs of a slot are spread over B blocks of 256 threads
+// (one wave per SIMD: such a block starts as soon as ONE synthesis block retires), SCANM_K legs per thread; what the
+// single block did with two block-wide scans is done with block-local scans plus a serial combine of the B block
+// totals in between (k_scanm_carry1/2) -- five short launches instead of one long one, the same sequential statement.
+#define SCANM_THREADS 256
+#define SCANM_K 8
+
+struct ScanM {  // scratch of the multi-block stitch, per slot: G = B * SCANM_THREADS thread records, B block records
+    int B, G;
+    int *t1_kind; long long *t1_w; double *t1_r;      // [S][G] block-local inclusive claim scan
+    int *b1_kind; long long *b1_w; double *b1_r;      // [S][B] block totals, then (k_scanm_carry1) exclusive carries
+    int *t2_fv, *t2_v, *t2_ic; double *t2_K, *t2_c;   // [S][G] (+ [4] for c) block-local inclusive fold scan
+    int *b2_fv, *b2_v, *b2_ic; double *b2_K, *b2_c;   // [S][B]
+};
+
+__device__ __forceinline__ void scanm_range(const DevPlan &P, int g, int *i0, int *i1)
+{
+    const int a = g * SCANM_K;
+    *i0 = a < P.LEGS ? a : P.LEGS;
+    *i1 = a + SCANM_K < P.LEGS ? a + SCANM_K : P.LEGS;
+}
+
+// phase A: claim summary of my legs + block-local "last one that speaks" scan
+__global__ __launch_bounds__(SCANM_THREADS) void k_scanm_claims(DevPlan P, ScanM M)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    __shared__ int s_kind[SCANM_THREADS];
+    __shared__ long long s_w[SCANM_THREADS];
+    __shared__ double s_r[SCANM_THREADS];
+    const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const int g = b * SCANM_THREADS + t;
+    const double start0 = P.state_in[s].carr_phase;
+    int i0, i1;
+    scanm_range(P, g, &i0, &i1);
+    ClaimState mine = {0, 0, 0.0};
+    for (int i = i0; i < i1; ++i) {
+        const LegRec L = leg_load(P, s, i, start0);
+        if (!L.act) {
+            mine.kind = 2;
+        } else {
+            if (L.root) {
+                mine.kind = 1;
+                mine.w = L.A;
+                mine.r = L.known;
+            }
+            if (L.hw) {
+                mine.kind = 1;
+                mine.w = L.cw;
+                mine.r = L.cr;
+            }
+        }
+    }
+    s_kind[t] = mine.kind;
+    s_w[t] = mine.w;
+    s_r[t] = mine.r;
+    __syncthreads();
+    for (int off = 1; off < SCANM_THREADS; off <<= 1) {
+        int k2 = 0;
+        long long w2 = 0;
+        double r2 = 0.0;
+        const bool take = t >= off && s_kind[t] == 0;
+        if (take) {
+            k2 = s_kind[t - off];
+            w2 = s_w[t - off];
+            r2 = s_r[t - off];
+        }
+        __syncthreads();
+        if (take) {
+            s_kind[t] = k2;
+            s_w[t] = w2;
+            s_r[t] = r2;
+        }
+        __syncthreads();
+    }
+    const size_t o = (size_t)s * M.G + g;
+    M.t1_kind[o] = s_kind[t];
+    M.t1_w[o] = s_w[t];
+    M.t1_r[o] = s_r[t];
+    if (t == SCANM_THREADS - 1) {
+        const size_t ob = (size_t)s * M.B + b;
+        M.b1_kind[ob] = s_kind[t];
+        M.b1_w[ob] = s_w[t];
+        M.b1_r[ob] = s_r[t];
+    }
+}
+
+// phase B: block totals -> exclusive carries (serial over the B blocks of a slot; B is small)
+__global__ void k_scanm_carry1(DevPlan P, ScanM M)
+{
+    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P.S) return;
+    int ck = 0;
+    long long cw = 0;
+    double cr = 0.0;
+    for (int b = 0; b < M.B; ++b) {
+        const size_t ob = (size_t)s * M.B + b;
+        const int k = M.b1_kind[ob];
+        const long long w = M.b1_w[ob];
+        const double r = M.b1_r[ob];
+        M.b1_kind[ob] = ck;
+        M.b1_w[ob] = cw;
+        M.b1_r[ob] = cr;
+        if (k != 0) {
+            ck = k;
+            cw = w;
+            cr = r;
+        }
+    }
+}
+
+__device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, int t)
+{
+    ClaimState lc = {0, 0, 0.0};
+    const size_t ob = (size_t)s * M.B + b;
+    lc.kind = M.b1_kind[ob];
+    lc.w = M.b1_w[ob];
+    lc.r = M.b1_r[ob];
+    if (t > 0) {
+        const size_t o = (size_t)s * M.G + (size_t)b * SCANM_THREADS + t - 1;
+        if (M.t1_kind[o] != 0) {
+            lc.kind = M.t1_kind[o];
+            lc.w = M.t1_w[o];
+            lc.r = M.t1_r[o];
+        }
+    }
+    return lc;
+}
+
+// phase C: fold my legs (segmented AND + D map) + block-local inclusive scan of the folds
+__global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    __shared__ int s_fv[SCANM_THREADS], s_v[SCANM_THREADS], s_ic[SCANM_THREADS];
+    __shared__ double s_K[SCANM_THREADS], s_c[4][SCANM_THREADS];
+    const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const int g = b * SCANM_THREADS + t;
+    const double start0 = P.state_in[s].carr_phase;
+    int i0, i1;
+    scanm_range(P, g, &i0, &i1);
+    {
+        ClaimState lc = scanm_lc0(M, s, b, t);
+        int allok = 1, fv = 0, isconst = 0;
+        double D4[4] = {0.0, GAL_U52, 2.0 * GAL_U52, 3.0 * GAL_U52};
+        for (int i = i0; i < i1; ++i) {
+            const LegRec L = leg_load(P, s, i, start0);
+            const LegOp o = leg_op(P, s, L, lc);
+            if (!o.act) {
+                allok = 0;
+                fv = 1;
+            } else {
+                if (o.root) {
+                    allok = 1;
+                    fv = 1;
+                }
+                allok &= o.link_ok ? 1 : 0;
+            }
+            if (!o.act || o.root || (o.hw && !o.same)) isconst = 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, D4[m]);
+        }
+        s_fv[t] = fv;
+        s_v[t] = allok;
+        s_ic[t] = isconst;
+        s_K[t] = D4[0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s_c[m][t] = D4[m] - (double)m * GAL_U52;
+    }
+    __syncthreads();
+    for (int off = 1; off < SCANM_THREADS; off <<= 1) {
+        const bool has = t >= off;
+        int afv = 0, av = 1;
+        DMap a, bb;
+        a.isconst = 0; a.K = 0.0; a.c[0] = a.c[1] = a.c[2] = a.c[3] = 0.0;
+        if (has) {
+            afv = s_fv[t - off];
+            av = s_v[t - off];
+            a.isconst = s_ic[t - off];
+            a.K = s_K[t - off];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a.c[m] = s_c[m][t - off];
+        }
+        const int bfv = s_fv[t], bv = s_v[t];
+        bb.isconst = s_ic[t];
+        bb.K = s_K[t];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bb.c[m] = s_c[m][t];
+        __syncthreads();
+        if (has) {
+            const DMap r = dmap_combine(a, bb);
+            s_fv[t] = afv | bfv;
+            s_v[t] = bfv ? bv : (av & bv);
+            s_ic[t] = r.isconst;
+            s_K[t] = r.K;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) s_c[m][t] = r.c[m];
+        }
+        __syncthreads();
+    }
+    const size_t o = (size_t)s * M.G + g;
+    M.t2_fv[o] = s_fv[t];
+    M.t2_v[o] = s_v[t];
+    M.t2_ic[o] = s_ic[t];
+    M.t2_K[o] = s_K[t];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) M.t2_c[o * 4 + m] = s_c[m][t];
+    if (t == SCANM_THREADS - 1) {
+        const size_t ob = (size_t)s * M.B + b;
+        M.b2_fv[ob] = s_fv[t];
+        M.b2_v[ob] = s_v[t];
+        M.b2_ic[ob] = s_ic[t];
+        M.b2_K[ob] = s_K[t];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) M.b2_c[ob * 4 + m] = s_c[m][t];
+    }
+}
+
+// phase D: fold totals of the blocks -> exclusive carries (identity in front of block 0)
+__global__ void k_scanm_carry2(DevPlan P, ScanM M)
+{
+    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P.S) return;
+    int cfv = 0, cv = 1;
+    DMap cm;
+    cm.isconst = 0; cm.K = 0.0; cm.c[0] = cm.c[1] = cm.c[2] = cm.c[3] = 0.0;
+    for (int b = 0; b < M.B; ++b) {
+        const size_t ob = (size_t)s * M.B + b;
+        const int bfv = M.b2_fv[ob], bv = M.b2_v[ob];
+        DMap bm;
+        bm.isconst = M.b2_ic[ob];
+        bm.K = M.b2_K[ob];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bm.c[m] = M.b2_c[ob * 4 + m];
+        M.b2_fv[ob] = cfv;
+        M.b2_v[ob] = cv;
+        M.b2_ic[ob] = cm.isconst;
+        M.b2_K[ob] = cm.K;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) M.b2_c[ob * 4 + m] = cm.c[m];
+        const DMap r = dmap_combine(cm, bm);
+        cv = bfv ? bv : (cv & bv);
+        cfv = cfv | bfv;
+        cm = r;
+    }
+}
+
+// phase E: replay my legs with the true carries and apply (sweep 3 of k_carr_scan)
+__global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM M)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    __shared__ int s_unver, s_rewalk;
+    const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const int g = b * SCANM_THREADS + t;
+    if (t == 0) {
+        s_unver = 0;
+        s_rewalk = 0;
+    }
+    __syncthreads();
+    const double start0 = P.state_in[s].carr_phase;
+    int i0, i1;
+    scanm_range(P, g, &i0, &i1);
+    // prefix in front of my legs = (carry of my block) then (local inclusive scan of the thread before me)
+    const size_t ob = (size_t)s * M.B + b;
+    int pfv = M.b2_fv[ob], pv = M.b2_v[ob];
+    DMap pm;
+    pm.isconst = M.b2_ic[ob];
+    pm.K = M.b2_K[ob];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pm.c[m] = M.b2_c[ob * 4 + m];
+    if (t > 0) {
+        const size_t o = (size_t)s * M.G + g - 1;
+        const int bfv = M.t2_fv[o], bv = M.t2_v[o];
+        DMap bm;
+        bm.isconst = M.t2_ic[o];
+        bm.K = M.t2_K[o];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bm.c[m] = M.t2_c[o * 4 + m];
+        const DMap r = dmap_combine(pm, bm);
+        pv = bfv ? bv : (pv & bv);
+        pfv = pfv | bfv;
+        pm = r;
+    }
+    ClaimState lc = scanm_lc0(M, s, b, t);
+    int allok = pfv ? pv : 0;  // nothing is verified before the first root
+    double D = pm.isconst ? pm.K : pm.c[0];  // the prefix map applied to D = 0
+    int unver = 0, rewalk = 0;
+    for (int i = i0; i < i1; ++i) {
+        const LegRec L = leg_load(P, s, i, start0);
+        const LegOp o = leg_op(P, s, L, lc);
+        if (!o.act) {
+            allok = 0;
+            D = 0.0;
+            continue;
+        }
+        if (o.root) {
+            allok = 1;
+            D = 0.0;
+        }
+        allok &= o.link_ok ? 1 : 0;
+        const double nr = o.base + D;
+        const size_t li = (size_t)s * P.LEGS + i;
+        if (allok) {
+            P.verified[li] = 1;
+        } else {
+            ++unver;
+            if (o.have && (L.aw != o.nw || d2u(L.ar) != d2u(nr))) {
+                const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
+                const int el = i / P.W;
+                const bool tr = P.translate && el >= P.tr_e0 && el < P.tr_e1 && L.aw == o.nw &&
+                                __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
+                P.anc_w[li] = o.nw;
+                P.anc_r[li] = nr;
+                P.dirty[li] = tr ? 2 : 1;
+                if (tr) P.shift[li] = dl;
+                rewalk += tr ? 0 : 1;
+            }
+            rewalk += o.have ? 0 : 1;
+        }
+        D = leg_d_out(o, D);
+    }
+    if (unver) atomicAdd(&s_unver, unver);
+    if (rewalk) atomicAdd(&s_rewalk, rewalk);
+    __syncthreads();
+    if (t == 0 && s_unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], s_unver);
+    if (t == 0 && s_rewalk) atomicAdd(&P.ctr[CTR_REWALK_NEXT], s_rewalk);
+}
+
 // after every slot's scan: publish the count the next pass looks at.  When the stitcher asked for translations
 // only (no leg has to be walked again), the translated claims are by construction the anchors it predicted
 // for their successors, so the next pass completes the chain and its scan is skipped (CTR_MODE); what stands
@@ -1446,9 +1780,42 @@ extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t s
     hipLaunchKernelGGL(k_walk_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P, first);
 }
 
+extern "C" int galk_scanm_blocks(int legs)
+{
+    return (legs + SCANM_THREADS * SCANM_K - 1) / (SCANM_THREADS * SCANM_K);
+}
+
+// scratch: the multi-block stitch's per-thread and per-block records (bytes for S slots; see ScanM)
+extern "C" size_t galk_scanm_bytes(int S, int legs)
+{
+    const size_t B = (size_t)galk_scanm_blocks(legs), G = B * SCANM_THREADS;
+    return (size_t)S * (G * (4 + 8 + 8 + 4 + 4 + 4 + 8 + 32) + B * (4 + 8 + 8 + 4 + 4 + 4 + 8 + 32)) + 4096;
+}
+
 extern "C" void galk_launch_carr_scan(const DevPlan *P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P);
+    if (P->scanm == nullptr) {  // short batches: one 1024-thread block per slot
+        hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P);
+    } else {
+        ScanM M;
+        M.B = galk_scanm_blocks(P->LEGS);
+        M.G = M.B * SCANM_THREADS;
+        const size_t SG = (size_t)P->S * M.G, SB = (size_t)P->S * M.B;
+        char *p = (char *)P->scanm;
+        auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return q; };
+        M.t1_w = (long long *)take(SG * 8); M.t1_r = (double *)take(SG * 8); M.t2_K = (double *)take(SG * 8);
+        M.t2_c = (double *)take(SG * 32);
+        M.b1_w = (long long *)take(SB * 8); M.b1_r = (double *)take(SB * 8); M.b2_K = (double *)take(SB * 8);
+        M.b2_c = (double *)take(SB * 32);
+        M.t1_kind = (int *)take(SG * 4); M.t2_fv = (int *)take(SG * 4); M.t2_v = (int *)take(SG * 4); M.t2_ic = (int *)take(SG * 4);
+        M.b1_kind = (int *)take(SB * 4); M.b2_fv = (int *)take(SB * 4); M.b2_v = (int *)take(SB * 4); M.b2_ic = (int *)take(SB * 4);
+        const dim3 grid(M.B, P->S), blk(SCANM_THREADS);
+        hipLaunchKernelGGL(k_scanm_claims, grid, blk, 0, st, *P, M);
+        hipLaunchKernelGGL(k_scanm_carry1, dim3(1), dim3(64), 0, st, *P, M);
+        hipLaunchKernelGGL(k_scanm_fold, grid, blk, 0, st, *P, M);
+        hipLaunchKernelGGL(k_scanm_carry2, dim3(1), dim3(64), 0, st, *P, M);
+        hipLaunchKernelGGL(k_scanm_apply, grid, blk, 0, st, *P, M);
+    }
     hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
 }
 
