@@ -696,15 +696,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 // drain completely, and with 2999 epochs the walker chain of the next step then takes longer than the synthesis it is
 // supposed to hide behind (2.9 ms against 2.5 ms).  Here the legs of a slot are spread over B blocks of 256 threads
 // (one wave per SIMD: such a block starts as soon as ONE synthesis block retires), SCANM_K legs per thread; what the
-// single block did with two block-wide scans is done with block-local scans plus a serial combine of the B block
-// totals in between (k_scanm_carry1/2) -- five short launches instead of one long one, the same sequential statement.
+// single block did with two block-wide scans is done with block-local scans plus a serial fold of the (few) block
+// totals in front of each block -- three short launches instead of one long one, the same sequential statement.
 #define SCANM_THREADS 256
-#define SCANM_K 8
+#define SCANM_K 4
 
 struct ScanM {  // scratch of the multi-block stitch, per slot: G = B * SCANM_THREADS thread records, B block records
     int B, G;
     int *t1_kind; long long *t1_w; double *t1_r;      // [S][G] block-local inclusive claim scan
-    int *b1_kind; long long *b1_w; double *b1_r;      // [S][B] block totals, then (k_scanm_carry1) exclusive carries
+    int *b1_kind; long long *b1_w; double *b1_r;      // [S][B] block totals
     int *t2_fv, *t2_v, *t2_ic; double *t2_K, *t2_c;   // [S][G] (+ [4] for c) block-local inclusive fold scan
     int *b2_fv, *b2_v, *b2_ic; double *b2_K, *b2_c;   // [S][B]
 };
@@ -781,38 +781,26 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_claims(DevPlan P, ScanM
     }
 }
 
-// phase B: block totals -> exclusive carries (serial over the B blocks of a slot; B is small)
-__global__ void k_scanm_carry1(DevPlan P, ScanM M)
+// claim carry in front of block b: the last block before it whose total says anything (B is small: one thread walks
+// the totals, the block shares the result)
+__device__ __forceinline__ ClaimState scanm_claim_carry(const ScanM &M, int s, int b)
 {
-    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P.S) return;
-    int ck = 0;
-    long long cw = 0;
-    double cr = 0.0;
-    for (int b = 0; b < M.B; ++b) {
-        const size_t ob = (size_t)s * M.B + b;
+    ClaimState c = {0, 0, 0.0};
+    for (int bb = 0; bb < b; ++bb) {
+        const size_t ob = (size_t)s * M.B + bb;
         const int k = M.b1_kind[ob];
-        const long long w = M.b1_w[ob];
-        const double r = M.b1_r[ob];
-        M.b1_kind[ob] = ck;
-        M.b1_w[ob] = cw;
-        M.b1_r[ob] = cr;
         if (k != 0) {
-            ck = k;
-            cw = w;
-            cr = r;
+            c.kind = k;
+            c.w = M.b1_w[ob];
+            c.r = M.b1_r[ob];
         }
     }
+    return c;
 }
 
-__device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, int t)
+__device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, int t, const ClaimState &carry)
 {
-    ClaimState lc = {0, 0, 0.0};
-    const size_t ob = (size_t)s * M.B + b;
-    lc.kind = M.b1_kind[ob];
-    lc.w = M.b1_w[ob];
-    lc.r = M.b1_r[ob];
+    ClaimState lc = carry;
     if (t > 0) {
         const size_t o = (size_t)s * M.G + (size_t)b * SCANM_THREADS + t - 1;
         if (M.t1_kind[o] != 0) {
@@ -824,20 +812,23 @@ __device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, in
     return lc;
 }
 
-// phase C: fold my legs (segmented AND + D map) + block-local inclusive scan of the folds
+// phase B: fold my legs (segmented AND + D map) + block-local inclusive scan of the folds
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M)
 {
     __builtin_amdgcn_s_setprio(3);
     if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
     __shared__ int s_fv[SCANM_THREADS], s_v[SCANM_THREADS], s_ic[SCANM_THREADS];
     __shared__ double s_K[SCANM_THREADS], s_c[4][SCANM_THREADS];
+    __shared__ ClaimState s_carry;
     const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     const int g = b * SCANM_THREADS + t;
     const double start0 = P.state_in[s].carr_phase;
     int i0, i1;
     scanm_range(P, g, &i0, &i1);
+    if (t == 0) s_carry = scanm_claim_carry(M, s, b);
+    __syncthreads();
     {
-        ClaimState lc = scanm_lc0(M, s, b, t);
+        ClaimState lc = scanm_lc0(M, s, b, t, s_carry);
         int allok = 1, fv = 0, isconst = 0;
         double D4[4] = {0.0, GAL_U52, 2.0 * GAL_U52, 3.0 * GAL_U52};
         for (int i = i0; i < i1; ++i) {
@@ -913,37 +904,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M
     }
 }
 
-// phase D: fold totals of the blocks -> exclusive carries (identity in front of block 0)
-__global__ void k_scanm_carry2(DevPlan P, ScanM M)
-{
-    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P.S) return;
-    int cfv = 0, cv = 1;
-    DMap cm;
-    cm.isconst = 0; cm.K = 0.0; cm.c[0] = cm.c[1] = cm.c[2] = cm.c[3] = 0.0;
-    for (int b = 0; b < M.B; ++b) {
-        const size_t ob = (size_t)s * M.B + b;
-        const int bfv = M.b2_fv[ob], bv = M.b2_v[ob];
-        DMap bm;
-        bm.isconst = M.b2_ic[ob];
-        bm.K = M.b2_K[ob];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) bm.c[m] = M.b2_c[ob * 4 + m];
-        M.b2_fv[ob] = cfv;
-        M.b2_v[ob] = cv;
-        M.b2_ic[ob] = cm.isconst;
-        M.b2_K[ob] = cm.K;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) M.b2_c[ob * 4 + m] = cm.c[m];
-        const DMap r = dmap_combine(cm, bm);
-        cv = bfv ? bv : (cv & bv);
-        cfv = cfv | bfv;
-        cm = r;
-    }
-}
-
-// phase E: replay my legs with the true carries and apply (sweep 3 of k_carr_scan)
+// phase C: replay my legs with the true carries and apply (sweep 3 of k_carr_scan)
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM M)
 {
     __builtin_amdgcn_s_setprio(3);
@@ -959,14 +920,40 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
     const double start0 = P.state_in[s].carr_phase;
     int i0, i1;
     scanm_range(P, g, &i0, &i1);
-    // prefix in front of my legs = (carry of my block) then (local inclusive scan of the thread before me)
-    const size_t ob = (size_t)s * M.B + b;
-    int pfv = M.b2_fv[ob], pv = M.b2_v[ob];
-    DMap pm;
-    pm.isconst = M.b2_ic[ob];
-    pm.K = M.b2_K[ob];
+    // carries in front of my block (thread 0 folds the totals of the blocks before it: B is small)
+    __shared__ ClaimState s_carry;
+    __shared__ int s_cfv, s_cv, s_cic;
+    __shared__ double s_cK, s_cc[4];
+    if (t == 0) {
+        s_carry = scanm_claim_carry(M, s, b);
+        int cfv = 0, cv = 1;
+        DMap cm;
+        cm.isconst = 0; cm.K = 0.0; cm.c[0] = cm.c[1] = cm.c[2] = cm.c[3] = 0.0;
+        for (int bb = 0; bb < b; ++bb) {
+            const size_t ob = (size_t)s * M.B + bb;
+            const int bfv = M.b2_fv[ob], bv = M.b2_v[ob];
+            DMap bm;
+            bm.isconst = M.b2_ic[ob];
+            bm.K = M.b2_K[ob];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pm.c[m] = M.b2_c[ob * 4 + m];
+            for (int m = 0; m < 4; ++m) bm.c[m] = M.b2_c[ob * 4 + m];
+            const DMap r = dmap_combine(cm, bm);
+            cv = bfv ? bv : (cv & bv);
+            cfv = cfv | bfv;
+            cm = r;
+        }
+        s_cfv = cfv; s_cv = cv; s_cic = cm.isconst; s_cK = cm.K;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s_cc[m] = cm.c[m];
+    }
+    __syncthreads();
+    // prefix in front of my legs = (carry of my block) then (local inclusive scan of the thread before me)
+    int pfv = s_cfv, pv = s_cv;
+    DMap pm;
+    pm.isconst = s_cic;
+    pm.K = s_cK;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pm.c[m] = s_cc[m];
     if (t > 0) {
         const size_t o = (size_t)s * M.G + g - 1;
         const int bfv = M.t2_fv[o], bv = M.t2_v[o];
@@ -980,7 +967,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
         pfv = pfv | bfv;
         pm = r;
     }
-    ClaimState lc = scanm_lc0(M, s, b, t);
+    ClaimState lc = scanm_lc0(M, s, b, t, s_carry);
     int allok = pfv ? pv : 0;  // nothing is verified before the first root
     double D = pm.isconst ? pm.K : pm.c[0];  // the prefix map applied to D = 0
     int unver = 0, rewalk = 0;
@@ -1811,9 +1798,7 @@ extern "C" void galk_launch_carr_scan(const DevPlan *P, hipStream_t st)
         M.b1_kind = (int *)take(SB * 4); M.b2_fv = (int *)take(SB * 4); M.b2_v = (int *)take(SB * 4); M.b2_ic = (int *)take(SB * 4);
         const dim3 grid(M.B, P->S), blk(SCANM_THREADS);
         hipLaunchKernelGGL(k_scanm_claims, grid, blk, 0, st, *P, M);
-        hipLaunchKernelGGL(k_scanm_carry1, dim3(1), dim3(64), 0, st, *P, M);
         hipLaunchKernelGGL(k_scanm_fold, grid, blk, 0, st, *P, M);
-        hipLaunchKernelGGL(k_scanm_carry2, dim3(1), dim3(64), 0, st, *P, M);
         hipLaunchKernelGGL(k_scanm_apply, grid, blk, 0, st, *P, M);
     }
     hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
