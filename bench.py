@@ -379,6 +379,7 @@ def main():
                                                           and e_count == args.epochs) else (None, None)
         achieved = 4.0 * samples_per_step / (avg_synth_ms * 1e-3) / 1e9 if avg_synth_ms > 0 else 0.0
         step_ms = elapsed / args.steps * 1e3
+        step_achieved = 4.0 * samples_per_step / (step_ms * 1e-3) / 1e9
         prof_ms, prof_src = profiled_kernel_ms() if traffic is not None else (None, None)
         line = {
             "metric": METRIC,
@@ -414,21 +415,28 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_synth<%d,false>%s" % (min(args.channels, 12), " (+ accumulate launch)" if args.channels > 12 else ""),
-                "achieved": round(achieved, 2),
+                # sustained: launches x algorithmic bytes over the timed region.  With two handles in flight consecutive
+                # k_synth launches OVERLAP (the second round of blocks of one runs beside the first round of the next), so
+                # the per-launch intervals below add up to more than the wall time; they are reported next to it
+                "achieved": round(step_achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "frac_uses": "avg_kernel_ms: HIP events around k_synth on its stream inside the timed region; with two "
-                             "handles in flight the interval contains the overlap with the other handle's kernel",
+                "frac": round(step_achieved / HBM_PEAK_GBS, 5),
+                "frac_uses": "timed region / launches (ms_per_step): consecutive launches overlap, so this is the sustained "
+                             "figure; per-launch intervals: overlapped_kernel_ms (HIP events in the timed region, agrees with "
+                             "rocprofv3), standalone_kernel_ms (one handle, no co-running walker)",
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "traffic_is_live": False,
+                "overlapped_kernel_ms": round(avg_synth_ms, 4),
+                "overlapped_achieved": round(achieved, 2),
+                "overlapped_frac": round(achieved / HBM_PEAK_GBS, 5),
                 "avg_kernel_ms": round(avg_synth_ms, 4),
                 "rocprof_avg_kernel_ms": prof_ms,
                 "rocprof_source": prof_src,
                 "rocprof_is_live": False,
-                "step_derived": {"ms": round(step_ms, 4), "achieved": round(4.0 * samples_per_step / (step_ms * 1e-3) / 1e9, 2),
-                                 "frac": round(4.0 * samples_per_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "step_derived": {"ms": round(step_ms, 4), "achieved": round(step_achieved, 2),
+                                 "frac": round(step_achieved / HBM_PEAK_GBS, 5)},
                 "standalone_kernel_ms": round(solo_ms, 4) if solo_ms else None,
                 "standalone_achieved": round(4.0 * samples_per_step / (solo_ms * 1e-3) / 1e9, 2) if solo_ms else None,
                 "standalone_frac": round(4.0 * samples_per_step / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if solo_ms else None,
