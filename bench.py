@@ -137,7 +137,7 @@ def leg_file_sink(seconds=120):
         try:
             t0 = time.perf_counter()
             res = subprocess.run([exe, "-e", nav, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", str(seconds), "-U", "1",
-                                  "-b", "1", "-o", sink], capture_output=True, text=True, timeout=300)
+                                  "-b", "1", "-P", "0", "-o", sink], capture_output=True, text=True, timeout=300)
             wall = time.perf_counter() - t0
             m = re.search(r"Process time = ([0-9.]+)", res.stderr)
             n_samples = (int(seconds * 10 + 0.5) - 1) * 260000

@@ -89,10 +89,11 @@ void poll_live_position(gal_scen *s)
     if (s->udp_fd < 0) return;
     double llh[3];
     bool got = false;
-    for (;;) {
+    for (;;) {  // drain the queue: the last well-formed datagram counts
         double buf[3];
-        const ssize_t n = recv(s->udp_fd, buf, sizeof(buf), MSG_DONTWAIT);
-        if (n != (ssize_t)sizeof(buf)) break;
+        const ssize_t n = recv(s->udp_fd, buf, sizeof(buf), MSG_DONTWAIT | MSG_TRUNC);  // MSG_TRUNC: the real length
+        if (n < 0) break;                          // nothing (more) waiting
+        if (n != (ssize_t)sizeof(buf)) continue;   // not a position update: ignored
         memcpy(llh, buf, sizeof(llh));
         got = true;
     }

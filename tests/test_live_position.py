@@ -29,6 +29,7 @@ def test_udp_position_update_takes_effect_at_the_next_epoch(pkg):
     a = live.next(20)
     tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
     tx.sendto(struct.pack("<3d", -7.0, 50.0, 10.0), ("127.0.0.1", port))  # superseded: only the last datagram counts
+    tx.sendto(b"junk in between", ("127.0.0.1", port))                      # skipped, the queue is drained past it
     tx.sendto(struct.pack("<3d", *there), ("127.0.0.1", port))
     import time
     time.sleep(0.05)
@@ -57,6 +58,7 @@ def test_malformed_datagrams_are_ignored(pkg):
     tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
     tx.sendto(b"hello", ("127.0.0.1", port))
     tx.sendto(struct.pack("<2d", 1.0, 2.0), ("127.0.0.1", port))
+    tx.sendto(struct.pack("<4d", 10.0, 20.0, 30.0, 40.0), ("127.0.0.1", port))  # too long: not truncated into a position
     import time
     time.sleep(0.05)
     rows = sc.all()
