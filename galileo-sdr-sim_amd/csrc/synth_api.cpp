@@ -452,7 +452,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
     // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
-    const bool multi_scan = LEGS > (size_t)kScanSingleBlockLegs;
+    size_t single_legs = (size_t)kScanSingleBlockLegs;
+#ifdef GAL_TEST_HOOKS
+    // lets the randomised soak (small batches) run the long-batch stitcher: GAL_SCAN_SINGLE_LEGS=0
+    if (const char *env = getenv("GAL_SCAN_SINGLE_LEGS")) single_legs = (size_t)atol(env);
+#endif
+    const bool multi_scan = LEGS > single_legs;
     const size_t o_scanm = multi_scan ? take(galk_scanm_bytes(S, (int)LEGS)) : 0;
 
     const size_t total = off;

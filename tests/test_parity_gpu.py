@@ -496,3 +496,30 @@ def test_m_dyn_full_size_properties(pkg):
     ref_tail, ref_st = oracle_run(tail, n, rate, st_c)
     assert np.array_equal(outs[0][2995 * n * 2:].cpu().numpy(), ref_tail)
     assert np.array_equal(ref_st["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+
+
+def test_long_batch_stitcher_on_small_batches(pkg, monkeypatch):
+    """Batches with more than 4096 carrier legs per slot are stitched by the multi-block kernels (k_scanm_*) instead of
+    the single-block k_carr_scan -- the same sequential statement.  The full-size tests cover it at 1199 / 2999 epochs;
+    here the fault-injection build forces it onto small random batches (channels coming and going, idle epochs, sign
+    changes, tie-prone steps), where every corner of the stitch is hit quickly."""
+    import importlib.util
+    import os
+
+    monkeypatch.setenv("GAL_SCAN_SINGLE_LEGS", "0")  # honoured by the GAL_TEST_HOOKS build only
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(77)
+    for c in range(60):
+        p, n_samp, rate, chunk = fz.random_case(rng, big=(c % 15 == 14))
+        with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0, chunk_samples=chunk,
+                             test_hooks=True) as eng:
+            iq, st, stats = eng.run_host(p)
+            fallbacks = eng.walk_counts()[2]
+        ref_iq, ref_st = oracle_run(p, n_samp, rate)
+        assert stats["chain_mismatch"] == 0 and fallbacks == 0, c
+        assert np.array_equal(iq, ref_iq), c
+        act = ref_st["prn"] > 0
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64)), c

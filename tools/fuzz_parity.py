@@ -2,7 +2,8 @@
 """Randomised parity soak on the GPU: HIP path vs the oracle, bit for bit, over randomly shaped batches
 (slots, channels, epoch length, sample rate, chunking, Doppler incl. tiny / zero / sign flips / few-bit steps,
 channels appearing, vanishing and being re-allocated, symbol counters near the page flip, code phases near the
-wrap).  Test infrastructure: uses the oracle as the checker.   python tools/fuzz_parity.py [n_cases] [seed] [big]"""
+wrap).  Test infrastructure: uses the oracle as the checker.   python tools/fuzz_parity.py [n_cases] [seed] [big]
+GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_SINGLE_LEGS=0: the long-batch stitcher on every batch)."""
 import os
 import sys
 import time
@@ -89,7 +90,7 @@ def main():
         p, n_samp, rate, chunk = random_case(rng, big)
         try:
             with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0,
-                                 chunk_samples=chunk) as eng:
+                                 chunk_samples=chunk, test_hooks=bool(os.environ.get("GAL_FUZZ_HOOKS"))) as eng:
                 cut = int(rng.integers(1, p.shape[0])) if (p.shape[0] > 1 and rng.random() < 0.4) else 0
                 if cut:  # the same run in two calls, the channel state carried by the caller
                     iq1, st1, stats = eng.run_host(p[:cut])
