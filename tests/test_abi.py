@@ -66,3 +66,22 @@ def test_product_never_touches_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".inc")) or fn == "Makefile":
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle_binding" not in txt and "galsyn_oracle" not in txt, fn
+
+
+def test_headers_compile_as_c_and_link(pkg, tmp_path):
+    """A plain C99 translation unit includes both headers, checks the layouts with _Static_assert, links against the two
+    libraries and uses the entry points that need no GPU (tests/abi_c/abi_check.c)."""
+    import subprocess
+
+    exe = tmp_path / "abi_check"
+    pkg_dir = os.path.join(ROOT, "galileo-sdr-sim_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "abi_c", "abi_check.c"), "-o", str(exe), "-L", pkg_dir, "-lgalsynth",
+                        "-lgalscen", "-Wl,-rpath," + pkg_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nav = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
+    r = subprocess.run([str(exe), nav], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gfx950" in r.stdout and "active channels 9" in r.stdout
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
