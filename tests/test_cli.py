@@ -113,3 +113,21 @@ def test_cli_time_overwrite(pkg, tmp_path):
     r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", "now", "-d", "1", "-P", "0", "-o", "/dev/null"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_sigint_finishes_the_current_epoch(tmp_path):
+    """SIGINT: the reference's handler lets the generator finish the epoch in flight and closes the file
+    (src/main.cpp sigint_handler); here: exit status 0 and a file that ends on an epoch boundary, shorter than asked."""
+    import signal
+    import time
+
+    out = tmp_path / "int.ishort"
+    p = subprocess.Popen([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "8", "-r", "-P", "0", "-o",
+                          str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    time.sleep(2.0)
+    p.send_signal(signal.SIGINT)
+    p.wait(timeout=30)
+    assert p.returncode == 0, p.stderr.read()
+    size = os.path.getsize(str(out))
+    assert size % (260000 * 4) == 0 and 5 * 260000 * 4 <= size < 79 * 260000 * 4
