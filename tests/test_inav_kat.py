@@ -206,3 +206,64 @@ def test_channel_coding_of_the_raw_page(pkg, scen):
         sym = pkg.unpack_page(scen.inav_page(9, len(ephs) // 2, 2198, float(sec)))
         want = np.concatenate([_icd_encode(raw[:120]), _icd_encode(raw[120:])])
         assert np.array_equal(sym, want), sec
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Second pin, against reference CODE rather than reference-held data: utils/generate_frame.cpp is a stand-alone
+# program of the reference (standard headers only) whose main() packs I/NAV word 2 of a hard-coded ephemeris with
+# the reference's own double -> scaled-integer routines and prints the four 32-bit words.  oracle/Makefile compiles
+# that file unmodified where it lies (oracle/_ref/ref_generate_frame); what it prints is committed as
+# tests/golden/ref_generate_frame.json by tools/make_golden_refutil.py.
+REFUTIL = os.path.join(G, "ref_generate_frame.json")
+
+
+def _rinex_record(svid, y, mo, d, h, mi, s, e, week, toe):
+    def f(v):
+        return "%19.12E" % v
+    rows = [
+        "E%02d %04d %02d %02d %02d %02d %02d" % (svid, y, mo, d, h, mi, s) + f(e["af0"]) + f(e["af1"]) + f(e["af2"]),
+        "    " + f(e["iodnav"]) + f(e["crs"]) + f(e["deltan"]) + f(e["m0"]),
+        "    " + f(e["cuc"]) + f(e["ecc"]) + f(e["cus"]) + f(e["sqrta"]),
+        "    " + f(toe) + f(e["cic"]) + f(e["omg0"]) + f(e["cis"]),
+        "    " + f(e["inc0"]) + f(e["crc"]) + f(e["aop"]) + f(e["omgdot"]),
+        "    " + f(e["idot"]) + f(517.0) + f(float(week)) + f(0.0),
+        "    " + f(3.12) + f(0.0) + f(e["bgde5a"]) + f(e["bgde5b"]),
+        "    " + f(toe + 660.0),
+    ]
+    return "\n".join(rows) + "\n"
+
+
+def test_word2_equals_the_compiled_reference_utility(pkg, tmp_path):
+    import json
+    import subprocess
+
+    fx = json.load(open(REFUTIL))
+    e = fx["ephemeris"]
+    # header of the day's file (iono / GST-UTC lines are not part of word 2), three records 10 min apart
+    head = "".join(line for line in open(NAV).read().splitlines(True)[:7])
+    body = ""
+    for k in range(3):
+        # toe 459600 s = Friday 07:40:00 of Galileo week 2198 (2022-02-25)
+        body += _rinex_record(1, 2022, 2, 25, 7, 40 + 10 * k, 0, e, 2198, float(e["toe"] + 600 * k))
+    nav = tmp_path / "refutil.rnx"
+    nav.write_text(head + body)
+    scen = pkg.Scenario(str(nav), llh=(-6, 51, 100), start="2022/02/25,07:40:00", duration_s=1)
+    assert scen.ephemerides(1)[0][0] == e["iodnav"]
+    page = scen.inav_raw(1, 0, 2198, 459600.0)  # slot 0 of the 60 s cycle carries word 2
+    w = _word128(page)
+    words = [int("".join(map(str, w[32 * i:32 * i + 32])), 2) for i in range(4)]
+    # field view of the same word, so a failure says which parameter
+    wt, made = _fields(page)
+    assert wt == 2 and made["iodnav"] == 126 and made["reserved"] == 0
+    # The utility drops iDot: it writes `IntValue >> 16` of a 14-bit quantity into the field
+    # (utils/generate_frame.cpp:248-249), i.e. always 0 / -1, while the simulator itself writes the 14 low bits
+    # (src/inav-msg.cpp:253-255 -- the layout the recorded broadcast pages confirm above).  So: the 112 bits in front
+    # of iDot (type, IODnav, Omega0, i0, omega) must equal the utility's print-out, and iDot is checked by value.
+    assert made["idot"] == round(e["idot"] / np.pi * 2.0 ** 43) == 1228
+    words[3] &= 0xFFFF0000
+    printed = "".join("%X" % x for x in words)  # std::hex << std::uppercase, no padding (utils/generate_frame.cpp:303)
+    assert printed == fx["printed"], (printed, fx["printed"])
+    # in the build container the compiled reference utility is present: its live output is the fixture
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "ref_generate_frame")
+    if os.path.exists(exe):
+        assert subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip() == fx["printed"]
