@@ -234,6 +234,11 @@ def measured_traffic():
         return None, None
 
 
+# A/B experiments only (tools/): GAL_BENCH_HOOKS=1 runs the GAL_TEST_HOOKS build of the library, whose environment
+# switches (GAL_SYNTH_RW=0 ...) select code paths; such a line carries "hooks_build": true and is never a result.
+HOOKS_BUILD = bool(os.environ.get("GAL_BENCH_HOOKS"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,7 +318,8 @@ def main():
     engines, outs, streams = [], [], []
     for k in range(depth):
         eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
-                              chunk_samples=args.chunk, flags=pkg.synth.GAL_CFG_CBOC if args.signal == "cboc" else 0)
+                              chunk_samples=args.chunk, flags=pkg.synth.GAL_CFG_CBOC if args.signal == "cboc" else 0,
+                              test_hooks=HOOKS_BUILD)
         st = torch.cuda.Stream()
         eng.set_stream(st.cuda_stream)
         eng.plan(params)  # inputs resident in HBM before the timed region
@@ -409,7 +415,7 @@ def main():
                 "chunk_samples": stats["chunk_samples"],
                 "walk_passes": stats["walk_passes"],
                 "chain_mismatch": stats["chain_mismatch"],
-                "pipeline_depth": depth,
+                "pipeline_depth": depth, **({"hooks_build": True} if HOOKS_BUILD else {}),
                 "output_checksum": "%08x" % chk,
             },
             "roofline": {

@@ -311,6 +311,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     int nact_max = 0;
     std::vector<int> cur_prn(S, 0);
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
+    bool rw_ok = true;  // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel
+    const double delt = 1.0 / h->cfg.sample_rate;
     for (int e = 0; e < E; ++e) {
         int n = 0;
         for (int s = 0; s < S; ++s) {
@@ -341,6 +343,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
+            {
+                const double cs2 = 2.0 * (r.f_code * delt);
+                rw_ok = rw_ok && cs2 >= 0.74 && cs2 < 0.9999;
+            }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;
         }
@@ -522,6 +528,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
+    P.rw = (rw_ok && P.signal == 0) ? 1 : 0;
+#ifdef GAL_TEST_HOOKS
+    if (const char *env = getenv("GAL_SYNTH_RW")) P.rw = P.rw && atoi(env) != 0;  // 0: classic windows (A/B runs)
+#endif
 
     // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
     // goes over in one copy; one memset clears what must start at zero; one sync at the end: after plan() the batch

@@ -1137,6 +1137,10 @@ __global__ void k_state_phase(DevPlan P)
 #define GAL_ACT_ROW 16  // bytes per epoch in the active-position lists (<= 12 entries used, zero-padded)
 #define STR_WORDS 512
 #define STR_PITCH 513  // LDS words per channel: one pad word (= word 0) so that "the next word" never wraps
+#define RW_BINS 128        // bins of the group-start fraction (k_synth<.., RW = 1>)
+#define RW_BIN_PITCH 130   // 129 entries used: a fraction that rounds to 1.0f lands in the (undecidable) entry 128
+#define RW_EDGE 9.5367431640625e-07f    // 2^-20: a threshold this close outside a bin is registered in the bin as well
+#define RW_DELTA 2.384185791015625e-07f  // 2^-22: a fraction this close to its threshold is not decided by the table
 #ifndef SYN_WAVES
 #define SYN_WAVES 3  // waves per SIMD the register allocation aims at (LDS allows 4 blocks per CU)
 #endif
@@ -1198,7 +1202,23 @@ struct ChanGroup {  // live only inside one 16-sample group
 };
 
 // sg * 0x55555555: 0, 0x5555.., 0xAAAA.., 0xFFFF.. = the XOR mask of the sign pair on all 16 half chips
-#define GAL_SIGN_MASK(sg) ((sg) * 0x55555555u)
+// (a 24-bit multiply and a shift-or: v_mul_lo_u32 is a quarter-rate instruction)
+__device__ __forceinline__ uint32_t gal_sign_mask(const uint32_t sg)
+{
+    const uint32_t m = __umul24(sg, 0x555555u);
+    uint32_t d;  // (asm: the combiner otherwise folds the shift into a second, 32-bit multiply)
+    asm("v_lshl_or_b32 %0, %1, 16, %1" : "=v"(d) : "v"(m));
+    return d;
+}
+#define GAL_SIGN_MASK(sg) gal_sign_mask(sg)
+
+// (m & a) | (~m & b) as the one instruction it is (the compiler expands the expression to not / and / and / or)
+__device__ __forceinline__ uint32_t gal_bfi(const uint32_t m, const uint32_t a, const uint32_t b)
+{
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+}
 
 // (non-zero, negative-if-non-zero) bit pairs -> two's-complement 2-bit fields 00 / 01 / 11 = 0 / +1 / -1: the upper
 // bit survives only where the lower one is set
@@ -1216,6 +1236,61 @@ __device__ __forceinline__ void group_begin_fast(const ChanState &c, ChanGroup &
     const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
     g.W = window_signed(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)ic0 << 1) ^ mask);  // v_alignbit uses shift[4:0]
     g.m = -2 * ic0;
+}
+
+// RESAMPLED window (k_synth<.., RW = 1>).  Sample u of a fast group reads half chip ic0 + g(u), g(u) = floor(f + u s),
+// f = frac(y) at the group start, s = the code step in half chips (0.74 <= s < 1 here): g advances by one per sample
+// except at <= 4 HOLDS, where two samples share a half chip.  Instead of evaluating (int)y, a shift-add and a
+// field extract per SAMPLE, the group start looks the hold positions up and spreads the window once,
+//     X = window with field u = half chip of SAMPLE u:   X <- (X & ~M_d) | ((X << 2) & M_d),  M_d = ~0 << 2 u_d,
+// after which a sample costs one v_bfe_i32 with a constant offset and the code NCO advances once per group
+// (GAL_ADV).  The pattern (M_1..M_4) depends on f only through the 15 thresholds T_u = 1 - frac(u s) it lies between;
+// the block prologue tabulates them per channel: s_bin[floor(128 f)] = (the one threshold near that bin, 16 x the
+// number of thresholds below the bin), s_pat[id] = masks for `id` thresholds <= f.  EXACTNESS: the sample's true half
+// chip is (int)y_u of the SEQUENTIAL y_u, which lies within 16 ulp(8192) = 2^-36 of the real line y_0 + u s; f and the
+// thresholds are rounded to float (2^-25 each); whenever f is within RW_DELTA = 2^-22 of the threshold of its bin, or
+// the bin is near two thresholds, `unsafe` is raised and the whole group runs the per-sample slow body instead.
+struct RwTmp {  // one channel's group-start temporaries between the phases below
+    int ic0;
+    float f;
+    uint2 be;
+    uint32_t lo, hi;
+    uint4 M;
+};
+
+// The group start in three phases, each run for the four channels of a part before the next one starts, so that the
+// part waits ONCE for each round of LDS reads instead of once per channel: (A) addresses, bin entry + stream words in
+// flight; (B) threshold compare, pattern masks in flight, signed window; (C) the spread.
+template <int J>
+__device__ __forceinline__ void rw_phase_a(const ChanState &c, RwTmp &t, const uint2 *s_bin)
+{
+    t.ic0 = (int)c.y;  // y < 8184 - 16*cs2: no wrap before the group ends
+    t.f = (float)__builtin_amdgcn_fract(c.y);
+    const int bi = (int)(t.f * (float)RW_BINS);
+    t.be = s_bin[J * RW_BIN_PITCH + bi];
+}
+
+template <int J>
+__device__ __forceinline__ void rw_phase_b(RwTmp &t, bool &unsafe, const uint32_t *s_str, const uint4 *s_pat)
+{
+    const float thr = __uint_as_float(t.be.x);
+    const uint32_t po = t.be.y + (t.f >= thr ? 16u : 0u);
+    t.M = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_pat + J * 16) + po);
+    const uint32_t *wp = s_str + J * STR_PITCH + (t.ic0 >> 4);
+    t.lo = wp[0];
+    t.hi = wp[1];
+    unsafe = unsafe | !(__builtin_fabsf(t.f - thr) >= RW_DELTA);  // (a NaN threshold = undecidable bin: unsafe)
+}
+
+__device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &t)
+{
+    const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
+    uint32_t x = window_signed(__builtin_amdgcn_alignbit(t.hi, t.lo, (uint32_t)t.ic0 << 1) ^ mask);
+    x = gal_bfi(t.M.x, x << 2, x);
+    x = gal_bfi(t.M.y, x << 2, x);
+    x = gal_bfi(t.M.z, x << 2, x);
+    x = gal_bfi(t.M.w, x << 2, x);
+    return x;
 }
 
 template <int J>
@@ -1305,6 +1380,19 @@ __device__ __forceinline__ void chan_step_fast(ChanState &c, const ChanGroup &g,
     c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));
 }
 
+// one sample of one channel in a resampled group: chip value from field U of X, carrier as in chan_step_fast
+__device__ __forceinline__ void chan_step_rw(ChanState &c, const uint32_t X, const int U, const double ds,
+                                             const uint32_t lutb, int &acc)
+{
+    const int v = __builtin_amdgcn_sbfe((int)X, (uint32_t)(2 * U), 2);
+    const int k = (int)(511.0 * c.p);
+    uint32_t a;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(k), "s"(lutb));
+    const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
+    gal_acc(acc, t, v);
+    c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));
+}
+
 // The same with the symbol advance of :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact);
 // the symbol counter is advanced in the group epilogue.
 __device__ __forceinline__ void chan_step_wrap(ChanState &c, ChanGroup &g, const double cs2, const double ds,
@@ -1361,7 +1449,9 @@ __device__ __forceinline__ void chan_step_cboc(ChanState &c, const double cs2, c
 #define GAL_MAX_NCH 12
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
 // SIG: 0 = BOC(1,1) as the reference generates it, 1 = CBOC(6,1,1/11) (see chan_step_cboc)
-template <int NCH, bool ACC, int SIG = 0>
+// RW: 1 = fast groups take their 16 chip values from a RESAMPLED window (rw_phase_a/b/c) instead of indexing the window
+//     per sample; needs 0.74 <= 2 f_code / fs < 1 on every channel of the batch (the host decides: DevPlan::rw)
+template <int NCH, bool ACC, int SIG = 0, int RW = 0>
 __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_WAVES))) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
                                                      const uint8_t *__restrict__ act_all,
                                                      const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
@@ -1371,6 +1461,11 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // entry k + 512 of table 0: LUT[k & 511], of table 1: LUT[-k & 511]; CBOC: the same pair for TA, then for TB
     constexpr int LUT_TABLES = SIG == 1 ? 4 : 2;
     __shared__ int s_lut[LUT_TABLES * 1024];
+    // RW: per channel the hold patterns of a 16-sample group (see rw_phase_a)
+    __shared__ uint2 s_bin[RW ? NCH * RW_BIN_PITCH : 1];
+    __shared__ uint4 s_pat[RW ? NCH * 16 : 1];
+    __shared__ float s_thr[RW ? NCH * 16 : 1];
+    __shared__ double s_tie[GAL_MAX_NCH];
 
     const int er = blockIdx.x / G.blocks_per_epoch;  // epoch relative to the executed range
     const int tg = blockIdx.x - er * G.blocks_per_epoch;
@@ -1432,7 +1527,85 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #pragma unroll
         for (int q = 0; q < LUT_TABLES * 1024 / SYN_BLOCK; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
     }
+    if constexpr (RW) {
+        // ---- hold patterns, step A: the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted (one thread per u
+        // ranks its own), and the tie binade of the channel's code step (see GAL_ROOM)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const double s = j < nact ? uniform_f64(2.0 * p_cstep[ixs[j]]) : 0.0;
+            if (tid < 15) {
+                const int u = tid + 1;
+                const double us = (double)u * s;
+                const double T = 1.0 - (us - __builtin_floor(us));
+                int rank = 0;
+                for (int v = 1; v <= 15; ++v) {
+                    const double vs = (double)v * s;
+                    const double Tv = 1.0 - (vs - __builtin_floor(vs));
+                    rank += (Tv < T) || (Tv == T && v < u);
+                }
+                s_thr[j * 16 + rank] = (float)T;
+            } else if (tid == 15) {
+                s_thr[j * 16 + 15] = 2.0f;
+            } else if (tid == 16) {
+                // y + s rounds to the grid q = 2^(e-52) of y's binade e; with M the 53-bit significand of s and
+                // es its exponent, s / q = M 2^(es-e) has the fractional part 1/2 -- a tie, whose rounding direction
+                // depends on y -- exactly in the binade e = es + 1 + ctz(M).  Everywhere else fl(y + s) = y + RN_q(s).
+                double tl = 1e300;
+                if (s > 0.0) {
+                    const uint64_t b = d2u(s);
+                    const uint64_t M = (b & 0xfffffffffffffULL) | 0x10000000000000ULL;
+                    const int es = (int)((b >> 52) & 0x7ff);
+                    tl = u2d((uint64_t)(es + 1 + __builtin_ctzll(M)) << 52);
+                }
+                s_tie[j] = tl;
+            }
+        }
+    }
     __syncthreads();
+    if constexpr (RW) {
+        // ---- step B: the bin table (threads 0..128) and the 16 patterns (wave 3) of each channel
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const bool on = j < nact;
+            const double s = on ? uniform_f64(2.0 * p_cstep[ixs[j]]) : 0.0;
+            if (tid <= RW_BINS) {
+                const float lo = (float)tid * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(tid + 1) * (1.0f / RW_BINS) + RW_EDGE;
+                int cnt = 0, idb = 0;
+                float thr = 4.0f;  // "no threshold near this bin": never reached, never close
+                for (int i = 0; i < 15; ++i) {
+                    const float t = s_thr[j * 16 + i];
+                    idb += t < lo;
+                    const bool in = t >= lo && t < hi;
+                    cnt += in;
+                    thr = in ? t : thr;
+                }
+                if (cnt >= 2 || tid == RW_BINS) thr = __builtin_nanf("");  // undecidable here: the group runs the slow body
+                if (!on) { thr = 4.0f; idb = 0; }
+                s_bin[j * RW_BIN_PITCH + tid] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
+            } else if (tid >= 192 && tid < 208) {
+                const int id = tid - 192;  // number of thresholds <= f
+                const double Tlo = id ? (double)s_thr[j * 16 + id - 1] : 0.0;
+                double Thi = (double)s_thr[j * 16 + id];
+                Thi = Thi > 1.0 ? 1.0 : Thi;
+                const double f = 0.5 * (Tlo + Thi);
+                uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+                int d = 0;
+                double gp = 0.0;  // floor(f), f < 1
+                for (int u = 1; u <= 15; ++u) {
+                    const double g = __builtin_floor(f + (double)u * s);
+                    if (g == gp) {  // sample u holds the half chip of sample u - 1
+                        const uint32_t m = ~0u << (2 * u);
+                        m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
+                        ++d;
+                    }
+                    gp = g;
+                }
+                if (!on) m0 = m1 = m2 = m3 = 0u;
+                s_pat[j * 16 + id] = make_uint4(m0, m1, m2, m3);
+            }
+        }
+        __syncthreads();
+    }
 
     // Position L of the epoch -> chunk c.  When the chunk length divides the code period (cls chunks per period),
     // the positions are ordered by CODE-PHASE CLASS c % cls first: all chunks of a class start at the same code phase,
@@ -1571,12 +1744,18 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // costs time only).
     const double thr2 = uniform_f64(8184.0 - 16.0 * csmax - 0.0009765625);
     const double inv16 = uniform_f64(csmax > 0.0 ? (1.0 - 9.313225746154785e-10) / (16.0 * csmax) : 0.0);
+    [[maybe_unused]] const double tieb = uniform_f64(16.0 * csmax + 0.0009765625);
 #define GAL_SF_DECL(j) [[maybe_unused]] int sf##j = 0;
     GAL_CH_LIST(GAL_SF_DECL)
 #undef GAL_SF_DECL
 
 // (no `j < nact` tests inside the group loop: see the zero-filled stream rows above)
-#define GAL_ROOM(j) if (j < NCH) { const double r = thr2 - ch##j.y; room = r < room ? r : room; negp |= (int)GAL_HI(ch##j.p); }
+// RW: the once-per-group code advance (GAL_ADV) assumes fl(y + s) = y + RN_q(s) within a binade, which holds in every
+// binade but the channel's tie binade [tl, 2 tl) (s_tie, block prologue): groups that could touch it run the slow body
+#define GAL_ROOM(j) if (j < NCH) { const double r = thr2 - ch##j.y; room = r < room ? r : room; negp |= (int)GAL_HI(ch##j.p); \
+        if constexpr (RW) { const double tl = s_tie[j], yy = ch##j.y;                                                       \
+            const double r2 = yy < tl ? (tl - tieb) - yy : (yy < 2.0 * tl ? -1.0 : 1048576.0);                              \
+            room = r2 < room ? r2 : room; } }
 #define GAL_SAFE(a, b, c, d)                                                     \
     if (a < NCH) {                                                               \
         double room = 1048576.0;                                                 \
@@ -1601,12 +1780,57 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // dependency chains give the scheduler enough ILP to cover FP64 and LDS latency, while only four channels'
 // group temporaries are live at once.  sched_barrier keeps the parts apart.  `near` is wave-uniform after the
 // ballot: no lane of the wave has any of the four codes within 16 samples of its wrap -> fast body.
+#define GAL_RW_A(j) if (j < NCH) rw_phase_a<j>(ch##j, rt##j, s_bin);
+#define GAL_RW_B(j) if (j < NCH) rw_phase_b<j>(rt##j, unsafe, s_str, s_pat);
+#define GAL_RW_C(j) if (j < NCH) gx##j = rw_phase_c(ch##j, rt##j);
+#define GAL_STEP_R(j) if (j < NCH) chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc);
+#define GAL_PIN_R(a, b, c, d) asm volatile("" : "+v"(acc), "+v"(ch##a.p), "+v"(ch##b.p), "+v"(ch##c.p), "+v"(ch##d.p));
+// RW: the code NCO over the 16 samples of a fast group in three instructions.  Within a binade (and outside the tie
+// binade, which GAL_ROOM keeps away) every sequential step adds the same S = RN_q(cs2) = fl(y + cs2) - y, and y + 16 S
+// is a multiple of q below the binade's end, hence exact: fma(S, 16, y) IS the 16th sequential sum.  If that value
+// has left y's binade the group may have crossed the boundary (coarser grid behind it): then, and only then, the 16
+// additions are made one by one (wave-uniform branch; the lanes of a wave share their code phase class).
+#define GAL_ADV(j)                                                                            \
+    if (j < NCH) {                                                                            \
+        const double y0 = ch##j.y;                                                            \
+        const double y1 = y0 + cs##j;                                                         \
+        const double S = y1 - y0;                                                             \
+        double y16 = __builtin_fma(S, 16.0, y0);                                              \
+        if (__builtin_amdgcn_ballot_w64((GAL_HI(y16) ^ GAL_HI(y0)) > 0xfffffu) != 0) {       \
+            y16 = y0;                                                                         \
+            _Pragma("unroll") for (int q = 0; q < SYN_GROUP; ++q) y16 = y16 + cs##j;         \
+        }                                                                                     \
+        ch##j.y = y16;                                                                        \
+    }
 #define GAL_PART(a, b, c, d)                                                     \
     if (a < NCH) {                                                               \
         ChanGroup gr##a = {0u, 0, 1}, gr##b = {0u, 0, 1};                        \
         ChanGroup gr##c = {0u, 0, 1}, gr##d = {0u, 0, 1};                        \
         const bool near = (GSZ != SYN_GROUP) | (sf##a < 1);                      \
-        if (__builtin_amdgcn_ballot_w64(near) == 0) {                            \
+        bool fast = __builtin_amdgcn_ballot_w64(near) == 0;                      \
+        if constexpr (RW != 0) {                                                 \
+            [[maybe_unused]] uint32_t gx##a = 0u, gx##b = 0u, gx##c = 0u, gx##d = 0u; \
+            [[maybe_unused]] RwTmp rt##a = {}, rt##b = {}, rt##c = {}, rt##d = {}; \
+            if (fast) {                                                          \
+                bool unsafe = false;                                             \
+                GAL_RW_A(a) GAL_RW_A(b) GAL_RW_A(c) GAL_RW_A(d)                  \
+                GAL_RW_B(a) GAL_RW_B(b) GAL_RW_B(c) GAL_RW_B(d)                  \
+                fast = __builtin_amdgcn_ballot_w64(unsafe) == 0;                 \
+            }                                                                    \
+            if (fast) {                                                          \
+                sf##a -= 1;                                                      \
+                GAL_RW_C(a) GAL_RW_C(b) GAL_RW_C(c) GAL_RW_C(d)                  \
+                GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                  \
+                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
+                {                                                                \
+                    int acc = o[u];                                              \
+                    GAL_STEP_R(a) GAL_STEP_R(b) GAL_STEP_R(c) GAL_STEP_R(d)      \
+                    if (u & 1) { GAL_PIN_R(a, b, c, d) }                         \
+                    o[u] = acc;                                                  \
+                }                                                                \
+                GAL_ADV(a) GAL_ADV(b) GAL_ADV(c) GAL_ADV(d)                      \
+            }                                                                    \
+        } else if (fast) {                                                       \
             sf##a -= 1;                                                          \
             GAL_BEGIN_F(a) GAL_BEGIN_F(b) GAL_BEGIN_F(c) GAL_BEGIN_F(d)          \
             GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
@@ -1617,7 +1841,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 if (u & 1) { GAL_PIN(a, b, c, d) } /* 2 steps per scheduling unit: measured best (1: -2 %, 4: spills) */ \
                 o[u] = acc;                                                      \
             }                                                                    \
-        } else {                                                                 \
+        }                                                                        \
+        if (!fast) {                                                             \
             GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)          \
             GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
             _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
@@ -1688,6 +1913,12 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_SAFE
 #undef GAL_ROOM
 #undef GAL_PART
+#undef GAL_ADV
+#undef GAL_RW_A
+#undef GAL_RW_B
+#undef GAL_RW_C
+#undef GAL_STEP_R
+#undef GAL_PIN_R
 #undef GAL_PIN
 #undef GAL_SGN4
 #undef GAL_BEGIN_F
@@ -1814,7 +2045,7 @@ extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
     hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
 }
 
-template <bool ACC, int SIG>
+template <bool ACC, int SIG, int RW = 0>
 static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact,
                           uint32_t *iq, int e0, int ne, hipStream_t st)
 {
@@ -1825,7 +2056,7 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     G.cls = P->cls > 0 ? P->cls : 1;
     G.per = P->nchunks / G.cls;
     switch (nch) {
-#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC, SIG>), grid, block, 0, st, Pd, G, act, nact, iq); break;
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC, SIG, RW>), grid, block, 0, st, Pd, G, act, nact, iq); break;
         GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
         GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
 #undef GAL_CASE
@@ -1840,6 +2071,9 @@ extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, i
     if (P->signal == 1)
         return accumulate ? launch_synth_t<true, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
                           : launch_synth_t<false, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
+    if (P->rw)
+        return accumulate ? launch_synth_t<true, 0, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
+                          : launch_synth_t<false, 0, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
     return accumulate ? launch_synth_t<true, 0>(P, Pd, nch, act, nact, iq, e0, ne, st)
                       : launch_synth_t<false, 0>(P, Pd, nch, act, nact, iq, e0, ne, st);
 }

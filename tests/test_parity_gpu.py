@@ -83,6 +83,50 @@ def test_sample_rates_window_limits(pkg, rate):
     _compare(pkg, p, n_samp, rate=rate, chunk_samples=64)
 
 
+@pytest.mark.parametrize("rate", [2.0462e6, 2.35e6, 2.6e6, 2.76e6, 2.77e6, 3.0e6])
+def test_resampled_window_rates(pkg, rate):
+    """k_synth's resampled-window fast body (one chip look-up pattern per 16-sample group, code NCO advanced once per
+    group) serves batches with 0.74 <= 2 f_code / fs < 0.9999: 2.0462 MS/s is just inside the upper end (one hold per
+    group at most), 2.76 MS/s just inside the lower end (four holds), 2.77 and 3.0 MS/s fall back to the classic body.
+    Epochs of 6.2 code periods so that every lane passes the small binades of the code phase (where the group advance
+    has to add sample by sample) and the channel's tie binade."""
+    n_samp = int(rate * 0.025)
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=12, n_slots=12, samples_per_epoch=n_samp, sample_rate=rate,
+                                     seed=int(rate) % 997)
+    _compare(pkg, p, n_samp, rate=rate)
+    _compare(pkg, p, n_samp, rate=rate, chunk_samples=208)
+
+
+def test_resampled_window_tie_binades(pkg):
+    """Code steps whose significand ends in k zero bits put the tie binade of the group advance at 2^k half chips:
+    steps built with 1 .. 13 trailing zeros make every binade of the code phase a tie binade for some channel."""
+    n_samp = 65000
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=12, n_slots=12, samples_per_epoch=n_samp, seed=4242)
+    for j in range(12):
+        step = float(p["f_code"][0, j]) / 2.6e6  # code step per sample; the kernel doubles it (exact)
+        m = np.frombuffer(np.float64(step).tobytes(), dtype=np.uint64)[0]
+        k = j + 2
+        m = (int(m) >> k << k) | (1 << k)  # significand ends in 1 followed by k zeros
+        step2 = np.frombuffer(np.uint64(m).tobytes(), dtype=np.float64)[0]
+        p["f_code"][:, j] = step2 * 2.6e6
+        # f_code * (1 / fs) must reproduce the crafted step: search the neighbourhood
+        f = float(p["f_code"][0, j])
+        for _ in range(64):
+            if f * (1.0 / 2.6e6) == step2:
+                break
+            f = np.nextafter(f, f + (1 if f * (1.0 / 2.6e6) < step2 else -1))
+        p["f_code"][:, j] = f
+    _compare(pkg, p, n_samp)
+
+
+def test_classic_window_body_at_the_reference_rate(pkg, monkeypatch):
+    """The classic fast body (per-sample window index) still serves other sample rates; the GAL_TEST_HOOKS build can be
+    told to use it at 2.6 MS/s too, so that both bodies are compared with the oracle on the same batch."""
+    monkeypatch.setenv("GAL_SYNTH_RW", "0")
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=12, n_slots=16, samples_per_epoch=52000, seed=99)
+    _compare(pkg, p, 52000, test_hooks=True)
+
+
 def test_code_wrap_at_every_group_position(pkg):
     """Code phases chosen so that the wrap (x >= 4092) falls on each of the 16 positions of a sample group,
     including the first sample (wrap pending from the previous group) and the first sample of a chunk."""

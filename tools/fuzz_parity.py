@@ -22,7 +22,7 @@ RESTART = 1
 
 
 def random_case(rng, big=False):
-    rate = float(rng.choice([2.047e6, 2.6e6, 2.6e6, 2.6e6, 4.0e6, 4.092e6, 10e6, 25e6]))
+    rate = float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 4.0e6, 4.092e6, 10e6, 25e6]))
     n_slots = int(rng.choice([4, 8, 16, 16, 24, 40, 64]))
     n_chan = int(rng.integers(1, n_slots + 1))
     n_ep = int(rng.integers(1, 7))
@@ -50,6 +50,12 @@ def random_case(rng, big=False):
             d = p["f_carr"][:, j] / rate
             p["f_carr"][:, j] = np.round(d * 2.0 ** k) / 2.0 ** k * rate
         p["f_code"][:, j] = 1.023e6 + p["f_carr"][:, j] * 0.0006493506493506494
+        if rng.random() < 0.25:  # code steps with few significant bits: the tie binade of k_synth's group advance moves up
+            k = int(rng.integers(1, 16))
+            st = (p["f_code"][:, j] * (1.0 / rate)).astype(np.float64)
+            m = st.view(np.uint64)
+            m = (m >> np.uint64(k) << np.uint64(k)) | np.uint64(1 << k)
+            p["f_code"][:, j] = m.view(np.float64) * rate  # (the product may miss the crafted step by an ulp: still few-bit-ish)
         if rng.random() < 0.3:
             p["ibit0"][0, j] = int(rng.choice([498, 499, 0]))
         if rng.random() < 0.3:
