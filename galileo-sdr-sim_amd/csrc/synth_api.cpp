@@ -3,6 +3,7 @@
 // implementation behind these entry points: without a usable GPU they fail with GAL_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -13,6 +14,26 @@
 
 #include "synth_dev.h"
 #include "e1_tables.inc"
+
+// Smallest distance between two of the 15 thresholds T_u = 1 - frac(u s) of the 16-sample hold pattern (k_synth,
+// rw_phase_a): the kernel's bin table (128 bins of the group-start fraction) decides a lane only if its bin holds ONE
+// threshold, so every pair must be more than a bin (plus the registration margin) apart -- true for 2.6 MS/s (0.017),
+// false where 2.046 MHz / fs is close to a fraction with a denominator below 16 (2.5 MS/s: 9/11, 2.728 MS/s: 3/4).
+static double rw_threshold_gap(double s)
+{
+    double T[15];
+    for (int u = 1; u <= 15; ++u) {
+        const double us = (double)u * s;
+        const double t = 1.0 - (us - std::floor(us));
+        int i = u - 1;
+        while (i > 0 && T[i - 1] > t) { T[i] = T[i - 1]; --i; }
+        T[i] = t;
+    }
+    double g = 1.0;
+    for (int i = 1; i < 15; ++i) g = std::min(g, T[i] - T[i - 1]);
+    return g;
+}
+static constexpr double kRwMinGap = 1.0 / 128.0 + 4e-6;
 
 extern "C" {
 void galk_launch_prep(const DevPlan *P, hipStream_t st);
@@ -117,6 +138,9 @@ struct gal_synth {
     gal_chan_state_t *h_state = nullptr;  // pinned [S]
     bool state_fetched = false;           // h_state holds the state of the batch in flight
     gal_synth_stats_t stats{};
+    // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
+    // their smallest distance (rw_threshold_gap); a step that moved by d can have closed that distance by 30 d at most
+    std::vector<double> rw_s0, rw_g0;
 };
 
 extern "C" {
@@ -311,7 +335,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     int nact_max = 0;
     std::vector<int> cur_prn(S, 0);
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
-    bool rw_ok = true;  // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel
+    // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel, thresholds a bin apart
+    bool rw_ok = true;
+    if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); }
     const double delt = 1.0 / h->cfg.sample_rate;
     for (int e = 0; e < E; ++e) {
         int n = 0;
@@ -343,9 +369,14 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
-            {
+            if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
-                rw_ok = rw_ok && cs2 >= 0.74 && cs2 < 0.9999;
+                rw_ok = cs2 >= 0.74 && cs2 < 0.9999;
+                if (rw_ok && !(h->rw_g0[s] - 30.0 * std::fabs(cs2 - h->rw_s0[s]) > kRwMinGap)) {
+                    h->rw_s0[s] = cs2;
+                    h->rw_g0[s] = rw_threshold_gap(cs2);
+                    rw_ok = h->rw_g0[s] > kRwMinGap;
+                }
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;
@@ -753,6 +784,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;
+    h->stats.window_mode = h->P.rw;
     h->legs_walked = ctr_end[CTR_WALKS];
     h->legs_translated = ctr_end[CTR_SHIFTS];
     if (stats) *stats = h->stats;

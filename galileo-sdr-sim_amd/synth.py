@@ -69,6 +69,8 @@ class _Stats(ctypes.Structure):
         ("chunks_per_epoch", ctypes.c_int32),
         ("ms_walk", ctypes.c_float),
         ("ms_synth", ctypes.c_float),
+        ("window_mode", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

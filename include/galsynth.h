@@ -105,6 +105,10 @@ typedef struct gal_synth_stats {
     int32_t chunks_per_epoch;
     float   ms_walk;            /* device time of the walker kernels, last execute (0 if timing disabled)      */
     float   ms_synth;           /* device time of the synthesis kernel, last execute                           */
+    int32_t window_mode;        /* fast body of the synthesis kernel: 1 resampled windows (one chip-pattern look-up per
+                                   16 samples; needs 0.74 <= 2 f_code / fs < 1 and well separated pattern thresholds,
+                                   true at the reference's 2.6 MS/s), 0 per-sample window index (any rate)           */
+    int32_t reserved;
 } gal_synth_stats_t;
 
 typedef struct gal_synth gal_synth_t;

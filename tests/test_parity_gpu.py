@@ -83,17 +83,21 @@ def test_sample_rates_window_limits(pkg, rate):
     _compare(pkg, p, n_samp, rate=rate, chunk_samples=64)
 
 
-@pytest.mark.parametrize("rate", [2.0462e6, 2.35e6, 2.6e6, 2.76e6, 2.77e6, 3.0e6])
-def test_resampled_window_rates(pkg, rate):
+@pytest.mark.parametrize("rate,mode", [(2.1e6, 1), (2.2e6, 1), (2.4e6, 1), (2.6e6, 1), (2.76e6, 1),
+                                       (2.0462e6, 0), (2.5e6, 0), (2.728e6, 0), (2.77e6, 0), (3.0e6, 0)])
+def test_resampled_window_rates(pkg, rate, mode):
     """k_synth's resampled-window fast body (one chip look-up pattern per 16-sample group, code NCO advanced once per
-    group) serves batches with 0.74 <= 2 f_code / fs < 0.9999: 2.0462 MS/s is just inside the upper end (one hold per
-    group at most), 2.76 MS/s just inside the lower end (four holds), 2.77 and 3.0 MS/s fall back to the classic body.
+    group) serves batches with 0.74 <= 2 f_code / fs < 0.9999 whose 15 pattern thresholds are more than a bin apart
+    (synth_api.cpp: rw_threshold_gap): the first five rates qualify (2.76 MS/s: four holds per group, the maximum);
+    2.0462 MS/s (thresholds 1e-4 apart), 2.5 MS/s (step ~ 9/11) and 2.728 MS/s (step = 3/4) have clustered thresholds,
+    2.77 and 3.0 MS/s are out of range: those run the classic body (gal_synth_stats_t.window_mode says which).
     Epochs of 6.2 code periods so that every lane passes the small binades of the code phase (where the group advance
     has to add sample by sample) and the channel's tie binade."""
     n_samp = int(rate * 0.025)
     p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=12, n_slots=12, samples_per_epoch=n_samp, sample_rate=rate,
                                      seed=int(rate) % 997)
-    _compare(pkg, p, n_samp, rate=rate)
+    _, _, stats = _compare(pkg, p, n_samp, rate=rate)
+    assert stats["window_mode"] == mode
     _compare(pkg, p, n_samp, rate=rate, chunk_samples=208)
 
 
@@ -124,7 +128,11 @@ def test_classic_window_body_at_the_reference_rate(pkg, monkeypatch):
     told to use it at 2.6 MS/s too, so that both bodies are compared with the oracle on the same batch."""
     monkeypatch.setenv("GAL_SYNTH_RW", "0")
     p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=12, n_slots=16, samples_per_epoch=52000, seed=99)
-    _compare(pkg, p, 52000, test_hooks=True)
+    _, _, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["window_mode"] == 0
+    monkeypatch.delenv("GAL_SYNTH_RW")
+    _, _, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["window_mode"] == 1
 
 
 def test_code_wrap_at_every_group_position(pkg):
