@@ -1527,14 +1527,25 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #pragma unroll
         for (int q = 0; q < LUT_TABLES * 1024 / SYN_BLOCK; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
     }
+    [[maybe_unused]] double rw_s[NCH];  // RW: the channels' code steps in half chips (wave-uniform)
     if constexpr (RW) {
-        // ---- hold patterns, step A: the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted (one thread per u
-        // ranks its own), and the tie binade of the channel's code step (see GAL_ROOM)
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const double s = j < nact ? uniform_f64(2.0 * p_cstep[ixs[j]]) : 0.0;
-            if (tid < 15) {
-                const int u = tid + 1;
+        for (int j = 0; j < NCH; ++j) rw_s[j] = j < nact ? uniform_f64(2.0 * p_cstep[ixs[j]]) : 0.0;
+    }
+    // step of channel jj, jj a per-thread value (a select chain over the uniform values: no LDS round trip)
+    auto rw_step_of = [&](const int jj) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) v = jj == j ? rw_s[j] : v;
+        return v;
+    };
+    if constexpr (RW) {
+        // ---- hold patterns, step A: the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted: thread
+        // (channel, u) ranks its own; thread (channel, 16) writes the sentinel and the tie binade of the code step
+        if (tid < NCH * 16) {
+            const int j = tid >> 4, u = (tid & 15) + 1;
+            const double s = rw_step_of(j);
+            if (u <= 15) {
                 const double us = (double)u * s;
                 const double T = 1.0 - (us - __builtin_floor(us));
                 int rank = 0;
@@ -1544,9 +1555,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                     rank += (Tv < T) || (Tv == T && v < u);
                 }
                 s_thr[j * 16 + rank] = (float)T;
-            } else if (tid == 15) {
+            } else {
                 s_thr[j * 16 + 15] = 2.0f;
-            } else if (tid == 16) {
                 // y + s rounds to the grid q = 2^(e-52) of y's binade e; with M the 53-bit significand of s and
                 // es its exponent, s / q = M 2^(es-e) has the fractional part 1/2 -- a tie, whose rounding direction
                 // depends on y -- exactly in the binade e = es + 1 + ctz(M).  Everywhere else fl(y + s) = y + RN_q(s).
@@ -1563,46 +1573,44 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     }
     __syncthreads();
     if constexpr (RW) {
-        // ---- step B: the bin table (threads 0..128) and the 16 patterns (wave 3) of each channel
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const bool on = j < nact;
-            const double s = on ? uniform_f64(2.0 * p_cstep[ixs[j]]) : 0.0;
-            if (tid <= RW_BINS) {
-                const float lo = (float)tid * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(tid + 1) * (1.0f / RW_BINS) + RW_EDGE;
-                int cnt = 0, idb = 0;
-                float thr = 4.0f;  // "no threshold near this bin": never reached, never close
-                for (int i = 0; i < 15; ++i) {
-                    const float t = s_thr[j * 16 + i];
-                    idb += t < lo;
-                    const bool in = t >= lo && t < hi;
-                    cnt += in;
-                    thr = in ? t : thr;
-                }
-                if (cnt >= 2 || tid == RW_BINS) thr = __builtin_nanf("");  // undecidable here: the group runs the slow body
-                if (!on) { thr = 4.0f; idb = 0; }
-                s_bin[j * RW_BIN_PITCH + tid] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
-            } else if (tid >= 192 && tid < 208) {
-                const int id = tid - 192;  // number of thresholds <= f
-                const double Tlo = id ? (double)s_thr[j * 16 + id - 1] : 0.0;
-                double Thi = (double)s_thr[j * 16 + id];
-                Thi = Thi > 1.0 ? 1.0 : Thi;
-                const double f = 0.5 * (Tlo + Thi);
-                uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
-                int d = 0;
-                double gp = 0.0;  // floor(f), f < 1
-                for (int u = 1; u <= 15; ++u) {
-                    const double g = __builtin_floor(f + (double)u * s);
-                    if (g == gp) {  // sample u holds the half chip of sample u - 1
-                        const uint32_t m = ~0u << (2 * u);
-                        m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
-                        ++d;
-                    }
-                    gp = g;
-                }
-                if (!on) m0 = m1 = m2 = m3 = 0u;
-                s_pat[j * 16 + id] = make_uint4(m0, m1, m2, m3);
+        // ---- step B: the bin tables (NCH x 129 entries over all threads) and the 16 patterns of each channel
+        for (int t = tid; t < NCH * (RW_BINS + 1); t += SYN_BLOCK) {
+            const int j = t / (RW_BINS + 1), b = t - j * (RW_BINS + 1);
+            const float lo = (float)b * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / RW_BINS) + RW_EDGE;
+            int cnt = 0, idb = 0;
+            float thr = 4.0f;  // "no threshold near this bin": never reached, never close
+            for (int i = 0; i < 15; ++i) {
+                const float th = s_thr[j * 16 + i];
+                idb += th < lo;
+                const bool in = th >= lo && th < hi;
+                cnt += in;
+                thr = in ? th : thr;
             }
+            if (cnt >= 2 || b == RW_BINS) thr = __builtin_nanf("");  // undecidable here: the group runs the slow body
+            if (j >= nact) { thr = 4.0f; idb = 0; }
+            s_bin[j * RW_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
+        }
+        if (tid < NCH * 16) {
+            const int j = tid >> 4, id = tid & 15;  // id = number of thresholds <= f
+            const double s = rw_step_of(j);
+            const double Tlo = id ? (double)s_thr[j * 16 + id - 1] : 0.0;
+            double Thi = (double)s_thr[j * 16 + id];
+            Thi = Thi > 1.0 ? 1.0 : Thi;
+            const double f = 0.5 * (Tlo + Thi);
+            uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+            int d = 0;
+            double gp = 0.0;  // floor(f), f < 1
+            for (int u = 1; u <= 15; ++u) {
+                const double g = __builtin_floor(f + (double)u * s);
+                if (g == gp) {  // sample u holds the half chip of sample u - 1
+                    const uint32_t m = ~0u << (2 * u);
+                    m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
+                    ++d;
+                }
+                gp = g;
+            }
+            if (j >= nact) m0 = m1 = m2 = m3 = 0u;
+            s_pat[tid] = make_uint4(m0, m1, m2, m3);
         }
         __syncthreads();
     }
