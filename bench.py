@@ -416,11 +416,14 @@ def main():
                 "walk_passes": stats["walk_passes"],
                 "chain_mismatch": stats["chain_mismatch"],
                 "pipeline_depth": depth, **({"hooks_build": True} if HOOKS_BUILD else {}),
+                "window_mode": stats.get("window_mode"),  # 1: k_synth's resampled-window fast body (galsynth.h)
                 "output_checksum": "%08x" % chk,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_synth<%d,false>%s" % (min(args.channels, 12), " (+ accumulate launch)" if args.channels > 12 else ""),
+                "kernel": "k_synth<%d,false,%d,%d>%s" % (min(args.channels, 12), 1 if args.signal == "cboc" else 0,
+                                                         stats.get("window_mode") or 0,
+                                                         " (+ accumulate launch)" if args.channels > 12 else ""),
                 # sustained: launches x algorithmic bytes over the timed region.  With two handles in flight consecutive
                 # k_synth launches OVERLAP (the second round of blocks of one runs beside the first round of the next), so
                 # the per-launch intervals below add up to more than the wall time; they are reported next to it
