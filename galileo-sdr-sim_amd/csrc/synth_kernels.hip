@@ -1271,15 +1271,19 @@ __device__ __forceinline__ void rw_phase_a(const ChanState &c, RwTmp &t, const u
 }
 
 template <int J>
-__device__ __forceinline__ void rw_phase_b(RwTmp &t, bool &unsafe, const uint32_t *s_str, const uint4 *s_pat)
+__device__ __forceinline__ bool rw_phase_b(RwTmp &t, const uint32_t str0, const uint4 *s_pat)
 {
     const float thr = __uint_as_float(t.be.x);
     const uint32_t po = t.be.y + (t.f >= thr ? 16u : 0u);
     t.M = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_pat + J * 16) + po);
-    const uint32_t *wp = s_str + J * STR_PITCH + (t.ic0 >> 4);
-    t.lo = wp[0];
-    t.hi = wp[1];
-    unsafe = unsafe | !(__builtin_fabsf(t.f - thr) >= RW_DELTA);  // (a NaN threshold = undecidable bin: unsafe)
+    // stream words ic0 / 16 and the next one of row J (str0: LDS byte address of the rows, in an SGPR -- written as
+    // asm because the compiler otherwise re-materialises the row offset in a VGPR for every group)
+    uint32_t wa;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(wa) : "v"(t.ic0 >> 4), "s"(str0 + (uint32_t)(J * STR_PITCH * 4)));
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    t.lo = ((lds_u32_ptr)(uintptr_t)wa)[0];
+    t.hi = ((lds_u32_ptr)(uintptr_t)wa)[1];
+    return !(__builtin_fabsf(t.f - thr) >= RW_DELTA);  // too close to call (a NaN threshold = undecidable bin)
 }
 
 __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &t)
@@ -1739,6 +1743,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     } else {
     // one threshold for all channels: y below it cannot reach the wrap within 16 samples (the code rates of
     // the channels differ by parts per million, so the largest step serves all)
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr0;
+    [[maybe_unused]] const uint32_t str0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32_ptr0)s_str);
     double csmax = 0.0;
 #define GAL_CSMAX(j) if (j < NCH) csmax = cs##j > csmax ? cs##j : csmax;
     GAL_CH_LIST(GAL_CSMAX)
@@ -1789,7 +1795,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // group temporaries are live at once.  sched_barrier keeps the parts apart.  `near` is wave-uniform after the
 // ballot: no lane of the wave has any of the four codes within 16 samples of its wrap -> fast body.
 #define GAL_RW_A(j) if (j < NCH) rw_phase_a<j>(ch##j, rt##j, s_bin);
-#define GAL_RW_B(j) if (j < NCH) rw_phase_b<j>(rt##j, unsafe, s_str, s_pat);
+#define GAL_RW_B(j) if (j < NCH) unsafe##j = rw_phase_b<j>(rt##j, str0, s_pat);
 #define GAL_RW_C(j) if (j < NCH) gx##j = rw_phase_c(ch##j, rt##j);
 #define GAL_STEP_R(j) if (j < NCH) chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc);
 #define GAL_PIN_R(a, b, c, d) asm volatile("" : "+v"(acc), "+v"(ch##a.p), "+v"(ch##b.p), "+v"(ch##c.p), "+v"(ch##d.p));
@@ -1820,10 +1826,11 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             [[maybe_unused]] uint32_t gx##a = 0u, gx##b = 0u, gx##c = 0u, gx##d = 0u; \
             [[maybe_unused]] RwTmp rt##a = {}, rt##b = {}, rt##c = {}, rt##d = {}; \
             if (fast) {                                                          \
-                bool unsafe = false;                                             \
+                [[maybe_unused]] bool unsafe##a = false, unsafe##b = false, unsafe##c = false, unsafe##d = false; \
                 GAL_RW_A(a) GAL_RW_A(b) GAL_RW_A(c) GAL_RW_A(d)                  \
                 GAL_RW_B(a) GAL_RW_B(b) GAL_RW_B(c) GAL_RW_B(d)                  \
-                fast = __builtin_amdgcn_ballot_w64(unsafe) == 0;                 \
+                fast = (__builtin_amdgcn_ballot_w64(unsafe##a) | __builtin_amdgcn_ballot_w64(unsafe##b) | \
+                        __builtin_amdgcn_ballot_w64(unsafe##c) | __builtin_amdgcn_ballot_w64(unsafe##d)) == 0; \
             }                                                                    \
             if (fast) {                                                          \
                 sf##a -= 1;                                                      \
