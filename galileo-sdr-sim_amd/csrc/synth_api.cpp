@@ -34,6 +34,11 @@ static double rw_threshold_gap(double s)
     return g;
 }
 static constexpr double kRwMinGap = 1.0 / 128.0 + 4e-6;
+#ifdef GAL_TEST_HOOKS
+// tests/test_walker_cpu.py checks the gate against an independent evaluation (no device needed)
+extern "C" double gal_hooks_rw_threshold_gap(double s) { return rw_threshold_gap(s); }
+extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
+#endif
 
 extern "C" {
 void galk_launch_prep(const DevPlan *P, hipStream_t st);

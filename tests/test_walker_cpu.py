@@ -230,3 +230,31 @@ def test_translated_legs_are_bit_exact(W):
                 tot_w0 += walks
                 assert shifts == 0
     assert tot_s > 0 and tot_w1 < 0.7 * tot_w0, (tot_w0, tot_w1, tot_s)
+
+
+def test_resampled_window_gate(pkg):
+    """Host-side gate of k_synth's resampled-window body (synth_api.cpp: rw_threshold_gap): the smallest distance between
+    two of the 15 hold-pattern thresholds 1 - frac(u s), against an independent numpy evaluation; and the decisions the
+    GPU rate tests rely on (2.6 MS/s qualifies with a wide margin, rates whose code step is near a fraction with a small
+    denominator do not).  The GAL_TEST_HOOKS build exports the function; no device is needed."""
+    import ctypes
+
+    lib = pkg.synth.load_library(hooks=True)
+    lib.gal_hooks_rw_threshold_gap.restype = ctypes.c_double
+    lib.gal_hooks_rw_threshold_gap.argtypes = [ctypes.c_double]
+    lib.gal_hooks_rw_min_gap.restype = ctypes.c_double
+    need = lib.gal_hooks_rw_min_gap()
+    assert 1.0 / 128.0 < need < 1.0 / 128.0 + 1e-5
+
+    def gap(s):
+        t = np.sort(1.0 - np.mod(np.arange(1, 16) * s, 1.0))
+        return float(np.diff(t).min())
+
+    rng = np.random.default_rng(5)
+    for s in list(rng.uniform(0.74, 0.9999, 200)) + [2 * 1.023e6 / fs for fs in (2.1e6, 2.2e6, 2.4e6, 2.6e6, 2.76e6)]:
+        assert abs(lib.gal_hooks_rw_threshold_gap(float(s)) - gap(s)) < 1e-12, s
+    for fs, ok in ((2.6e6, True), (2.1e6, True), (2.76e6, True), (2.5e6, False), (2.728e6, False), (2.0462e6, False)):
+        assert (lib.gal_hooks_rw_threshold_gap(2 * 1.023e6 / fs) > need) == ok, fs
+    # the whole Doppler range of the reference's rate keeps its distance (f_code = 1.023e6 (1 +- 3.5e3 / 1575.42e6))
+    for d in np.linspace(-3500.0, 3500.0, 29):
+        assert lib.gal_hooks_rw_threshold_gap(2 * (1.023e6 + d * 0.0006493506493506494) / 2.6e6) > 2 * need
