@@ -700,6 +700,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     HIP_TRY(hipEventRecord(h->ev[2], st));
     HIP_TRY(hipMemcpyAsync(h->h_ctr + CTR_COUNT, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
     h->last_iq = (uint32_t *)iq_dev;
+    h->stats.synth_runs = 1;
     h->executed = true;
     h->in_flight = true;
     return GAL_OK;
@@ -738,6 +739,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         h->state_fetched = false;
         galk_launch_state_phase(P, st);
         HIP_TRY(hipEventRecord(h->ev[1], st));
+        h->stats.synth_runs += 1;
         int rc = enqueue_synth(h, h->last_iq);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev[2], st));
@@ -773,6 +775,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         h->state_fetched = false;
         galk_launch_state_phase(P, st);
         HIP_TRY(hipEventRecord(h->ev[1], st));
+        h->stats.synth_runs += 1;
         int rc = enqueue_synth(h, h->last_iq);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev[2], st));

@@ -70,7 +70,7 @@ class _Stats(ctypes.Structure):
         ("ms_walk", ctypes.c_float),
         ("ms_synth", ctypes.c_float),
         ("window_mode", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("synth_runs", ctypes.c_int32),
     ]
 
 

@@ -219,7 +219,10 @@ def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
     monkeypatch.setenv("GAL_WALK_PASSES", "1")  # honoured by the GAL_TEST_HOOKS build only
     p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=77)
     iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
-    assert stats["walk_passes"] >= 2
+    assert stats["walk_passes"] >= 2 and stats["synth_runs"] == 2
+    monkeypatch.delenv("GAL_WALK_PASSES")
+    iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["walk_passes"] == 2 and stats["synth_runs"] == 1
 
 
 def test_translated_legs_on_moving_receiver(pkg):
