@@ -73,7 +73,8 @@ struct DevPlan {
     // tables
     const int *lut;       // [512] int16 pairs (2 cos, 2 sin), low half first; CBOC: [2][512] = 2 TA, 2 TB
     int signal;           // 0 BOC(1,1) (the reference), 1 CBOC(6,1,1/11) (GAL_CFG_CBOC)
-    int rw;               // 1: every code step of the batch has 0.74 <= 2 f_code / fs < 1 -> k_synth<.., RW = 1>
+    int rw;               // resampled-window body of k_synth: 1 every code step has 0.74 <= 2 f_code / fs < 1 (holds),
+                          // 2 every code step has 2 f_code / fs <= 0.133 (advances), 0 classic per-sample window index
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 

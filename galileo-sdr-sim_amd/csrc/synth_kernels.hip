@@ -1286,14 +1286,33 @@ __device__ __forceinline__ bool rw_phase_b(RwTmp &t, const uint32_t str0, const 
     return !(__builtin_fabsf(t.f - thr) >= RW_DELTA);  // too close to call (a NaN threshold = undecidable bin)
 }
 
+// all 16 fields = field d of w (a two's-complement 2-bit value 00 / 01 / 11)
+__device__ __forceinline__ uint32_t rw_rep(const uint32_t w, const int d)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)w, 2 * d, 1);      // 0 / ~0: the field's low bit
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)w, 2 * d + 1, 1);  // ... its high bit
+    return gal_bfi(0x55555555u, lo, hi);
+}
+
+// MODE 1: code step 0.74 .. 1 half chips per sample -- the window advances every sample except at <= 4 holds (masks
+// M_d = ~0 << 2 u_d): spread.  MODE 2: code step <= 2/15 (sample rates from 15.4 MS/s) -- the window advances at <= 2
+// samples of the group (masks A_d = ~0 << 2 u_d): X = field 0 everywhere, field 1 from the first advance on, field 2
+// from the second.
+template <int MODE>
 __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &t)
 {
     const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
     uint32_t x = window_signed(__builtin_amdgcn_alignbit(t.hi, t.lo, (uint32_t)t.ic0 << 1) ^ mask);
-    x = gal_bfi(t.M.x, x << 2, x);
-    x = gal_bfi(t.M.y, x << 2, x);
-    x = gal_bfi(t.M.z, x << 2, x);
-    x = gal_bfi(t.M.w, x << 2, x);
+    if constexpr (MODE == 2) {
+        const uint32_t w = x;
+        x = gal_bfi(t.M.x, rw_rep(w, 1), rw_rep(w, 0));
+        x = gal_bfi(t.M.y, rw_rep(w, 2), x);
+    } else {
+        x = gal_bfi(t.M.x, x << 2, x);
+        x = gal_bfi(t.M.y, x << 2, x);
+        x = gal_bfi(t.M.z, x << 2, x);
+        x = gal_bfi(t.M.w, x << 2, x);
+    }
     return x;
 }
 
@@ -1453,8 +1472,9 @@ __device__ __forceinline__ void chan_step_cboc(ChanState &c, const double cs2, c
 #define GAL_MAX_NCH 12
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
 // SIG: 0 = BOC(1,1) as the reference generates it, 1 = CBOC(6,1,1/11) (see chan_step_cboc)
-// RW: 1 = fast groups take their 16 chip values from a RESAMPLED window (rw_phase_a/b/c) instead of indexing the window
-//     per sample; needs 0.74 <= 2 f_code / fs < 1 on every channel of the batch (the host decides: DevPlan::rw)
+// RW: 1, 2 = fast groups take their 16 chip values from a RESAMPLED window (rw_phase_a/b/c) instead of indexing the
+//     window per sample; 1 needs 0.74 <= 2 f_code / fs < 1 on every channel of the batch (2.6 MS/s), 2 needs
+//     2 f_code / fs <= 0.133 (15.4 MS/s and above: config 4's 25 MS/s); the host decides (DevPlan::rw)
 template <int NCH, bool ACC, int SIG = 0, int RW = 0>
 __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_WAVES))) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
                                                      const uint8_t *__restrict__ act_all,
@@ -1606,7 +1626,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             double gp = 0.0;  // floor(f), f < 1
             for (int u = 1; u <= 15; ++u) {
                 const double g = __builtin_floor(f + (double)u * s);
-                if (g == gp) {  // sample u holds the half chip of sample u - 1
+                if ((RW == 2) ? (g != gp) : (g == gp)) {  // RW 1: sample u HOLDS the half chip of sample u - 1; 2: ADVANCES
                     const uint32_t m = ~0u << (2 * u);
                     m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
                     ++d;
@@ -1796,7 +1816,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // ballot: no lane of the wave has any of the four codes within 16 samples of its wrap -> fast body.
 #define GAL_RW_A(j) if (j < NCH) rw_phase_a<j>(ch##j, rt##j, s_bin);
 #define GAL_RW_B(j) if (j < NCH) unsafe##j = rw_phase_b<j>(rt##j, str0, s_pat);
-#define GAL_RW_C(j) if (j < NCH) gx##j = rw_phase_c(ch##j, rt##j);
+#define GAL_RW_C(j) if (j < NCH) gx##j = rw_phase_c<RW>(ch##j, rt##j);
 #define GAL_STEP_R(j) if (j < NCH) chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc);
 #define GAL_PIN_R(a, b, c, d) asm volatile("" : "+v"(acc), "+v"(ch##a.p), "+v"(ch##b.p), "+v"(ch##c.p), "+v"(ch##d.p));
 // RW: the code NCO over the 16 samples of a fast group in three instructions.  Within a binade (and outside the tie
@@ -2086,9 +2106,12 @@ extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, i
     if (P->signal == 1)
         return accumulate ? launch_synth_t<true, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
                           : launch_synth_t<false, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
-    if (P->rw)
+    if (P->rw == 1)
         return accumulate ? launch_synth_t<true, 0, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
                           : launch_synth_t<false, 0, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
+    if (P->rw == 2)
+        return accumulate ? launch_synth_t<true, 0, 2>(P, Pd, nch, act, nact, iq, e0, ne, st)
+                          : launch_synth_t<false, 0, 2>(P, Pd, nch, act, nact, iq, e0, ne, st);
     return accumulate ? launch_synth_t<true, 0>(P, Pd, nch, act, nact, iq, e0, ne, st)
                       : launch_synth_t<false, 0>(P, Pd, nch, act, nact, iq, e0, ne, st);
 }

@@ -84,18 +84,21 @@ def test_sample_rates_window_limits(pkg, rate):
 
 
 @pytest.mark.parametrize("rate,mode", [(2.1e6, 1), (2.2e6, 1), (2.4e6, 1), (2.6e6, 1), (2.76e6, 1),
-                                       (2.0462e6, 0), (2.5e6, 0), (2.728e6, 0), (2.77e6, 0), (3.0e6, 0)])
+                                       (2.0462e6, 0), (2.5e6, 0), (2.728e6, 0), (2.77e6, 0), (3.0e6, 0),
+                                       (10e6, 0), (15.3e6, 0), (15.5e6, 2), (16e6, 2), (25e6, 2), (40e6, 2), (200e6, 2)])
 def test_resampled_window_rates(pkg, rate, mode):
     """k_synth's resampled-window fast body (one chip look-up pattern per 16-sample group, code NCO advanced once per
     group) serves batches with 0.74 <= 2 f_code / fs < 0.9999 whose 15 pattern thresholds are more than a bin apart
     (synth_api.cpp: rw_threshold_gap): the first five rates qualify (2.76 MS/s: four holds per group, the maximum);
     2.0462 MS/s (thresholds 1e-4 apart), 2.5 MS/s (step ~ 9/11) and 2.728 MS/s (step = 3/4) have clustered thresholds,
-    2.77 and 3.0 MS/s are out of range: those run the classic body (gal_synth_stats_t.window_mode says which).
+    2.77 and 3.0 MS/s are out of range: those run the classic body (gal_synth_stats_t.window_mode says which).  From
+    15.4 MS/s (code step <= 2/15 half chips) the body's second form takes over: the window ADVANCES at <= 2 samples of
+    a group instead of holding at <= 4 (config 4's 25 MS/s); 10 and 15.3 MS/s lie between the two forms.
     Epochs of 6.2 code periods so that every lane passes the small binades of the code phase (where the group advance
     has to add sample by sample) and the channel's tie binade."""
-    n_samp = int(rate * 0.025)
-    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=12, n_slots=12, samples_per_epoch=n_samp, sample_rate=rate,
-                                     seed=int(rate) % 997)
+    n_samp = int(rate * (0.025 if rate < 5e6 else 0.009 if rate < 100e6 else 0.0045))
+    p = pkg.workloads.make_synthetic(n_epochs=4 if rate < 100e6 else 2, n_chan=12, n_slots=12, samples_per_epoch=n_samp,
+                                     sample_rate=rate, seed=int(rate) % 997)
     _, _, stats = _compare(pkg, p, n_samp, rate=rate)
     assert stats["window_mode"] == mode
     _compare(pkg, p, n_samp, rate=rate, chunk_samples=208)
@@ -133,6 +136,13 @@ def test_classic_window_body_at_the_reference_rate(pkg, monkeypatch):
     monkeypatch.delenv("GAL_SYNTH_RW")
     _, _, stats = _compare(pkg, p, 52000, test_hooks=True)
     assert stats["window_mode"] == 1
+    # ... and the same at 25 MS/s, 24 channels (two launches, the second accumulating): advance form against classic
+    p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=24, n_slots=24, samples_per_epoch=250000, sample_rate=25e6, seed=98)
+    _, _, stats = _compare(pkg, p, 250000, rate=25e6, test_hooks=True)
+    assert stats["window_mode"] == 2
+    monkeypatch.setenv("GAL_SYNTH_RW", "0")
+    _, _, stats = _compare(pkg, p, 250000, rate=25e6, test_hooks=True)
+    assert stats["window_mode"] == 0
 
 
 def test_code_wrap_at_every_group_position(pkg):
