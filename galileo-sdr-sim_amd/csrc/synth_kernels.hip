@@ -1468,6 +1468,38 @@ __device__ __forceinline__ void chan_step_cboc(ChanState &c, const double cs2, c
     c.p = carr_step(c.p, __builtin_fabs(ds));
 }
 
+// CBOC inside the group machinery of the BOC(1,1) path: a group that cannot reach the code wrap (same countdown) reads
+// its half-chip fields from the 16-half-chip window, signs of the current symbol applied -- bit 0: B != C, i.e. the
+// (B - C) term is the one that is non-zero; bit 1: the sign of C x secondary x BOC(1,1) sub-carrier -- and needs
+// neither the wrap test nor the stream read of chan_step_cboc per sample.
+template <int J>
+__device__ __forceinline__ void group_begin_cboc(const ChanState &c, ChanGroup &g, const uint32_t *s_str)
+{
+    const int ic0 = (int)c.y;  // y < 8184 - 16*cs2: no wrap before the group ends
+    const uint32_t *wp = s_str + J * STR_PITCH + (ic0 >> 4);
+    const uint32_t lo = wp[0], hi = wp[1];
+    g.W = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)ic0 << 1) ^ GAL_SIGN_MASK((c.st >> 10) & 3u);
+    g.m = -2 * ic0;
+}
+
+__device__ __forceinline__ void chan_step_cboc_fast(ChanState &c, const ChanGroup &g, const double cs2, const double ds,
+                                                    const uint32_t lutb, int &acc)
+{
+    const int h = (int)c.y;
+    int off;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(h), "v"(g.m));
+    const uint32_t f = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);
+    const int i12 = (int)(6.0 * c.y);
+    const uint32_t nz = f & 1u;
+    const uint32_t sign = nz ? (f >> 1) : ((f >> 1) ^ 1u ^ ((uint32_t)(h ^ i12) & 1u));
+    const int k = (int)(511.0 * c.p);
+    const uint32_t a = lutb + (nz ? 0u : 8192u) + (uint32_t)(k << 2);
+    const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
+    gal_acc(acc, t, sign ? -1 : 1);
+    c.y = c.y + cs2;
+    c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));  // mirrored phase non-negative in a fast group (GAL_SAFE)
+}
+
 #define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define GAL_MAX_NCH 12
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
@@ -1723,8 +1755,13 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // bursts at 1.2x: tools/wrcal.hip).
     const bool vec_ok = ((((size_t)er * G.N + n0) & 15) == 0);
 
-    if constexpr (SIG == 1) {
-        // ---- CBOC: plain per-sample loop, four samples per 16-byte store
+#ifdef GAL_CBOC_PLAIN
+    constexpr bool kCbocPlain = SIG == 1;
+#else
+    constexpr bool kCbocPlain = false;
+#endif
+    if constexpr (kCbocPlain) {
+        // ---- CBOC: plain per-sample loop, four samples per 16-byte store (the first version; A/B builds only)
 #define GAL_SGN4(j) [[maybe_unused]] const uint32_t sg4##j = lut0 + (((uint32_t)(d2u(ds##j) >> 32) >> 31) << 12);
         GAL_CH_LIST(GAL_SGN4)
 #undef GAL_SGN4
@@ -1798,11 +1835,15 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         const int n = (int)(room * inv16); /* room < 0 -> n <= 0 */              \
         sf##a = negp < 0 ? 0 : n;                                                \
     }
-#define GAL_BEGIN_F(j) if (j < NCH) group_begin_fast<j>(ch##j, gr##j, s_str);
+#define GAL_BEGIN_F(j) if (j < NCH) { if constexpr (SIG == 1) group_begin_cboc<j>(ch##j, gr##j, s_str); else group_begin_fast<j>(ch##j, gr##j, s_str); }
 #define GAL_BEGIN_S(j) if (j < NCH) group_begin_slow<j>(ch##j, gr##j, s_str);
 /* LDS byte address of entry k = 0 of the channel's table: plain (ds >= 0) or conjugate (ds < 0); scalar ALU */
 #define GAL_SGN4(j) const uint32_t sg4##j = lut0 + (((uint32_t)(d2u(ds##j) >> 32) >> 31) << 12);
-#define GAL_STEP_F(j) if (j < NCH) chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
+#define GAL_STEP_F(j) if (j < NCH) { if constexpr (SIG == 1) { if (j < nact) chan_step_cboc_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); } \
+                                    else chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); }
+// CBOC slow groups: the per-sample step that tests the wrap and reads the stream itself (idle positions skipped: a CBOC
+// channel never contributes zero)
+#define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j>(ch##j, cs##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
 #define GAL_STEP_S(j) if (j < NCH) chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
 #define GAL_END(j) if (j < NCH) group_end(ch##j, gr##j, Pd, ix##j);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
@@ -1878,16 +1919,27 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             }                                                                    \
         }                                                                        \
         if (!fast) {                                                             \
-            GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)          \
-            GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
-            _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
-            {                                                                    \
-                int acc = o[u];                                                  \
-                GAL_STEP_S(a) GAL_STEP_S(b) GAL_STEP_S(c) GAL_STEP_S(d)          \
-                GAL_PIN(a, b, c, d)                                              \
-                o[u] = acc;                                                      \
+            if constexpr (SIG == 1) {                                            \
+                GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                  \
+                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
+                {                                                                \
+                    int acc = o[u];                                              \
+                    GAL_STEP_C(a) GAL_STEP_C(b) GAL_STEP_C(c) GAL_STEP_C(d)      \
+                    GAL_PIN(a, b, c, d)                                          \
+                    o[u] = acc;                                                  \
+                }                                                                \
+            } else {                                                             \
+                GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)      \
+                GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                  \
+                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
+                {                                                                \
+                    int acc = o[u];                                              \
+                    GAL_STEP_S(a) GAL_STEP_S(b) GAL_STEP_S(c) GAL_STEP_S(d)      \
+                    GAL_PIN(a, b, c, d)                                          \
+                    o[u] = acc;                                                  \
+                }                                                                \
+                GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)                      \
             }                                                                    \
-            GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)                          \
             if (GSZ == SYN_GROUP) { GAL_SAFE(a, b, c, d) }                       \
         }                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                       \
@@ -1959,6 +2011,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_BEGIN_F
 #undef GAL_BEGIN_S
 #undef GAL_STEP_F
+#undef GAL_STEP_C
 #undef GAL_STEP_S
 #undef GAL_END
 

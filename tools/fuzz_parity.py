@@ -3,7 +3,8 @@
 (slots, channels, epoch length, sample rate, chunking, Doppler incl. tiny / zero / sign flips / few-bit steps,
 channels appearing, vanishing and being re-allocated, symbol counters near the page flip, code phases near the
 wrap).  Test infrastructure: uses the oracle as the checker.   python tools/fuzz_parity.py [n_cases] [seed] [big]
-GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_SINGLE_LEGS=0: the long-batch stitcher on every batch)."""
+GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_SINGLE_LEGS=0: the long-batch stitcher on every batch).
+GAL_FUZZ_CBOC=1 runs the opt-in CBOC(6,1,1/11) mode against the checker's CBOC loop."""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ from oracle_binding import oracle_run  # noqa: E402
 
 pkg = load_pkg()
 RESTART = 1
+CBOC = bool(os.environ.get("GAL_FUZZ_CBOC"))
 
 
 def random_case(rng, big=False):
@@ -96,7 +98,8 @@ def main():
         p, n_samp, rate, chunk = random_case(rng, big)
         try:
             with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0,
-                                 chunk_samples=chunk, test_hooks=bool(os.environ.get("GAL_FUZZ_HOOKS"))) as eng:
+                                 chunk_samples=chunk, test_hooks=bool(os.environ.get("GAL_FUZZ_HOOKS")),
+                                 flags=pkg.synth.GAL_CFG_CBOC if CBOC else 0) as eng:
                 cut = int(rng.integers(1, p.shape[0])) if (p.shape[0] > 1 and rng.random() < 0.4) else 0
                 if cut:  # the same run in two calls, the channel state carried by the caller
                     iq1, st1, stats = eng.run_host(p[:cut])
@@ -112,7 +115,7 @@ def main():
             msg = str(ex)
             key = msg.split(":")[-1].strip()[:50]
             try:
-                oracle_run(p, n_samp, rate)
+                oracle_run(p, n_samp, rate, cboc=CBOC)
             except Exception:
                 rejected["(oracle too) " + key] = rejected.get("(oracle too) " + key, 0) + 1
                 continue
@@ -122,7 +125,7 @@ def main():
             print("case %d: engine rejected: %s" % (c, msg))
             bad += 1
             continue
-        ref_iq, ref_st = oracle_run(p, n_samp, rate)
+        ref_iq, ref_st = oracle_run(p, n_samp, rate, cboc=CBOC)
         n_run += 1
         samples += p.shape[0] * n_samp
         act = ref_st["prn"] > 0
