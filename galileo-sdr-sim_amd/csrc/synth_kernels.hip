@@ -1490,12 +1490,15 @@ __device__ __forceinline__ void chan_step_cboc_fast(ChanState &c, const ChanGrou
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(h), "v"(g.m));
     const uint32_t f = __builtin_amdgcn_ubfe(g.W, (uint32_t)off, 2);
     const int i12 = (int)(6.0 * c.y);
-    const uint32_t nz = f & 1u;
-    const uint32_t sign = nz ? (f >> 1) : ((f >> 1) ^ 1u ^ ((uint32_t)(h ^ i12) & 1u));
+    // branch-free: bit 0 of f = 1: (B - C) term, sign = bit 1; = 0: (B + C) term, sign = bit 1 ^ 1 ^ parity(h ^ i12)
+    uint32_t par = (uint32_t)(h ^ i12);
+    asm("" : "+v"(par));  // (keeps the compiler from predicating the (int)(6y) path on bit 0: exec-mask juggling per sample)
+    const uint32_t flip = ~(f | par) & 1u;
+    const int v = 1 - 2 * (int)((f >> 1) ^ flip);
     const int k = (int)(511.0 * c.p);
-    const uint32_t a = lutb + (nz ? 0u : 8192u) + (uint32_t)(k << 2);
+    const uint32_t a = lutb + ((~f & 1u) << 13) + (uint32_t)(k << 2);  // B tables 8 KB behind the A tables
     const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
-    gal_acc(acc, t, sign ? -1 : 1);
+    gal_acc(acc, t, v);
     c.y = c.y + cs2;
     c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));  // mirrored phase non-negative in a fast group (GAL_SAFE)
 }
@@ -1839,7 +1842,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #define GAL_BEGIN_S(j) if (j < NCH) group_begin_slow<j>(ch##j, gr##j, s_str);
 /* LDS byte address of entry k = 0 of the channel's table: plain (ds >= 0) or conjugate (ds < 0); scalar ALU */
 #define GAL_SGN4(j) const uint32_t sg4##j = lut0 + (((uint32_t)(d2u(ds##j) >> 32) >> 31) << 12);
-#define GAL_STEP_F(j) if (j < NCH) { if constexpr (SIG == 1) { if (j < nact) chan_step_cboc_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); } \
+#define GAL_STEP_F(j) if (j < NCH) { if constexpr (SIG == 1) { if (full || j < nact) chan_step_cboc_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); } \
                                     else chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); }
 // CBOC slow groups: the per-sample step that tests the wrap and reads the stream itself (idle positions skipped: a CBOC
 // channel never contributes zero)
@@ -1877,6 +1880,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         }                                                                                     \
         ch##j.y = y16;                                                                        \
     }
+#define GAL_LAST_OF(a, b, c, d) ((d) < NCH ? (d) : (c) < NCH ? (c) : (b) < NCH ? (b) : (a))
 #define GAL_PART(a, b, c, d)                                                     \
     if (a < NCH) {                                                               \
         ChanGroup gr##a = {0u, 0, 1}, gr##b = {0u, 0, 1};                        \
@@ -1910,12 +1914,26 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             sf##a -= 1;                                                          \
             GAL_BEGIN_F(a) GAL_BEGIN_F(b) GAL_BEGIN_F(c) GAL_BEGIN_F(d)          \
             GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                      \
-            _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                      \
-            {                                                                    \
-                int acc = o[u];                                                  \
-                GAL_STEP_F(a) GAL_STEP_F(b) GAL_STEP_F(c) GAL_STEP_F(d)          \
-                if (u & 1) { GAL_PIN(a, b, c, d) } /* 2 steps per scheduling unit: measured best (1: -2 %, 4: spills) */ \
-                o[u] = acc;                                                      \
+            /* CBOC: a channel never contributes zero, so idle positions must be skipped; the usual epoch has all */ \
+            /* positions of the part active: one test per group instead of one per channel and sample             */ \
+            if (SIG != 1 || GAL_LAST_OF(a, b, c, d) < nact) {                    \
+                constexpr bool full = true;                                      \
+                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
+                {                                                                \
+                    int acc = o[u];                                              \
+                    GAL_STEP_F(a) GAL_STEP_F(b) GAL_STEP_F(c) GAL_STEP_F(d)      \
+                    if (u & 1) { GAL_PIN(a, b, c, d) } /* 2 steps per scheduling unit: measured best (1: -2 %, 4: spills) */ \
+                    o[u] = acc;                                                  \
+                }                                                                \
+            } else {                                                             \
+                constexpr bool full = false;                                     \
+                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
+                {                                                                \
+                    int acc = o[u];                                              \
+                    GAL_STEP_F(a) GAL_STEP_F(b) GAL_STEP_F(c) GAL_STEP_F(d)      \
+                    if (u & 1) { GAL_PIN(a, b, c, d) }                           \
+                    o[u] = acc;                                                  \
+                }                                                                \
             }                                                                    \
         }                                                                        \
         if (!fast) {                                                             \
@@ -2000,6 +2018,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_SAFE
 #undef GAL_ROOM
 #undef GAL_PART
+#undef GAL_LAST_OF
 #undef GAL_ADV
 #undef GAL_RW_A
 #undef GAL_RW_B
