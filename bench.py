@@ -160,7 +160,7 @@ def leg_file_sink(seconds=120):
 
 def leg_config(torch, pkg, workload, epochs, steps, local_rank):
     """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
-    bounded epoch count), pipelined like the headline."""
+    bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode), pipelined like the headline."""
     n_samp, rate, n_slots, n_chan = 260000, 2.6e6, 16, 12
     if workload == "syn24":
         n_samp, rate, n_slots, n_chan = 2500000, 25e6, 24, 24
@@ -168,7 +168,8 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank):
                                      dyn_track=(workload == "dyn"))
     engines, outs = [], []
     for _ in range(2):
-        eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank)
+        eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
+                              flags=pkg.synth.GAL_CFG_CBOC if workload == "cboc" else 0)
         st = torch.cuda.Stream()
         eng.set_stream(st.cuda_stream)
         eng.plan(params)
@@ -197,7 +198,7 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank):
     value = epochs * n_samp * steps / dt / 1e6
     return {"value": round(value, 1), "unit": "Msamples/s", "x_realtime": round(value * 1e6 / rate, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "epochs": epochs, "channels": n_chan, "samples_per_epoch": n_samp, "steps": steps,
-            "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3)}
+            "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3), "window_mode": stats[-1].get("window_mode")}
 
 
 def profiled_kernel_ms():
@@ -467,7 +468,9 @@ def main():
             torch.cuda.empty_cache()
             line["e2e"]["file_sink"] = leg_file_sink()
             line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 6, local_rank),
-                               "syn24": leg_config(torch, pkg, "syn24", 600, 4, local_rank)}
+                               "syn24": leg_config(torch, pkg, "syn24", 600, 4, local_rank),
+                               # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
+                               "cboc": leg_config(torch, pkg, "cboc", 1199, 10, local_rank)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
         line["x_realtime"] = round(value * 1e6 / rate, 2)
