@@ -569,7 +569,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
     P.rw = (rw_ok && P.signal == 0) ? rw_mode : 0;
 #ifdef GAL_TEST_HOOKS
-    if (const char *env = getenv("GAL_SYNTH_RW")) P.rw = atoi(env) != 0 ? P.rw : 0;  // 0: classic windows (A/B runs)
+    // 0: classic windows (A/B runs); 11 / 12: force form 1 / 2 whatever the gate says (the kernel's own safety nets
+    // -- undecidable bins, pattern overflow -- must then keep the output exact)
+    if (const char *env = getenv("GAL_SYNTH_RW")) {
+        const int v = atoi(env);
+        P.rw = v == 0 ? 0 : (v == 11 || v == 12) ? (P.signal == 0 ? v - 10 : 0) : P.rw;
+    }
 #endif
 
     // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and

@@ -1525,6 +1525,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     __shared__ uint4 s_pat[RW ? NCH * 16 : 1];
     __shared__ float s_thr[RW ? NCH * 16 : 1];
     __shared__ double s_tie[GAL_MAX_NCH];
+    __shared__ int s_rwbad;  // RW: a channel's group has more holds / advances than the pattern masks hold (the host's
+                             // gate excludes it; if it happens all the same, every group of the block runs the slow body)
 
     const int er = blockIdx.x / G.blocks_per_epoch;  // epoch relative to the executed range
     const int tg = blockIdx.x - er * G.blocks_per_epoch;
@@ -1601,6 +1603,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     if constexpr (RW) {
         // ---- hold patterns, step A: the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted: thread
         // (channel, u) ranks its own; thread (channel, 16) writes the sentinel and the tie binade of the code step
+        if (tid == 0) s_rwbad = 0;
         if (tid < NCH * 16) {
             const int j = tid >> 4, u = (tid & 15) + 1;
             const double s = rw_step_of(j);
@@ -1669,10 +1672,12 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 gp = g;
             }
             if (j >= nact) m0 = m1 = m2 = m3 = 0u;
+            else if (d > (RW == 2 ? 2 : 4)) s_rwbad = 1;
             s_pat[tid] = make_uint4(m0, m1, m2, m3);
         }
         __syncthreads();
     }
+    [[maybe_unused]] const bool rw_off = RW != 0 && __builtin_amdgcn_readfirstlane(s_rwbad) != 0;
 
     // Position L of the epoch -> chunk c.  When the chunk length divides the code period (cls chunks per period),
     // the positions are ordered by CODE-PHASE CLASS c % cls first: all chunks of a class start at the same code phase,
@@ -1885,7 +1890,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     if (a < NCH) {                                                               \
         ChanGroup gr##a = {0u, 0, 1}, gr##b = {0u, 0, 1};                        \
         ChanGroup gr##c = {0u, 0, 1}, gr##d = {0u, 0, 1};                        \
-        const bool near = (GSZ != SYN_GROUP) | (sf##a < 1);                      \
+        const bool near = (GSZ != SYN_GROUP) | (sf##a < 1) | rw_off;             \
         bool fast = __builtin_amdgcn_ballot_w64(near) == 0;                      \
         if constexpr (RW != 0) {                                                 \
             [[maybe_unused]] uint32_t gx##a = 0u, gx##b = 0u, gx##c = 0u, gx##d = 0u; \

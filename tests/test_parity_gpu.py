@@ -145,6 +145,20 @@ def test_classic_window_body_at_the_reference_rate(pkg, monkeypatch):
     assert stats["window_mode"] == 0
 
 
+@pytest.mark.parametrize("rate,force", [(3.0e6, 11), (2.5e6, 11), (2.0462e6, 11), (10e6, 12), (4.0e6, 12), (2.6e6, 12)])
+def test_resampled_window_safety_nets(pkg, monkeypatch, rate, force):
+    """The host's gate keeps the resampled-window bodies away from rates they do not serve.  Forced onto such rates
+    (GAL_TEST_HOOKS build) the kernel's own nets must hold: more holds / advances per group than the pattern masks carry
+    (3 MS/s in form 1; 2.6, 4 and 10 MS/s in form 2) turn the block over to the slow body; clustered thresholds
+    (2.5 and 2.0462 MS/s in form 1) leave bins undecidable, whose lanes do the same group by group."""
+    monkeypatch.setenv("GAL_SYNTH_RW", str(force))
+    n_samp = int(rate * 0.012)
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=8, n_slots=8, samples_per_epoch=n_samp, sample_rate=rate,
+                                     seed=int(rate) % 991 + force)
+    _, _, stats = _compare(pkg, p, n_samp, rate=rate, test_hooks=True)
+    assert stats["window_mode"] == force - 10
+
+
 def test_code_wrap_at_every_group_position(pkg):
     """Code phases chosen so that the wrap (x >= 4092) falls on each of the 16 positions of a sample group,
     including the first sample (wrap pending from the previous group) and the first sample of a chunk."""
