@@ -31,6 +31,10 @@ def test_struct_layouts_match_header(pkg):
                               "page_init")] == [0, 4, 8, 16, 24, 32, 40, 48, 112]
     g = pkg.CHAN_STATE_DTYPE.fields
     assert [g[k][1] for k in ("carr_phase", "page", "prn")] == [0, 8, 72]
+    import ctypes
+
+    st = pkg.synth._Stats
+    assert ctypes.sizeof(st) == 40 and st.ms_walk.offset == 24 and st.window_mode.offset == 32 and st.synth_runs.offset == 36
 
 
 def test_version_and_tables_without_gpu(pkg):
