@@ -467,8 +467,8 @@ def main():
             del outs[:], out
             torch.cuda.empty_cache()
             line["e2e"]["file_sink"] = leg_file_sink()
-            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 6, local_rank),
-                               "syn24": leg_config(torch, pkg, "syn24", 600, 4, local_rank),
+            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 16, local_rank),
+                               "syn24": leg_config(torch, pkg, "syn24", 600, 8, local_rank),
                                # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
                                "cboc": leg_config(torch, pkg, "cboc", 1199, 10, local_rank)}
         if world == 1 and not args.no_cpu_baseline:
