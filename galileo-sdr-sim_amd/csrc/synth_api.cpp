@@ -41,6 +41,7 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 #endif
 
 extern "C" {
+void galk_warm(hipStream_t st);
 void galk_launch_prep(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
@@ -279,6 +280,11 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     }
     if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
+    galk_warm(nullptr);  // code-object load now, not inside the first batch
+    if (hipStreamSynchronize(nullptr) != hipSuccess) {
+        gal_synth_destroy(h);
+        return fail(GAL_E_DEVICE, "kernel launch failed on device %d: %s", dev, hipGetErrorString(hipGetLastError()));
+    }
     *out = h;
     return GAL_OK;
 }

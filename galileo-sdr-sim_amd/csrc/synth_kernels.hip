@@ -2087,6 +2087,11 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 
 // ------------------------------------------------------------------------------------------------
 // Launchers (called from synth_api.cpp, which is plain C++ and does not see <<<>>>).
+// Loads the code object (HIP does that at the first launch of any of its kernels: ~20 ms for the ~4 MB of k_synth
+// instantiations) when the handle is created instead of inside the caller's first batch.
+__global__ void k_warm() {}
+extern "C" void galk_warm(hipStream_t st) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st); }
+
 extern "C" void galk_launch_prep(const DevPlan *P, hipStream_t st)
 {
     const int n = P->E * P->S;
