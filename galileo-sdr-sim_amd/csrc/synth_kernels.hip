@@ -2172,13 +2172,24 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1; G.blocks_per_epoch = P->blocks_per_epoch;
     G.cls = P->cls > 0 ? P->cls : 1;
     G.per = P->nchunks / G.cls;
-    switch (nch) {
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC, SIG, RW>), grid, block, 0, st, Pd, G, act, nact, iq); break;
-        GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
-        GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
-#undef GAL_CASE
-    default: return -1;
+    if constexpr (SIG == 1) {
+        // the opt-in CBOC mode is built for 4, 8 and 12 positions only (a third of the compile time of this file went
+        // into its 24 instantiations): positions beyond the active count are idle and skipped like in any epoch with
+        // fewer channels than the launch was sized for
+        if (nch < 1 || nch > 12) return -1;
+        switch ((nch + 3) / 4 * 4) {
+            GAL_CASE(4) GAL_CASE(8) GAL_CASE(12)
+        default: return -1;
+        }
+    } else {
+        switch (nch) {
+            GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
+            GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
+        default: return -1;
+        }
     }
+#undef GAL_CASE
     return 0;
 }
 
