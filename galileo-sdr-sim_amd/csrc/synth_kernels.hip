@@ -33,10 +33,25 @@
 
 using namespace galnco;
 
+// The file is compiled as five translation units, side by side (Makefile: -DGAL_TU=0..4), because the instantiations of
+// k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
+// GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
+// by both libraries.  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
+#if !defined(GAL_TU)
+#define GAL_TU_WALK 1
+#define GAL_TU_SYNTH 1
+#define GAL_TU_FAMILY(k) 1
+#else
+#define GAL_TU_WALK (GAL_TU == 0)
+#define GAL_TU_SYNTH (GAL_TU != 0)
+#define GAL_TU_FAMILY(k) (GAL_TU == (k))
+#endif
+
 #ifdef GAL_TEST_HOOKS
 #define GAL_HOOK_BAD_LEG 5  // (slot 0, epoch 0, leg 5) receives a wrong translation when P.translate == 2
 #endif
 
+#if GAL_TU_WALK
 // ------------------------------------------------------------------------------------------------
 __global__ void k_prep(DevPlan P)
 {
@@ -1106,6 +1121,9 @@ __global__ void k_state_phase(DevPlan P)
     P.state_out[s].carr_phase = prn > 0 ? P.pend[(size_t)s * P.LEGS + (P.LEGS - 1)] : 0.0;
 }
 
+#endif  // GAL_TU_WALK
+
+#if GAL_TU_SYNTH
 // ------------------------------------------------------------------------------------------------
 // Hot kernel.  Block = 256 threads = 4 waves = 4 tiles of 64 chunks of ONE epoch, so every per-epoch
 // constant (NCO steps, active PRNs) is wave-uniform and lives in SGPRs.
@@ -2085,12 +2103,11 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     }
 }
 
+#endif  // GAL_TU_SYNTH
+
 // ------------------------------------------------------------------------------------------------
 // Launchers (called from synth_api.cpp, which is plain C++ and does not see <<<>>>).
-// Loads the code object (HIP does that at the first launch of any of its kernels: ~20 ms for the ~4 MB of k_synth
-// instantiations) when the handle is created instead of inside the caller's first batch.
-__global__ void k_warm() {}
-extern "C" void galk_warm(hipStream_t st) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st); }
+#if GAL_TU_WALK
 
 extern "C" void galk_launch_prep(const DevPlan *P, hipStream_t st)
 {
@@ -2162,6 +2179,9 @@ extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
     hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
 }
 
+#endif  // GAL_TU_WALK
+
+#if GAL_TU_SYNTH
 template <bool ACC, int SIG, int RW = 0>
 static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact,
                           uint32_t *iq, int e0, int ne, hipStream_t st)
@@ -2193,18 +2213,58 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     return 0;
 }
 
+// One launcher and one no-op kernel per k_synth family (each family is its own code object in the product build; HIP
+// loads a code object at the first launch of any of its kernels -- ~10 ms for the larger ones --, which galk_warm moves
+// from the caller's first batch into gal_synth_create).
+#define GAL_FAMILY(K, SIG, RW)                                                                                       \
+    __global__ void k_warm_f##K() {}                                                                                 \
+    extern "C" void galk_warm_f##K(hipStream_t st) { hipLaunchKernelGGL(k_warm_f##K, dim3(1), dim3(64), 0, st); }    \
+    extern "C" int galk_launch_synth_f##K(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate,               \
+                                          const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne,         \
+                                          hipStream_t st)                                                             \
+    {                                                                                                                \
+        return accumulate ? launch_synth_t<true, SIG, RW>(P, Pd, nch, act, nact, iq, e0, ne, st)                      \
+                          : launch_synth_t<false, SIG, RW>(P, Pd, nch, act, nact, iq, e0, ne, st);                    \
+    }
+#if GAL_TU_FAMILY(1)
+GAL_FAMILY(1, 0, 0)
+#endif
+#if GAL_TU_FAMILY(2)
+GAL_FAMILY(2, 0, 1)
+#endif
+#if GAL_TU_FAMILY(3)
+GAL_FAMILY(3, 0, 2)
+#endif
+#if GAL_TU_FAMILY(4)
+GAL_FAMILY(4, 1, 0)
+#endif
+#undef GAL_FAMILY
+#endif  // GAL_TU_SYNTH
+
+#if GAL_TU_WALK
+#define GAL_FAMILY_DECL(K)                                                                                           \
+    extern "C" void galk_warm_f##K(hipStream_t st);                                                                  \
+    extern "C" int galk_launch_synth_f##K(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate,               \
+                                          const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st);
+GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4)
+#undef GAL_FAMILY_DECL
+
+__global__ void k_warm() {}
+extern "C" void galk_warm(hipStream_t st)
+{
+    hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st);
+    galk_warm_f1(st);
+    galk_warm_f2(st);
+    galk_warm_f3(st);
+    galk_warm_f4(st);
+}
+
 extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
                                  const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st)
 {
-    if (P->signal == 1)
-        return accumulate ? launch_synth_t<true, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
-                          : launch_synth_t<false, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
-    if (P->rw == 1)
-        return accumulate ? launch_synth_t<true, 0, 1>(P, Pd, nch, act, nact, iq, e0, ne, st)
-                          : launch_synth_t<false, 0, 1>(P, Pd, nch, act, nact, iq, e0, ne, st);
-    if (P->rw == 2)
-        return accumulate ? launch_synth_t<true, 0, 2>(P, Pd, nch, act, nact, iq, e0, ne, st)
-                          : launch_synth_t<false, 0, 2>(P, Pd, nch, act, nact, iq, e0, ne, st);
-    return accumulate ? launch_synth_t<true, 0>(P, Pd, nch, act, nact, iq, e0, ne, st)
-                      : launch_synth_t<false, 0>(P, Pd, nch, act, nact, iq, e0, ne, st);
+    if (P->signal == 1) return galk_launch_synth_f4(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->rw == 1) return galk_launch_synth_f2(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->rw == 2) return galk_launch_synth_f3(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    return galk_launch_synth_f1(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
 }
+#endif  // GAL_TU_WALK
