@@ -348,7 +348,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
     // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel, thresholds a bin apart
     bool rw_ok = true;
-    int rw_mode = 0;  // 1: holds (code step 0.74 .. 1 half chips per sample), 2: advances (<= 0.133); one mode per batch
+    int rw_mode = 0;  // 1: holds (code step 0.74 .. 1 half chips per sample), 2: <= 2 advances (<= 0.133), 3: <= 4 advances
+                      // (<= 0.266); one form per batch
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); }
     const double delt = 1.0 / h->cfg.sample_rate;
     for (int e = 0; e < E; ++e) {
@@ -383,7 +384,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             cur_prn[s] = r.prn;
             if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
-                const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : 0;
+                const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
                 rw_ok = mode != 0 && (rw_mode == 0 || rw_mode == mode);
                 rw_mode = mode;
                 if (rw_ok && !(h->rw_g0[s] - 30.0 * std::fabs(cs2 - h->rw_s0[s]) > kRwMinGap)) {
@@ -575,11 +576,11 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
     P.rw = (rw_ok && P.signal == 0) ? rw_mode : 0;
 #ifdef GAL_TEST_HOOKS
-    // 0: classic windows (A/B runs); 11 / 12: force form 1 / 2 whatever the gate says (the kernel's own safety nets
+    // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)
     if (const char *env = getenv("GAL_SYNTH_RW")) {
         const int v = atoi(env);
-        P.rw = v == 0 ? 0 : (v == 11 || v == 12) ? (P.signal == 0 ? v - 10 : 0) : P.rw;
+        P.rw = v == 0 ? 0 : (v >= 11 && v <= 13) ? (P.signal == 0 ? v - 10 : 0) : P.rw;
     }
 #endif
 

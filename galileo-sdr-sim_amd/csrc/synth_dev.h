@@ -74,7 +74,7 @@ struct DevPlan {
     const int *lut;       // [512] int16 pairs (2 cos, 2 sin), low half first; CBOC: [2][512] = 2 TA, 2 TB
     int signal;           // 0 BOC(1,1) (the reference), 1 CBOC(6,1,1/11) (GAL_CFG_CBOC)
     int rw;               // resampled-window body of k_synth: 1 every code step has 0.74 <= 2 f_code / fs < 1 (holds),
-                          // 2 every code step has 2 f_code / fs <= 0.133 (advances), 0 classic per-sample window index
+                          // 2 / 3 every code step has 2 f_code / fs <= 0.133 / 0.266 (<= 2 / 4 advances), 0 classic per-sample window index
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 

@@ -36,7 +36,7 @@ using namespace galnco;
 // The file is compiled as five translation units, side by side (Makefile: -DGAL_TU=0..4), because the instantiations of
 // k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
 // GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
-// by both libraries.  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
+// by both libraries; TU 5 the family (0, 3).  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
 #if !defined(GAL_TU)
 #define GAL_TU_WALK 1
 #define GAL_TU_SYNTH 1
@@ -1315,7 +1315,7 @@ __device__ __forceinline__ uint32_t rw_rep(const uint32_t w, const int d)
 // MODE 1: code step 0.74 .. 1 half chips per sample -- the window advances every sample except at <= 4 holds (masks
 // M_d = ~0 << 2 u_d): spread.  MODE 2: code step <= 2/15 (sample rates from 15.4 MS/s) -- the window advances at <= 2
 // samples of the group (masks A_d = ~0 << 2 u_d): X = field 0 everywhere, field 1 from the first advance on, field 2
-// from the second.
+// from the second.  MODE 3: the same with <= 4 advances, code step <= 4/15 (7.7 .. 15.4 MS/s).
 template <int MODE>
 __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &t)
 {
@@ -1325,6 +1325,12 @@ __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &
         const uint32_t w = x;
         x = gal_bfi(t.M.x, rw_rep(w, 1), rw_rep(w, 0));
         x = gal_bfi(t.M.y, rw_rep(w, 2), x);
+    } else if constexpr (MODE == 3) {  // <= 4 advances: code step <= 4/15 half chips (7.7 .. 15.4 MS/s)
+        const uint32_t w = x;
+        x = gal_bfi(t.M.x, rw_rep(w, 1), rw_rep(w, 0));
+        x = gal_bfi(t.M.y, rw_rep(w, 2), x);
+        x = gal_bfi(t.M.z, rw_rep(w, 3), x);
+        x = gal_bfi(t.M.w, rw_rep(w, 4), x);
     } else {
         x = gal_bfi(t.M.x, x << 2, x);
         x = gal_bfi(t.M.y, x << 2, x);
@@ -1682,7 +1688,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             double gp = 0.0;  // floor(f), f < 1
             for (int u = 1; u <= 15; ++u) {
                 const double g = __builtin_floor(f + (double)u * s);
-                if ((RW == 2) ? (g != gp) : (g == gp)) {  // RW 1: sample u HOLDS the half chip of sample u - 1; 2: ADVANCES
+                if ((RW >= 2) ? (g != gp) : (g == gp)) {  // RW 1: sample u HOLDS the half chip of sample u - 1; 2, 3: ADVANCES
                     const uint32_t m = ~0u << (2 * u);
                     m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
                     ++d;
@@ -1690,7 +1696,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 gp = g;
             }
             if (j >= nact) m0 = m1 = m2 = m3 = 0u;
-            else if (d > (RW == 2 ? 2 : 4)) s_rwbad = 1;
+            else if (d > (RW == 2 ? 2 : 4)) s_rwbad = 1;  // (form 1: 4 holds, form 2: 2 advances, form 3: 4 advances)
             s_pat[tid] = make_uint4(m0, m1, m2, m3);
         }
         __syncthreads();
@@ -2238,6 +2244,9 @@ GAL_FAMILY(3, 0, 2)
 #if GAL_TU_FAMILY(4)
 GAL_FAMILY(4, 1, 0)
 #endif
+#if GAL_TU_FAMILY(5)
+GAL_FAMILY(5, 0, 3)
+#endif
 #undef GAL_FAMILY
 #endif  // GAL_TU_SYNTH
 
@@ -2246,7 +2255,7 @@ GAL_FAMILY(4, 1, 0)
     extern "C" void galk_warm_f##K(hipStream_t st);                                                                  \
     extern "C" int galk_launch_synth_f##K(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate,               \
                                           const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st);
-GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4)
+GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_FAMILY_DECL(5)
 #undef GAL_FAMILY_DECL
 
 __global__ void k_warm() {}
@@ -2257,6 +2266,7 @@ extern "C" void galk_warm(hipStream_t st)
     galk_warm_f2(st);
     galk_warm_f3(st);
     galk_warm_f4(st);
+    galk_warm_f5(st);
 }
 
 extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
@@ -2265,6 +2275,7 @@ extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, i
     if (P->signal == 1) return galk_launch_synth_f4(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
     if (P->rw == 1) return galk_launch_synth_f2(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
     if (P->rw == 2) return galk_launch_synth_f3(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->rw == 3) return galk_launch_synth_f5(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
     return galk_launch_synth_f1(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
 }
 #endif  // GAL_TU_WALK

@@ -105,10 +105,10 @@ typedef struct gal_synth_stats {
     int32_t chunks_per_epoch;
     float   ms_walk;            /* device time of the walker kernels, last execute (0 if timing disabled)      */
     float   ms_synth;           /* device time of the synthesis kernel, last execute                           */
-    int32_t window_mode;        /* fast body of the synthesis kernel: 1 / 2 resampled windows (one chip-pattern look-up per
+    int32_t window_mode;        /* fast body of the synthesis kernel: 1 / 2 / 3 resampled windows (one chip-pattern look-up per
                                    16 samples; 1: 0.74 <= 2 f_code / fs < 1, as at the reference's 2.6 MS/s; 2: 2 f_code / fs
-                                   <= 0.133, sample rates from 15.4 MS/s; both need well separated pattern thresholds),
-                                   0 per-sample window index (any rate).  Same bits either way                        */
+                                   <= 0.133, sample rates from 15.4 MS/s; 3: <= 0.266, from 7.7 MS/s; all need well
+                                   separated pattern thresholds), 0 per-sample window index (any rate).  Same bits either way */
     int32_t synth_runs;         /* synthesis launches the last batch took: 1, or 2 when gal_synth_finish() had to repeat
                                    it (carrier chain not complete when the kernel was started, or the replay check failed) */
 } gal_synth_stats_t;

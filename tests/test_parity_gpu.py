@@ -85,7 +85,8 @@ def test_sample_rates_window_limits(pkg, rate):
 
 @pytest.mark.parametrize("rate,mode", [(2.1e6, 1), (2.2e6, 1), (2.4e6, 1), (2.6e6, 1), (2.76e6, 1),
                                        (2.0462e6, 0), (2.5e6, 0), (2.728e6, 0), (2.77e6, 0), (3.0e6, 0),
-                                       (10e6, 0), (15.3e6, 0), (15.5e6, 2), (16e6, 2), (25e6, 2), (40e6, 2), (200e6, 2)])
+                                       (5e6, 0), (7.6e6, 0), (7.8e6, 3), (10e6, 3), (12.5e6, 3), (15.3e6, 3),
+                                       (15.5e6, 2), (16e6, 2), (25e6, 2), (40e6, 2), (200e6, 2)])
 def test_resampled_window_rates(pkg, rate, mode):
     """k_synth's resampled-window fast body (one chip look-up pattern per 16-sample group, code NCO advanced once per
     group) serves batches with 0.74 <= 2 f_code / fs < 0.9999 whose 15 pattern thresholds are more than a bin apart
@@ -93,7 +94,8 @@ def test_resampled_window_rates(pkg, rate, mode):
     2.0462 MS/s (thresholds 1e-4 apart), 2.5 MS/s (step ~ 9/11) and 2.728 MS/s (step = 3/4) have clustered thresholds,
     2.77 and 3.0 MS/s are out of range: those run the classic body (gal_synth_stats_t.window_mode says which).  From
     15.4 MS/s (code step <= 2/15 half chips) the body's second form takes over: the window ADVANCES at <= 2 samples of
-    a group instead of holding at <= 4 (config 4's 25 MS/s); 10 and 15.3 MS/s lie between the two forms.
+    a group instead of holding at <= 4 (config 4's 25 MS/s); the third form does the same with <= 4 advances (7.7 to
+    15.4 MS/s); 5 and 7.6 MS/s lie between the forms.
     Epochs of 6.2 code periods so that every lane passes the small binades of the code phase (where the group advance
     has to add sample by sample) and the channel's tie binade."""
     n_samp = int(rate * (0.025 if rate < 5e6 else 0.009 if rate < 100e6 else 0.0045))
@@ -145,12 +147,14 @@ def test_classic_window_body_at_the_reference_rate(pkg, monkeypatch):
     assert stats["window_mode"] == 0
 
 
-@pytest.mark.parametrize("rate,force", [(3.0e6, 11), (2.5e6, 11), (2.0462e6, 11), (10e6, 12), (4.0e6, 12), (2.6e6, 12)])
+@pytest.mark.parametrize("rate,force", [(3.0e6, 11), (2.5e6, 11), (2.0462e6, 11), (10e6, 12), (4.0e6, 12), (2.6e6, 12),
+                                        (4.0e6, 13), (2.6e6, 13), (25e6, 13)])
 def test_resampled_window_safety_nets(pkg, monkeypatch, rate, force):
     """The host's gate keeps the resampled-window bodies away from rates they do not serve.  Forced onto such rates
     (GAL_TEST_HOOKS build) the kernel's own nets must hold: more holds / advances per group than the pattern masks carry
-    (3 MS/s in form 1; 2.6, 4 and 10 MS/s in form 2) turn the block over to the slow body; clustered thresholds
-    (2.5 and 2.0462 MS/s in form 1) leave bins undecidable, whose lanes do the same group by group."""
+    (3 MS/s in form 1; 2.6, 4 and 10 MS/s in form 2; 2.6 and 4 MS/s in form 3) turn the block over to the slow body;
+    clustered thresholds (2.5 and 2.0462 MS/s in form 1) leave bins undecidable, whose lanes do the same group by group;
+    25 MS/s in form 3 is simply the wider form on a rate the narrower one serves."""
     monkeypatch.setenv("GAL_SYNTH_RW", str(force))
     n_samp = int(rate * 0.012)
     p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=8, n_slots=8, samples_per_epoch=n_samp, sample_rate=rate,

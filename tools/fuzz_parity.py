@@ -24,7 +24,7 @@ CBOC = bool(os.environ.get("GAL_FUZZ_CBOC"))
 
 
 def random_case(rng, big=False):
-    rate = float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 4.0e6, 4.092e6, 10e6, 15.4e6, 16e6, 25e6, 25e6, 40e6]))
+    rate = float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 4.0e6, 4.092e6, 7.7e6, 8e6, 10e6, 12.5e6, 15.4e6, 16e6, 25e6, 25e6, 40e6]))
     n_slots = int(rng.choice([4, 8, 16, 16, 24, 40, 64]))
     n_chan = int(rng.integers(1, n_slots + 1))
     n_ep = int(rng.integers(1, 7))
