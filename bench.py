@@ -414,7 +414,7 @@ def main():
                     args.epochs, n_samp, rate / 1e6),
                 "channels": args.channels,
                 "chunk_samples": stats["chunk_samples"],
-                "walk_passes": stats["walk_passes"],
+                "walk_passes": stats["walk_passes"], "synth_runs_max": max(s.get("synth_runs", 1) for s in step_stats),
                 "chain_mismatch": stats["chain_mismatch"],
                 "pipeline_depth": depth, **({"hooks_build": True} if HOOKS_BUILD else {}),
                 "window_mode": stats.get("window_mode"),  # 1: k_synth's resampled-window fast body (galsynth.h)

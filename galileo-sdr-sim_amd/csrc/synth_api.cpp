@@ -98,7 +98,10 @@ void init_tables()
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
 constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block per slot stitches the carrier legs
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
-constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare (17 us of no-op launches)
+constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare -- ~60 us of no-op
+                                    // launches in front of k_synth when the chain is complete after two, as it normally is;
+                                    // a handle whose last batch got by with two enqueues two (gal_synth_finish iterates and
+                                    // repeats the synthesis if that turns out to be one too few, and the handle goes back to three)
 
 }  // namespace
 
@@ -144,6 +147,7 @@ struct gal_synth {
     gal_chan_state_t *h_state = nullptr;  // pinned [S]
     bool state_fetched = false;           // h_state holds the state of the batch in flight
     gal_synth_stats_t stats{};
+    int enq_passes = kDefaultPasses;  // carrier passes the next execute enqueues (see kDefaultPasses)
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
     // their smallest distance (rw_threshold_gap); a step that moved by d can have closed that distance by 30 d at most
     std::vector<double> rw_s0, rw_g0;
@@ -680,7 +684,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     // handles can be kept in flight (the latency-bound walk of one batch then runs beside the issue-bound synthesis
     // of another).  gal_synth_finish() looks at the counter; in the rare case that the chain was not verified by then
     // it iterates further and repeats the synthesis.
-    int n_passes = kDefaultPasses;
+    int n_passes = h->enq_passes;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;
 #endif
@@ -803,6 +807,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         h->n_fallbacks += 1;
     }
     h->stats.walk_passes = ctr_end[CTR_PASSES];
+    h->enq_passes = ctr_end[CTR_PASSES] > 2 ? kDefaultPasses : 2;
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
