@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         int negp = 0;                                                            \
         GAL_ROOM(a) GAL_ROOM(b) GAL_ROOM(c) GAL_ROOM(d)                          \
         const int n = (int)(room * inv16); /* room < 0 -> n <= 0 */              \
-        sf##a = negp < 0 ? 0 : n;                                                \
+        sf##a = ((negp < 0) | rw_off) ? 0 : n; /* rw_off: pattern overflow, every group of the block slow */ \
     }
 #define GAL_BEGIN_F(j) if (j < NCH) { if constexpr (SIG == 1) group_begin_cboc<j>(ch##j, gr##j, s_str); else group_begin_fast<j>(ch##j, gr##j, s_str); }
 #define GAL_BEGIN_S(j) if (j < NCH) group_begin_slow<j>(ch##j, gr##j, s_str);
@@ -1914,7 +1914,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     if (a < NCH) {                                                               \
         ChanGroup gr##a = {0u, 0, 1}, gr##b = {0u, 0, 1};                        \
         ChanGroup gr##c = {0u, 0, 1}, gr##d = {0u, 0, 1};                        \
-        const bool near = (GSZ != SYN_GROUP) | (sf##a < 1) | rw_off;             \
+        const bool near = (GSZ != SYN_GROUP) | (sf##a < 1);                      \
         bool fast = __builtin_amdgcn_ballot_w64(near) == 0;                      \
         if constexpr (RW != 0) {                                                 \
             [[maybe_unused]] uint32_t gx##a = 0u, gx##b = 0u, gx##c = 0u, gx##d = 0u; \
