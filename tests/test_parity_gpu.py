@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C-ABI) against the oracle, bit for bit, on seeded inputs.
 int16 IQ is integer work: the bar is exact equality, pre-quantisation tolerance is 0."""
+import os
+
 import numpy as np
 import pytest
 
@@ -251,6 +253,31 @@ def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
     monkeypatch.delenv("GAL_WALK_PASSES")
     iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
     assert stats["walk_passes"] == 2 and stats["synth_runs"] == 1
+
+
+def test_enqueued_carrier_passes_adapt_to_the_previous_batch(pkg):
+    """A handle enqueues three carrier passes for its first batch and two after a batch that got by with two.  If a batch
+    then needs the third after all, gal_synth_finish() iterates and repeats the synthesis (synth_runs == 2), and the next
+    batch gets three again.  The three-pass batch is case 35 of tools/find_three_pass_batch.py 4000 5 (the fuzz generator)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity as fz
+
+    hard, n_samp, rate, chunk = fz.random_case(np.random.default_rng([5, 35]), False)
+    assert (rate, n_samp, chunk, hard.shape) == (2.6e6, 260000, 1360, (3, 8))
+    easy = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=8, samples_per_epoch=n_samp, seed=12)
+    ref_hard, _ = oracle_run(hard, n_samp, rate)
+    ref_easy, _ = oracle_run(easy, n_samp, rate)
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=8, device=0, chunk_samples=chunk) as eng:
+        iq, _, stats = eng.run_host(hard)  # first batch: three passes enqueued
+        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 3 and stats["synth_runs"] == 1
+        iq, _, stats = eng.run_host(easy)  # still three enqueued (the batch before needed them); needs two
+        assert np.array_equal(iq, ref_easy) and stats["walk_passes"] == 2 and stats["synth_runs"] == 1
+        iq, _, stats = eng.run_host(hard)  # two enqueued, three needed: repaired
+        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 3 and stats["synth_runs"] == 2
+        iq, _, stats = eng.run_host(hard)  # three enqueued again
+        assert np.array_equal(iq, ref_hard) and stats["synth_runs"] == 1
 
 
 def test_translated_legs_on_moving_receiver(pkg):
