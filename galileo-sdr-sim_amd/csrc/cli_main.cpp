@@ -10,17 +10,30 @@
 // ((int)(10 d + 0.5) - 1) * 260000 * 4 bytes (src/galileo-sdr.cpp:438,536-542); default name
 // galileosim.ishort, "-" = stdout.  Errors print a message and exit(1); success exits 0.
 //
-// Pipeline of three threads: a producer runs the host front-end (libgalscen: orbits, ranges, I/NAV pages) up to two
-// batches ahead -> the main thread plans and executes each batch on the GPU and, after gal_synth_finish(), enqueues
-// the copy into one of two pinned buffers -> a writer thread streams full buffers to the sink.  In steady state the
-// run time is that of the slowest stage: the device->host copy for /dev/null, the write for a file.
+// Pipeline: a producer thread runs the host front-end (libgalscen: orbits, ranges, I/NAV pages) up to two batches
+// ahead -> the main thread plans and executes each batch on the GPU and, after gal_synth_finish(), enqueues the copy
+// into one of two pinned buffers on two copy streams -> the sink moves full buffers into the output.  The sink of a
+// regular file is the file's own page cache: the file is sized up front and mapped, and a pool of writer threads copies
+// disjoint pieces of the pinned buffer into the mapping (page faults and copies run in parallel; a single write()/fwrite
+// stream is one core's copy speed, and buffered pwrite()s of several threads serialise on the inode lock).  Pipes,
+// stdout and devices get plain sequential write()s.  In steady state the run time is that of the slowest stage.
+//
+// --sites <file>: BASELINE config 5 as a product entry point -- one line `lat,lon,hgt[,outfile]` per receiver site, one
+// child process of this executable per site, spread over the GPUs of the node (GAL_DEVICE), every site's ishort file
+// written on its own; the parent prints the aggregate.  This is the reference's way of doing it too: N independent
+// usrp_galileo processes (src/main.cpp:168-408), nothing is exchanged between sites.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
 #include <getopt.h>
 #include <signal.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -51,9 +64,15 @@ void usage(const char *prog)
            "  -d <duration>    Duration [sec]\n"
            "  -I <x>           Disable ionospheric delay\n"
            "  -T <date,time>   Overwrite TOC and TOE to scenario start time (use `now` for the current time)\n"
-           "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (default 7533, 0 = off)\n"
+           "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (0 = off; default: 7533 on\n"
+           "                   the loopback interface; a port given here is bound on all interfaces, as the reference's)\n"
            "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
            "  -C               CBOC(6,1,1/11) sub-carrier of the E1 OS ICD instead of the reference's BOC(1,1) (opt-in)\n"
+           "  --strict         Stop with an error where a satellite in view runs out of ephemeris (default: its channel\n"
+           "                   keeps the last valid record; the reference indexes out of bounds there)\n"
+           "  --sites <file>   One line lat,lon,hgt[,outfile] per receiver site: one process per site over the GPUs of the\n"
+           "                   node (--gpus N, default all; --per-gpu K processes per GPU, default 1); -o is the name stem\n"
+           "  --writers <n>    Threads that move finished batches into a regular output file (default: up to 16)\n"
            "  -v               Verbose\n"
            "  -U/-b/-a/-G/-p/-n/-g/-i     accepted for compatibility (file sink only)\n",
            prog);
@@ -66,6 +85,258 @@ struct Slot {  // one pinned host buffer of the double-buffered sink
     bool full = false;
 };
 
+// ---- the output ------------------------------------------------------------------------------------------------
+// Regular file: ftruncate to the final size + one shared mapping; put() has `n_workers` threads copy disjoint pieces.
+// Anything else (stdout, pipe, device): sequential write().
+class Sink {
+public:
+    ~Sink() { close_workers(); }
+
+    bool open(const char *path, size_t total_bytes, int n_workers)
+    {
+        total_ = total_bytes;
+        if (strcmp(path, "-") == 0) {
+            fd_ = STDOUT_FILENO;
+            own_fd_ = false;
+        } else {
+            fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+            if (fd_ < 0) fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);  // write-only sinks (devices, FIFOs)
+            if (fd_ < 0) return false;
+            own_fd_ = true;
+        }
+        struct stat sb;
+        const char *force = getenv("GAL_SINK");  // "stream": never map (A/B measurements)
+        if (own_fd_ && fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode) && total_ > 0 && n_workers > 0 &&
+            !(force && strcmp(force, "stream") == 0) && ftruncate(fd_, (off_t)total_) == 0) {
+            void *m = mmap(nullptr, total_, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
+            if (m != MAP_FAILED) {
+                map_ = (char *)m;
+                for (int i = 0; i < n_workers; ++i) workers_.emplace_back([this, i] { worker(i); });
+            } else if (ftruncate(fd_, 0) != 0) {
+                return false;
+            }
+        }
+        return true;
+    }
+    bool mapped() const { return map_ != nullptr; }
+    int workers() const { return (int)workers_.size(); }
+
+    // appends `bytes` from `src`; returns false on an I/O error
+    bool put(const char *src, size_t bytes)
+    {
+        if (map_) {
+            if (pos_ + bytes > total_) return false;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                job_src_ = src;
+                job_dst_ = map_ + pos_;
+                job_bytes_ = bytes;
+                job_next_ = 0;
+                job_left_ = (int)workers_.size();
+                ++job_id_;
+            }
+            cv_.notify_all();
+            std::unique_lock<std::mutex> lk(mu_);
+            done_cv_.wait(lk, [&] { return job_left_ == 0; });
+            pos_ += bytes;
+            return true;
+        }
+        while (bytes) {
+            const ssize_t n = ::write(fd_, src, bytes < ((size_t)1 << 30) ? bytes : ((size_t)1 << 30));
+            if (n < 0) {
+                if (errno == EINTR) continue;
+                return false;
+            }
+            src += n;
+            bytes -= (size_t)n;
+            pos_ += (size_t)n;
+        }
+        return true;
+    }
+
+    // all data are in the file (mapped sink: in its page cache); a run that stopped early is cut to what was written
+    bool finish()
+    {
+        close_workers();
+        bool ok = true;
+        if (map_) {
+            munmap(map_, total_);
+            map_ = nullptr;
+            if (pos_ < total_ && ftruncate(fd_, (off_t)pos_) != 0) ok = false;
+        }
+        if (own_fd_ && fd_ >= 0 && ::close(fd_) != 0) ok = false;
+        fd_ = -1;
+        return ok;
+    }
+
+private:
+    static constexpr size_t kPiece = (size_t)2 << 20;  // 2 MiB: whole huge pages where the file system has them
+
+    void worker(int)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return quit_ || job_id_ != seen; });
+            if (quit_) return;
+            seen = job_id_;
+            for (;;) {
+                const size_t o = job_next_;
+                if (o >= job_bytes_) break;
+                const size_t n = job_bytes_ - o < kPiece ? job_bytes_ - o : kPiece;
+                job_next_ = o + n;
+                lk.unlock();
+                memcpy(job_dst_ + o, job_src_ + o, n);
+                lk.lock();
+            }
+            if (--job_left_ == 0) done_cv_.notify_all();
+        }
+    }
+    void close_workers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+        workers_.clear();
+    }
+
+    int fd_ = -1;
+    bool own_fd_ = false;
+    char *map_ = nullptr;
+    size_t total_ = 0, pos_ = 0;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    bool quit_ = false;
+    unsigned long job_id_ = 0;
+    const char *job_src_ = nullptr;
+    char *job_dst_ = nullptr;
+    size_t job_bytes_ = 0, job_next_ = 0;
+    int job_left_ = 0;
+};
+
+// ---- --sites: one child process per receiver site ---------------------------------------------------------------
+struct Site {
+    std::string llh, out;
+};
+
+int run_sites(const char *self, const std::vector<std::string> &base_args, const char *sites_file, const char *out_stem,
+              int n_gpus, int per_gpu)
+{
+    std::vector<Site> sites;
+    FILE *fp = fopen(sites_file, "r");
+    if (!fp) {
+        fprintf(stderr, "ERROR: cannot read the site list %s\n", sites_file);
+        return 1;
+    }
+    char line[4096];
+    while (fgets(line, sizeof(line), fp)) {
+        double a, b, c;
+        int used = 0;
+        if (line[0] == '#' || sscanf(line, " %lf , %lf , %lf%n", &a, &b, &c, &used) != 3) continue;
+        Site s;
+        char buf[128];
+        snprintf(buf, sizeof(buf), "%.10g,%.10g,%.10g", a, b, c);
+        s.llh = buf;
+        const char *rest = line + used;
+        while (*rest == ' ' || *rest == ',' || *rest == '\t') ++rest;
+        std::string name(rest);
+        while (!name.empty() && (name.back() == '\n' || name.back() == '\r' || name.back() == ' ')) name.pop_back();
+        if (name.empty()) {
+            snprintf(buf, sizeof(buf), ".site%zu.ishort", sites.size());
+            std::string stem(out_stem[0] ? out_stem : "galileosim");
+            const std::string ext = ".ishort";
+            if (stem.size() > ext.size() && stem.compare(stem.size() - ext.size(), ext.size(), ext) == 0)
+                stem.resize(stem.size() - ext.size());
+            name = stem + buf;
+        }
+        s.out = name;
+        sites.push_back(s);
+    }
+    fclose(fp);
+    if (sites.empty()) {
+        fprintf(stderr, "ERROR: no site (lat,lon,hgt) in %s\n", sites_file);
+        return 1;
+    }
+    if (n_gpus <= 0) n_gpus = gal_synth_device_count();
+    if (n_gpus <= 0) {
+        fprintf(stderr, "ERROR: no usable gfx950 device (there is no CPU fallback)\n");
+        return 1;
+    }
+    if (per_gpu < 1) per_gpu = 1;
+    const int lanes = n_gpus * per_gpu;
+    fprintf(stderr, "%zu sites over %d GPU%s (%d process%s per GPU)\n", sites.size(), n_gpus, n_gpus > 1 ? "s" : "", per_gpu,
+            per_gpu > 1 ? "es" : "");
+    std::vector<pid_t> lane_pid(lanes, 0);
+    std::vector<int> lane_site(lanes, -1);
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t next = 0, done = 0;
+    int failed = 0;
+    long long total_bytes = 0;
+    signal(SIGINT, on_sigint);
+    while (done < sites.size()) {
+        for (int l = 0; l < lanes && next < sites.size() && !g_stop; ++l) {
+            if (lane_pid[l] != 0) continue;
+            const Site &s = sites[next];
+            std::vector<std::string> args(base_args);
+            args.push_back("-l");
+            args.push_back(s.llh);
+            args.push_back("-o");
+            args.push_back(s.out);
+            const pid_t pid = fork();
+            if (pid < 0) {
+                perror("fork");
+                return 1;
+            }
+            if (pid == 0) {
+                char dev[16];
+                snprintf(dev, sizeof(dev), "%d", l % n_gpus);
+                setenv("GAL_DEVICE", dev, 1);
+                std::vector<char *> av;
+                av.push_back(const_cast<char *>(self));
+                for (auto &a : args) av.push_back(const_cast<char *>(a.c_str()));
+                av.push_back(nullptr);
+                execv(self, av.data());
+                perror("execv");
+                _exit(127);
+            }
+            lane_pid[l] = pid;
+            lane_site[l] = (int)next;
+            ++next;
+        }
+        int status = 0;
+        const pid_t pid = wait(&status);
+        if (pid < 0) {
+            if (errno == EINTR) continue;
+            break;
+        }
+        for (int l = 0; l < lanes; ++l) {
+            if (lane_pid[l] != pid) continue;
+            const Site &s = sites[lane_site[l]];
+            struct stat sb;
+            const long long bytes = stat(s.out.c_str(), &sb) == 0 ? (long long)sb.st_size : 0;
+            const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+            fprintf(stderr, "site %d (%s) on GPU %d -> %s: %s, %lld bytes\n", lane_site[l], s.llh.c_str(), l % n_gpus,
+                    s.out.c_str(), ok ? "ok" : "FAILED", bytes);
+            if (!ok) ++failed;
+            total_bytes += bytes;
+            lane_pid[l] = 0;
+            ++done;
+        }
+        if (g_stop && next < sites.size()) {  // interrupted: the sites not started yet are dropped
+            done += sites.size() - next;
+            next = sites.size();
+        }
+    }
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "\nDone!\nSites = %zu  failed = %d  Process time = %.2f [sec]  (%.1f Msamples/s aggregate over %d GPU%s, incl. process "
+                    "start-up)\n", sites.size(), failed, el, total_bytes / 4 / el / 1e6, n_gpus, n_gpus > 1 ? "s" : "");
+    return failed ? 1 : 0;
+}
+
 }  // namespace
 
 int main(int argc, char *argv[])
@@ -76,7 +347,7 @@ int main(int argc, char *argv[])
     }
     gal_scen_cfg_t sc;
     memset(&sc, 0, sizeof(sc));
-    char navfile[4096] = "", outfile[4096] = "", umfile[4096] = "";
+    char navfile[4096] = "", outfile[4096] = "", umfile[4096] = "", sitesfile[4096] = "";
     sc.llh[0] = 42.3601;  // defaults of src/main.cpp:179-196
     sc.llh[1] = -71.0589;
     sc.llh[2] = 2;
@@ -84,11 +355,29 @@ int main(int argc, char *argv[])
     sc.iono_enable = 1;
     sc.n_slots = GAL_MAX_CHAN;
     bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false;
-    int batch_epochs = 128;
+    int batch_epochs = 128, n_writers = -1, sites_gpus = 0, sites_per_gpu = 1;
     sc.udp_port = GAL_SCEN_UDP_PORT;  // the reference always listens for position updates (src/galileo-sdr.cpp:185)
+    sc.udp_loopback = 1;              // ... on every interface; the default listener here takes local datagrams only
 
+    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU };
+    static const struct option long_opts[] = {{"strict", no_argument, nullptr, OPT_STRICT},
+                                              {"sites", required_argument, nullptr, OPT_SITES},
+                                              {"writers", required_argument, nullptr, OPT_WRITERS},
+                                              {"gpus", required_argument, nullptr, OPT_GPUS},
+                                              {"per-gpu", required_argument, nullptr, OPT_PER_GPU},
+                                              {nullptr, 0, nullptr, 0}};
+    std::vector<std::string> child_args;  // --sites: everything but -l / -o / --sites / --gpus / --per-gpu goes to the children
     int opt;
-    while ((opt = getopt(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC")) != -1) {
+    while ((opt = getopt_long(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC", long_opts, nullptr)) != -1) {
+        if (opt != 'l' && opt != 'o' && opt != OPT_SITES && opt != OPT_GPUS && opt != OPT_PER_GPU && opt != '?' && opt != ':') {
+            if (opt >= 1000) {
+                child_args.push_back(opt == OPT_STRICT ? "--strict" : "--writers");
+            } else {
+                char name[3] = {'-', (char)opt, 0};
+                child_args.push_back(name);
+            }
+            if (optarg) child_args.push_back(optarg);
+        }
         switch (opt) {
         case 'e': snprintf(navfile, sizeof(navfile), "%s", optarg); break;
         case 'o': snprintf(outfile, sizeof(outfile), "%s", optarg); break;
@@ -119,9 +408,18 @@ int main(int argc, char *argv[])
         case 'I': sc.iono_enable = 0; break;
         case 'v': verbose = true; break;
         case 'B': batch_epochs = atoi(optarg); have_batch = true; break;
-        case 'P': sc.udp_port = atoi(optarg); udp_given = true; break;
+        case 'P':
+            sc.udp_port = atoi(optarg);
+            sc.udp_loopback = 0;
+            udp_given = true;
+            break;
         case 'r': realtime = true; break;
         case 'C': cboc = true; break;
+        case OPT_STRICT: sc.strict_eph = 1; break;
+        case OPT_SITES: snprintf(sitesfile, sizeof(sitesfile), "%s", optarg); break;
+        case OPT_WRITERS: n_writers = atoi(optarg); break;
+        case OPT_GPUS: sites_gpus = atoi(optarg); break;
+        case OPT_PER_GPU: sites_per_gpu = atoi(optarg); break;
         case 'n': case 'g': case 'G': case 'a': case 'p': case 'i': case 'U': case 'b': break;
         case ':':
         case '?':
@@ -133,6 +431,17 @@ int main(int argc, char *argv[])
     if (navfile[0] == 0) {
         printf("ERROR: Galileo ephemeris/nav_msg file is not specified.\n");
         exit(1);
+    }
+    if (sitesfile[0]) {
+        if (!udp_given) {  // several listeners cannot share the default port: the sites run without one unless -P says otherwise
+            child_args.push_back("-P");
+            child_args.push_back("0");
+        }
+        char self[4096];
+        const ssize_t n = readlink("/proc/self/exe", self, sizeof(self) - 1);
+        if (n <= 0) snprintf(self, sizeof(self), "%s", argv[0]);
+        else self[n] = 0;
+        return run_sites(self, child_args, sitesfile, outfile, sites_gpus, sites_per_gpu);
     }
     if (outfile[0] == 0) {
         printf("[+] File sink not specified. Using galileosim.ishort\n");
@@ -146,7 +455,7 @@ int main(int argc, char *argv[])
 
     gal_scen_t *scen = nullptr;
     int orc = gal_scen_open(&sc, &scen);
-    if (orc == GAL_E_IO && sc.udp_port > 0 && !udp_given && strstr(gal_scen_last_error(), "UDP")) {
+    if (orc == GAL_E_BUSY && sc.udp_port > 0 && !udp_given) {
         // the default port is taken (another instance): the reference would exit; carry on without the listener
         fprintf(stderr, "WARNING: %s; continuing without run-time position updates\n", gal_scen_last_error());
         sc.udp_port = 0;
@@ -163,15 +472,6 @@ int main(int argc, char *argv[])
     fprintf(stderr, "\n%s\nStart = %d:%.0f  Duration = %.1f [sec]  (%d epochs of 0.1 s)\n",
             sc.motion_file ? "Using user motion file." : "Using static location mode.", wk, ws, (total + 1) / 10.0, total);
 
-    FILE *fp = stdout;
-    if (strcmp("-", outfile)) {
-        fp = fopen(outfile, "wb");
-        if (!fp) {
-            fprintf(stderr, "ERROR: Failed to open output file.\n");
-            exit(1);
-        }
-    }
-
     gal_synth_cfg_t cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.sample_rate = 2.6e6;
@@ -179,6 +479,18 @@ int main(int argc, char *argv[])
     cfg.n_slots = sc.n_slots;
     cfg.device = getenv("GAL_DEVICE") ? atoi(getenv("GAL_DEVICE")) : -1;
     if (cboc) cfg.flags |= GAL_CFG_CBOC;
+    const size_t epoch_bytes = (size_t)cfg.samples_per_epoch * 4;
+
+    if (n_writers < 0) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        n_writers = hc >= 32 ? 16 : hc >= 4 ? (int)hc / 2 : 1;
+    }
+    Sink sink;
+    if (!sink.open(outfile, realtime ? 0 : (size_t)total * epoch_bytes, n_writers)) {  // (paced runs stream: they are slow by design)
+        fprintf(stderr, "ERROR: Failed to open output file.\n");
+        exit(1);
+    }
+
     gal_synth_t *eng = nullptr;
     if (gal_synth_create(&cfg, &eng) != GAL_OK) {
         fprintf(stderr, "ERROR: %s\n", gal_synth_last_error());
@@ -188,7 +500,7 @@ int main(int argc, char *argv[])
     hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     gal_synth_set_stream(eng, stream);
 
-    const size_t epoch_bytes = (size_t)cfg.samples_per_epoch * 4;
+    if (batch_epochs > total) batch_epochs = total > 0 ? total : 1;
     const size_t batch_bytes = epoch_bytes * batch_epochs;
     int16_t *d_iq[2] = {nullptr, nullptr};
     Slot slot[2];
@@ -220,9 +532,9 @@ int main(int argc, char *argv[])
             if (!slot[next_write].full) return;
             Slot &s = slot[next_write];
             lk.unlock();
-            hipEventSynchronize(s.copied[0]);
-            hipEventSynchronize(s.copied[1]);
-            if (fwrite(s.host, 1, s.bytes, fp) != s.bytes) io_error = true;
+            if (hipEventSynchronize(s.copied[0]) != hipSuccess || hipEventSynchronize(s.copied[1]) != hipSuccess ||
+                !sink.put((const char *)s.host, s.bytes))
+                io_error = true;
             lk.lock();
             s.full = false;
             next_write ^= 1;
@@ -276,7 +588,8 @@ int main(int argc, char *argv[])
     memset(state.data(), 0, sizeof(gal_chan_state_t) * sc.n_slots);
     bool have_state = false;
     int emitted = 0, cur = 0, rc = 0, r = 0;
-    while (emitted < total && !io_error) {
+    // (SIGINT: the batch in flight is finished and written, batches the producer has queued behind it are dropped)
+    while (emitted < total && !io_error && !g_stop) {
         {
             std::unique_lock<std::mutex> lk(rmu);
             rcv.wait(lk, [&] { return rb[r].ready; });
@@ -318,12 +631,18 @@ int main(int argc, char *argv[])
             const size_t half = epoch_bytes * (size_t)((n + 1) / 2);
             const size_t part[2] = {half, slot[cur].bytes - half};
             size_t off = 0;
+            hipError_t cerr = hipSuccess;
             for (int k = 0; k < 2; ++k) {
-                if (part[k])
-                    hipMemcpyAsync((char *)slot[cur].host + off, (const char *)d_iq[cur] + off, part[k],
-                                   hipMemcpyDeviceToHost, copy_stream[k]);
-                hipEventRecord(slot[cur].copied[k], copy_stream[k]);
+                if (part[k] && cerr == hipSuccess)
+                    cerr = hipMemcpyAsync((char *)slot[cur].host + off, (const char *)d_iq[cur] + off, part[k],
+                                          hipMemcpyDeviceToHost, copy_stream[k]);
+                if (cerr == hipSuccess) cerr = hipEventRecord(slot[cur].copied[k], copy_stream[k]);
                 off += part[k];
+            }
+            if (cerr != hipSuccess) {
+                fprintf(stderr, "\nERROR: device -> host copy failed: %s\n", hipGetErrorString(cerr));
+                rc = 1;
+                break;
             }
         }
         have_state = true;
@@ -355,8 +674,10 @@ int main(int argc, char *argv[])
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     fprintf(stderr, "\nDone!\nProcess time = %.2f [sec]  (%.1f Msamples/s, %.0fx real time)\n", el,
             emitted * 0.26 / el, emitted * 0.1 / el);
-    if (fp != stdout) fclose(fp);
-    else fflush(stdout);
+    if (gal_scen_eph_gaps(scen) > 0)
+        fprintf(stderr, "NOTE: %d (satellite, refresh) pairs ran on a stale ephemeris record (see the warning above)\n",
+                gal_scen_eph_gaps(scen));
+    if (!sink.finish()) io_error = true;
     gal_synth_destroy(eng);
     gal_scen_close(scen);
     if (io_error) {

@@ -72,7 +72,9 @@ struct gal_scen {
     int udp_fd = -1;         // run-time position updates (cfg.udp_port)
     bool have_live = false;
     double xyz_live[3];
-    int live_updates = 0;
+    int live_updates = 0, live_rejected = 0;
+    bool gap_warned = false;  // ephemeris-gap policy, see gal_scen_next
+    int eph_gaps = 0;         // (satellite, refresh) pairs that kept a stale record
 
     ~gal_scen()
     {
@@ -94,11 +96,19 @@ void poll_live_position(gal_scen *s)
         const ssize_t n = recv(s->udp_fd, buf, sizeof(buf), MSG_DONTWAIT | MSG_TRUNC);  // MSG_TRUNC: the real length
         if (n < 0) break;                          // nothing (more) waiting
         if (n != (ssize_t)sizeof(buf)) continue;   // not a position update: ignored
+        // (the reference takes whatever arrives; a NaN or an out-of-range coordinate would go straight into the ranges
+        // and from there into the NCO steps, so such datagrams are dropped here)
+        if (!(std::isfinite(buf[0]) && std::isfinite(buf[1]) && std::isfinite(buf[2])) || std::fabs(buf[0]) > 90.0 ||
+            std::fabs(buf[1]) > 360.0 || buf[2] < -1.0e4 || buf[2] > 1.0e8) {
+            s->live_rejected++;
+            continue;
+        }
         memcpy(llh, buf, sizeof(llh));
         got = true;
     }
     if (!got) return;
-    if (s->cfg.verbose) fprintf(stdout, "Location Update: %f,%f,%f\n", llh[0], llh[1], llh[2]);
+    // stderr, not the reference's stdout (include/socket.h:178): stdout may be the IQ sink (-o -)
+    if (s->cfg.verbose) fprintf(stderr, "Location Update: %f,%f,%f\n", llh[0], llh[1], llh[2]);
     llh[0] = llh[0] / kR2D;
     llh[1] = llh[1] / kR2D;
     llh_to_ecef(llh, s->xyz_live);
@@ -301,12 +311,12 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
         memset(&addr, 0, sizeof(addr));
         addr.sin_family = AF_INET;
         addr.sin_port = htons((uint16_t)cfg->udp_port);
-        addr.sin_addr.s_addr = INADDR_ANY;
+        addr.sin_addr.s_addr = cfg->udp_loopback ? htonl(INADDR_LOOPBACK) : INADDR_ANY;
         if (s->udp_fd < 0 || bind(s->udp_fd, (struct sockaddr *)&addr, sizeof(addr)) < 0) {
             const int port = cfg->udp_port;
             delete s;
-            return scen_fail(GAL_E_IO, "cannot listen for position updates on UDP port %d (the reference exits here too: "
-                                       "one instance per port)", port);
+            return scen_fail(GAL_E_BUSY, "cannot listen for position updates on UDP port %d (the reference exits here too: "
+                                         "one instance per port)", port);
         }
     }
     *out = s;
@@ -340,7 +350,7 @@ int32_t gal_scen_next(gal_scen_t *s, int32_t max_epochs, gal_chan_epoch_t *rows)
             const int k = s->current_eph[sv];
             if (k < 0 || k >= (int)s->nav.sv[sv].size())
                 return scen_fail(GAL_E_STATE, "PRN %d is allocated but has no current ephemeris (the reference "
-                                              "indexes out of bounds here)", c.prn);
+                                              "indexes out of bounds here; strict_eph is set)", c.prn);
             const Ephemeris &eph = s->nav.sv[sv][k];
             Range rho;
             compute_range(&rho, eph, s->nav.iono, s->grx, xyz);
@@ -383,7 +393,26 @@ int32_t gal_scen_next(gal_scen_t *s, int32_t max_epochs, gal_chan_epoch_t *rows)
         // 30 s refresh, src/galileo-sdr.cpp:545-562
         const int igrx = (int)(s->grx.sec * 10.0 + 0.5);
         if ((int)fmodf((float)igrx, 300) == 0) {
-            for (int sv = 0; sv < kMaxSat; ++sv) s->current_eph[sv] = match_ephemeris(s->grx, s->nav.sv[sv]);
+            for (int sv = 0; sv < kMaxSat; ++sv) {
+                const int k = match_ephemeris(s->grx, s->nav.sv[sv]);
+                // Ephemeris gap: no record of this satellite is within an hour of its TOC any more, but the satellite
+                // still occupies a channel (allocateChannel skips satellites without a match, so it neither frees nor
+                // re-checks it, src/channel.cpp:38-44).  The reference stores the -1 and then reads
+                // eph_vector[sv][-1] (src/galileo-sdr.cpp:458,555-558): undefined behaviour, no parity is definable.
+                // Policy here: the channel keeps its last valid record until a later refresh finds
+                // a match again or the satellite sets; gal_scen_cfg_t.strict_eph turns the gap into an error instead.
+                if (k < 0 && s->allocated[sv] >= 0 && s->current_eph[sv] >= 0 && !s->cfg.strict_eph) {
+                    s->eph_gaps++;
+                    if (!s->gap_warned) {
+                        fprintf(stderr, "WARNING: PRN %d has no ephemeris within an hour of %d:%.1f; its channel keeps the "
+                                        "last valid record (the reference indexes out of bounds here; --strict aborts "
+                                        "instead)\n", sv + 1, s->grx.week, s->grx.sec);
+                        s->gap_warned = true;
+                    }
+                    continue;
+                }
+                s->current_eph[sv] = k;
+            }
             allocate_channels(s, s->grx, xyz);
         }
         s->grx.sec = s->grx.sec + kEpochDt;
@@ -451,6 +480,9 @@ int gal_scen_eph_info(const gal_scen_t *s, int32_t svid, int32_t eph_index, int3
     if (toc_sec) *toc_sec = e.toc.sec;
     return GAL_OK;
 }
+
+int32_t gal_scen_eph_gaps(const gal_scen_t *s) { return s ? s->eph_gaps : 0; }
+int32_t gal_scen_live_rejected(const gal_scen_t *s) { return s ? s->live_rejected : 0; }
 
 int gal_scen_close(gal_scen_t *s)
 {

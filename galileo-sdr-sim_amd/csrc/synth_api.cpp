@@ -149,7 +149,7 @@ struct gal_synth {
     gal_synth_stats_t stats{};
     int enq_passes = kDefaultPasses;  // carrier passes the next execute enqueues (see kDefaultPasses)
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
-    // their smallest distance (rw_threshold_gap); a step that moved by d can have closed that distance by 30 d at most
+    // their smallest distance (rw_threshold_gap) -- reused only for the identical step
     std::vector<double> rw_s0, rw_g0;
 };
 
@@ -391,11 +391,13 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
                 rw_ok = mode != 0 && (rw_mode == 0 || rw_mode == mode);
                 rw_mode = mode;
-                if (rw_ok && !(h->rw_g0[s] - 30.0 * std::fabs(cs2 - h->rw_s0[s]) > kRwMinGap)) {
+                // (evaluated for every record: the distance is not a continuous function of the step -- when some u s
+                // crosses an integer its threshold jumps from 0 to 1 -- so a cached value cannot be extrapolated)
+                if (rw_ok && cs2 != h->rw_s0[s]) {
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
-                    rw_ok = h->rw_g0[s] > kRwMinGap;
                 }
+                if (rw_ok) rw_ok = h->rw_g0[s] > kRwMinGap;
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;

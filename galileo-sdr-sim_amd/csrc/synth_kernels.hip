@@ -33,7 +33,7 @@
 
 using namespace galnco;
 
-// The file is compiled as five translation units, side by side (Makefile: -DGAL_TU=0..4), because the instantiations of
+// The file is compiled as six translation units, side by side (Makefile: -DGAL_TU=0..5), because the instantiations of
 // k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
 // GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
 // by both libraries; TU 5 the family (0, 3).  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).

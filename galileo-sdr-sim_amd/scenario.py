@@ -23,6 +23,8 @@ EXPORTED_SYMBOLS = (
     "gal_scen_crc24q",
     "gal_scen_eph_count",
     "gal_scen_eph_info",
+    "gal_scen_eph_gaps",
+    "gal_scen_live_rejected",
 )
 
 
@@ -40,7 +42,8 @@ class _Cfg(ctypes.Structure):
         ("verbose", ctypes.c_int32),
         ("time_overwrite", ctypes.c_int32),
         ("udp_port", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 2),
+        ("strict_eph", ctypes.c_int32),
+        ("udp_loopback", ctypes.c_int32),
     ]
 
 
@@ -66,6 +69,8 @@ def load_library():
         lib.gal_scen_start_time.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]
         lib.gal_scen_next.argtypes = [vp, ctypes.c_int32, vp]
         lib.gal_scen_close.argtypes = [vp]
+        lib.gal_scen_eph_gaps.argtypes = [vp]
+        lib.gal_scen_live_rejected.argtypes = [vp]
         lib.gal_scen_inav_page.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, vp]
         lib.gal_scen_inav_raw.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, vp]
         lib.gal_scen_crc24q.argtypes = [vp, ctypes.c_int32]
@@ -96,7 +101,8 @@ class Scenario:
     """Sequential producer of [n_epochs, n_slots] gal_chan_epoch_t rows."""
 
     def __init__(self, nav_file, llh=(42.3601, -71.0589, 2.0), start=None, duration_s=300.0, iono_enable=True,
-                 n_slots=16, motion_file=None, verbose=False, time_overwrite=False, udp_port=0):
+                 n_slots=16, motion_file=None, verbose=False, time_overwrite=False, udp_port=0, strict_eph=False,
+                 udp_loopback=False):
         self._lib = load_library()
         cfg = _Cfg()
         cfg.nav_file = os.fsencode(nav_file)
@@ -113,6 +119,8 @@ class Scenario:
         cfg.verbose = 1 if verbose else 0
         cfg.time_overwrite = 1 if time_overwrite else 0
         cfg.udp_port = int(udp_port)
+        cfg.strict_eph = 1 if strict_eph else 0
+        cfg.udp_loopback = 1 if udp_loopback else 0
         self._keep = cfg
         self._h = ctypes.c_void_p()
         rc = self._lib.gal_scen_open(ctypes.byref(cfg), ctypes.byref(self._h))
@@ -135,6 +143,15 @@ class Scenario:
 
     def all(self):
         return self.next(self.total_epochs)
+
+    @property
+    def eph_gaps(self):
+        """(satellite, refresh) pairs at which a channel kept a stale ephemeris record (strict_eph off)."""
+        return int(self._lib.gal_scen_eph_gaps(self._h))
+
+    @property
+    def live_rejected(self):
+        return int(self._lib.gal_scen_live_rejected(self._h))
 
     def inav_page(self, svid, eph_index, week, sec):
         w = np.zeros(GAL_PAGE_WORDS, dtype="<u4")

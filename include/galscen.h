@@ -37,7 +37,12 @@ typedef struct gal_scen_cfg {
     int32_t udp_port;         /* > 0: listen on this UDP port for run-time position updates, 3 doubles lat [deg],
                                  lon [deg], height [m] per datagram -- the reference's locations_thread on port 7533
                                  (include/socket.h:165-180), read once per epoch (src/galileo-sdr.cpp:443-448)      */
-    int32_t reserved[2];
+    int32_t strict_eph;       /* ephemeris-gap policy.  At a 30 s refresh the reference stores epoch_matcher's -1 for a
+                                 satellite that still holds a channel and then reads eph_vector[sv][-1]
+                                 (src/galileo-sdr.cpp:458,555-558; src/rinex.cpp:27-44): undefined behaviour.  0 (default):
+                                 the channel keeps its last valid record until a later refresh matches again or frees it,
+                                 one warning on stderr, gal_scen_eph_gaps() counts; 1: gal_scen_next fails with GAL_E_STATE */
+    int32_t udp_loopback;     /* 1: bind the position listener to 127.0.0.1 only (the reference binds INADDR_ANY)      */
 } gal_scen_cfg_t;
 
 #define GAL_SCEN_UDP_PORT 7533 /* the reference's port (include/socket.h:169) */
@@ -55,6 +60,10 @@ int gal_scen_start_time(const gal_scen_t *s, int32_t *week, double *sec);
  * (0 at the end) or a negative gal_status_t. */
 int32_t gal_scen_next(gal_scen_t *s, int32_t max_epochs, gal_chan_epoch_t *rows);
 int gal_scen_close(gal_scen_t *s);
+/* (satellite, refresh) pairs so far at which a channel kept a stale ephemeris record (strict_eph == 0), and position
+ * datagrams dropped because a coordinate was not finite or out of range. */
+int32_t gal_scen_eph_gaps(const gal_scen_t *s);
+int32_t gal_scen_live_rejected(const gal_scen_t *s);
 
 /* I/NAV page generator on its own (reference src/inav-msg.cpp:28-54): 500 symbols of the page that
  * starts at Galileo time (week, sec) for the ephemeris record `eph_index` of `svid` in the opened file. */

@@ -37,7 +37,8 @@ typedef enum gal_status {
     GAL_E_DEVICE = -3,    /* HIP runtime error / no usable GPU (there is NO CPU fallback)   */
     GAL_E_STATE = -4,     /* call sequence error (execute before plan, ...)                 */
     GAL_E_CHAIN = -5,     /* NCO chain self-check failed (see gal_synth_stats_t)            */
-    GAL_E_IO = -6
+    GAL_E_IO = -6,
+    GAL_E_BUSY = -7       /* a resource another instance holds (galscen: the UDP position port)   */
 } gal_status_t;
 
 /* gal_chan_epoch_t.flags */

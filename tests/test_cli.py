@@ -131,3 +131,57 @@ def test_cli_sigint_finishes_the_current_epoch(tmp_path):
     assert p.returncode == 0, p.stderr.read()
     size = os.path.getsize(str(out))
     assert size % (260000 * 4) == 0 and 5 * 260000 * 4 <= size < 79 * 260000 * 4
+
+
+def test_cli_sites_errors(tmp_path):
+    """--sites: a missing or empty site list is an error before anything is started."""
+    r = subprocess.run([CLI, "-e", NAV, "--sites", str(tmp_path / "missing.txt"), "-d", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot read the site list" in r.stderr
+    empty = tmp_path / "empty.txt"
+    empty.write_text("# nothing here\n\n")
+    r = subprocess.run([CLI, "-e", NAV, "--sites", str(empty), "-d", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no site" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_sites_one_process_per_site(pkg, tmp_path):
+    """BASELINE config 5 through the product entry point: `--sites` starts one process per receiver site (here three sites,
+    two processes at a time on GPU 0), every site gets its own ishort file, the parent reports the aggregate; each file
+    equals the oracle on the front-end's rows for that site."""
+    import numpy as np
+
+    from oracle_binding import oracle_run
+
+    sites = [(-6.0, 51.0, 100.0), (45.0, 10.0, 100.0), (0.0, 0.0, 100.0)]
+    named = tmp_path / "third.bin"
+    lst = tmp_path / "sites.txt"
+    lst.write_text("# lat,lon,hgt[,outfile]\n-6,51,100\n45, 10, 100\n0,0,100,%s\n" % named)
+    stem = tmp_path / "run.ishort"
+    r = subprocess.run([CLI, "-e", NAV, "--sites", str(lst), "-t", "2022/02/20,12:00:00", "-d", "6", "-I", "1", "-o", str(stem),
+                        "--gpus", "1", "--per-gpu", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Sites = 3  failed = 0" in r.stderr
+    outs = [tmp_path / "run.site0.ishort", tmp_path / "run.site1.ishort", named]
+    for llh, out in zip(sites, outs):
+        rows = pkg.Scenario(NAV, llh=llh, start="2022/02/20,12:00:00", duration_s=6, iono_enable=False).all()
+        ref_iq, _ = oracle_run(rows, 260000, 2.6e6)
+        got = np.fromfile(str(out), dtype=np.int16)
+        assert got.size == ref_iq.size == 59 * 520000 and np.array_equal(got, ref_iq), llh
+    # a failing site fails the run (start time outside the file) but the report still comes
+    r = subprocess.run([CLI, "-e", NAV, "--sites", str(lst), "-t", "2019/01/01,00:00:00", "-d", "2", "-o", str(stem), "--gpus", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "failed = 3" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_file_sink_variants_agree(tmp_path):
+    """The mapped multi-writer sink (regular files), the sequential sink (GAL_SINK=stream) and stdout give the same bytes;
+    an interrupted mapped run is cut to what was written (test_cli_sigint... covers the paced, streaming case)."""
+    common = [CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "10", "-I", "1", "-P", "0", "-B", "40"]
+    a, b, c = tmp_path / "a.ishort", tmp_path / "b.ishort", tmp_path / "c.ishort"
+    assert subprocess.run(common + ["-o", str(a), "--writers", "5"], capture_output=True).returncode == 0
+    assert subprocess.run(common + ["-o", str(b)], capture_output=True, env=dict(os.environ, GAL_SINK="stream")).returncode == 0
+    assert subprocess.run(common + ["-o", str(c), "--writers", "0"], capture_output=True).returncode == 0
+    for f in (a, b, c):
+        data = f.read_bytes()
+        assert len(data) == REF["G1"]["bytes"] and hashlib.md5(data).hexdigest() == REF["G1"]["md5"], f

@@ -259,12 +259,9 @@ def test_enqueued_carrier_passes_adapt_to_the_previous_batch(pkg):
     """A handle enqueues three carrier passes for its first batch and two after a batch that got by with two.  If a batch
     then needs the third after all, gal_synth_finish() iterates and repeats the synthesis (synth_runs == 2), and the next
     batch gets three again.  The three-pass batch is case 35 of tools/find_three_pass_batch.py 4000 5 (the fuzz generator)."""
-    import sys
+    from fuzz_cases import random_case
 
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import fuzz_parity as fz
-
-    hard, n_samp, rate, chunk = fz.random_case(np.random.default_rng([5, 35]), False)
+    hard, n_samp, rate, chunk = random_case(pkg, np.random.default_rng([5, 35]), False)
     assert (rate, n_samp, chunk, hard.shape) == (2.6e6, 260000, 1360, (3, 8))
     easy = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=8, samples_per_epoch=n_samp, seed=12)
     ref_hard, _ = oracle_run(hard, n_samp, rate)
@@ -340,10 +337,93 @@ def test_full_size_properties(pkg):
         b = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
         eng.execute(b.data_ptr())
         st_b, _ = eng.finish()
+        # state at epoch 1195 from a third plan, so that the oracle can replay the LAST 4 epochs on its own
+        eng.plan(q[:495], st_a)
+        c = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(c.data_ptr())
+        st_c, _ = eng.finish()
     assert torch.equal(outs[0][: a.numel()], a) and torch.equal(outs[0][a.numel():], b)
     act = state_full["prn"] > 0
     assert np.array_equal(st_b["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
     assert np.array_equal(st_b["page"][act], state_full["page"][act])
+    tail = p[1195:].copy()
+    tail["flags"][0, :12] = 0
+    ref_tail, ref_st = oracle_run(tail, n, rate, st_c)
+    assert np.array_equal(outs[0][1195 * n * 2:].cpu().numpy(), ref_tail)
+    assert np.array_equal(ref_st["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+
+
+def _dev_equal(a, b, piece=1 << 30):
+    """torch.equal in pieces (the comparison mask of a 60 GB pair would be another 30 GB)."""
+    import torch
+
+    if a.numel() != b.numel():
+        return False
+    return all(torch.equal(a[o:o + piece], b[o:o + piece]) for o in range(0, a.numel(), piece))
+
+
+def test_m_syn24_full_size_properties(pkg):
+    """BASELINE config 4 at FULL size (M-SYN24: 5999 epochs x 2 500 000 samples x 24 SVs @25 MS/s = 15.0 G samples,
+    60 GB of IQ per run, sample indices beyond 2^32 bytes and 2^32 int16 elements), where the oracle would need an hour:
+      * the first 2 and the LAST 2 epochs equal the oracle (the latter restarted on the carried state of a split run);
+      * chunk 0 (default) and 2048 give the same 60 GB;
+      * a run split 3000 + 2999 with the carried state equals the single run, end state included;
+      * the chain self-check is clean, the all-walked fallback is never needed, the synthesis ran once per batch."""
+    import torch
+
+    n, rate, S = 2500000, 25e6, 24
+    free, _total = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs 200 GB of free HBM (two 60 GB outputs plus the split runs)")
+    p = pkg.workloads.m_syn24()
+    E = p.shape[0]
+    assert E == 5999
+    outs = []
+    for chunk in (0, 2048):
+        with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=S, device=0, chunk_samples=chunk) as eng:
+            eng.plan(p)
+            assert eng.output_bytes() == E * n * 4 > 2 ** 35
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr())
+            st, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0 and stats["n_active_max"] == 24 and stats["synth_runs"] == 1
+            assert eng.walk_counts()[2] == 0
+            if chunk == 0:
+                state_full = st
+        outs.append(out)
+    assert _dev_equal(outs[0], outs[1])
+    del outs[1:], out
+    torch.cuda.empty_cache()
+    full = outs[0]
+    ref_iq, _ = oracle_run(p[:2], n, rate)
+    assert np.array_equal(full[: 2 * n * 2].cpu().numpy(), ref_iq)
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=S, device=0) as eng:
+        eng.plan(p[:3000])
+        a = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+        eng.execute(a.data_ptr())
+        st_a, stats_a = eng.finish()
+        assert stats_a["chain_mismatch"] == 0
+        assert _dev_equal(full[: a.numel()], a)
+        q = p[3000:].copy()
+        q["flags"][0, :] = 0  # continues from the carried state
+        eng.plan(q, st_a)
+        eng.execute(a.data_ptr())  # 2999 epochs into the 3000-epoch buffer
+        st_b, stats_b = eng.finish()
+        assert stats_b["chain_mismatch"] == 0
+        assert _dev_equal(full[3000 * n * 2:], a[: 2999 * n * 2])
+        # state at epoch 5997 from a third plan, so that the oracle can replay the last 2 epochs on its own
+        eng.plan(q[:2997], st_a)
+        eng.execute(a.data_ptr())
+        st_c, _ = eng.finish()
+    act = state_full["prn"] > 0
+    assert act.sum() == 24
+    assert np.array_equal(st_b["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+    assert np.array_equal(st_b["page"][act], state_full["page"][act])
+    tail = p[5997:].copy()
+    tail["flags"][0, :] = 0
+    ref_tail, ref_st = oracle_run(tail, n, rate, st_c)
+    assert np.array_equal(full[5997 * n * 2:].cpu().numpy(), ref_tail)
+    assert np.array_equal(ref_st["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
 
 
 def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
@@ -402,19 +482,14 @@ def test_range_execute_never_rests_on_an_unreplayed_translation(pkg, monkeypatch
 
 
 def test_randomised_soak(pkg):
-    """A slice of tools/fuzz_parity.py (random shapes, rates, chunkings, Doppler patterns, channels coming and
-    going): every case bit-exact, the all-walked fallback never needed.  The tool itself was run over 6000
+    """A slice of the randomised soak (tests/fuzz_cases.py, driven at length by tools/fuzz_parity.py: random shapes,
+    rates, chunkings, Doppler patterns, channels coming and going): every case bit-exact, the all-walked fallback never needed.  The tool itself was run over 6000
     small and 360 reference-geometry cases at the end of round 1."""
-    import importlib.util
-    import os
+    from fuzz_cases import random_case
 
-    spec = importlib.util.spec_from_file_location(
-        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
-    fz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fz)
     rng = np.random.default_rng(2024)
     for c in range(80):
-        p, n_samp, rate, chunk = fz.random_case(rng, big=(c % 20 == 19))
+        p, n_samp, rate, chunk = random_case(pkg, rng, big=(c % 20 == 19))
         with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0,
                              chunk_samples=chunk) as eng:
             iq, st, stats = eng.run_host(p)
@@ -613,17 +688,12 @@ def test_long_batch_stitcher_on_small_batches(pkg, monkeypatch):
     the single-block k_carr_scan -- the same sequential statement.  The full-size tests cover it at 1199 / 2999 epochs;
     here the fault-injection build forces it onto small random batches (channels coming and going, idle epochs, sign
     changes, tie-prone steps), where every corner of the stitch is hit quickly."""
-    import importlib.util
-    import os
-
     monkeypatch.setenv("GAL_SCAN_SINGLE_LEGS", "0")  # honoured by the GAL_TEST_HOOKS build only
-    spec = importlib.util.spec_from_file_location(
-        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
-    fz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fz)
+    from fuzz_cases import random_case
+
     rng = np.random.default_rng(77)
     for c in range(60):
-        p, n_samp, rate, chunk = fz.random_case(rng, big=(c % 15 == 14))
+        p, n_samp, rate, chunk = random_case(pkg, rng, big=(c % 15 == 14))
         with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0, chunk_samples=chunk,
                              test_hooks=True) as eng:
             iq, st, stats = eng.run_host(p)

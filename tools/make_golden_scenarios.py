@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
-"""Writes the scenario fixtures under tests/golden/ (run in the build container):
+"""Scenario fixtures under tests/golden/ (run in the build container).
 
-  g1_params.npz   gal_chan_epoch_t rows of scenario G1 as produced by THIS repo's host front-end
-                  (libgalscen.so), plus the per-epoch SHA-256 of the oracle's IQ for those rows.
   reference_md5.json
-                  md5 of the reference's OWN output file for G1/G2 (and size/PRNs for G3), copied from
-                  BASELINE.md §2 / SURVEY.md §8(c) where the survey recorded them from the unmodified
-                  reference binary run in this container.  These are the parity pins: the fixture rows
-                  are accepted only because oracle(rows) hashes to the reference's md5.
+        md5 / size / PRNs of the REFERENCE'S OWN output files for scenarios G1..G7.  This file is DATA recorded from
+        runs of the reference binary (its "source" fields say by whom and how); this script never writes it -- it
+        reads it, and checks every md5 in it against  front-end (libgalscen.so) -> oracle  on the same command line.
+  g1_params.npz
+        gal_chan_epoch_t rows of scenario G1 as produced by THIS repo's host front-end, plus the per-epoch SHA-256
+        of the oracle's IQ for those rows (accepted only because oracle(rows) hashes to the reference's md5).
+        Rewritten by this script, byte-identical when nothing changed (np.savez, no timestamps).
 """
 import hashlib
 import json
 import os
+import shlex
 import sys
 
 import numpy as np
@@ -24,30 +26,41 @@ from oracle_binding import oracle_run  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 NAV = os.path.join(G, "20feb2022.rnx")
+DEFAULTS = {"l": "-6,51,100", "t": "2022/02/20,12:00:00", "d": "10"}  # the command line of G1/G2 (reference_md5.json "source")
 
-REFERENCE = {
-    "source": "BASELINE.md section 2 and SURVEY.md section 8(c): unmodified reference binary, "
-              "rinex_files/20feb2022.rnx, -l -6,51,100 -t 2022/02/20,12:00:00 -d 10 -U 1 -b 1",
-    "G1": {"args": "-I 1", "md5": "7ab498dea29a96ff4c4729995d309222", "bytes": 102960000,
-           "prns": [5, 9, 10, 11, 12, 14, 24, 31, 36]},
-    "G2": {"args": "(iono on, reference flags -g -DDEBUG)", "md5": "25a99db96927e1f13cc79e6c73a8bc22",
-           "bytes": 102960000},
-    "G3": {"args": "-d 3, no -t", "start_week": 2197, "start_sec": 597600, "prns": [13, 18], "bytes": 30160000},
-}
+
+def scenario_of(pkg, args):
+    """Scenario for a pin's reference command-line fragment (-l / -t / -d / -I; anything else is commentary)."""
+    opt = dict(DEFAULTS)
+    iono = True
+    tok = shlex.split(args.replace("(", " ").replace(")", " ").replace(",", ",").strip())
+    i = 0
+    while i < len(tok):
+        if tok[i] in ("-l", "-t", "-d") and i + 1 < len(tok):
+            opt[tok[i][1]] = tok[i + 1]
+            i += 2
+        elif tok[i] == "-I":
+            iono = False
+            i += 2
+        else:
+            i += 1
+    return pkg.Scenario(NAV, llh=tuple(float(v) for v in opt["l"].split(",")), start=opt["t"], duration_s=float(opt["d"]),
+                        iono_enable=iono)
 
 
 def main():
     pkg = load_pkg()
-    sc = pkg.Scenario(NAV, llh=(-6, 51, 100), start="2022/02/20,12:00:00", duration_s=10, iono_enable=False)
-    rows = sc.all()
-    iq, st = oracle_run(rows, 260000, 2.6e6)
-    md5 = hashlib.md5(iq.tobytes()).hexdigest()
-    assert md5 == REFERENCE["G1"]["md5"], md5
-    digests = [hashlib.sha256(iq[e * 520000:(e + 1) * 520000].tobytes()).digest() for e in range(rows.shape[0])]
-    sha = np.frombuffer(b"".join(digests), dtype=np.uint8).reshape(-1, 32)
-    np.savez_compressed(os.path.join(G, "g1_params.npz"), rows=rows, epoch_sha256=sha, carr_phase_end=st["carr_phase"])
-    json.dump(REFERENCE, open(os.path.join(G, "reference_md5.json"), "w"), indent=1)
-    print("G1 ok", md5, rows.shape)
+    ref = json.load(open(os.path.join(G, "reference_md5.json")))
+    for name in sorted(k for k in ref if k.startswith("G") and "md5" in ref[k]):
+        rows = scenario_of(pkg, ref[name]["args"]).all()
+        iq, st = oracle_run(rows, 260000, 2.6e6)
+        md5 = hashlib.md5(iq.tobytes()).hexdigest()
+        assert iq.nbytes == ref[name]["bytes"] and md5 == ref[name]["md5"], (name, md5, iq.nbytes)
+        print(name, "ok", md5, rows.shape, "%d SVs" % int((rows["prn"][0] > 0).sum()))
+        if name == "G1":
+            digests = [hashlib.sha256(iq[e * 520000:(e + 1) * 520000].tobytes()).digest() for e in range(rows.shape[0])]
+            sha = np.frombuffer(b"".join(digests), dtype=np.uint8).reshape(-1, 32)
+            np.savez_compressed(os.path.join(G, "g1_params.npz"), rows=rows, epoch_sha256=sha, carr_phase_end=st["carr_phase"])
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 # Profiles to be judged, for one round tag (run on the GPU box from the repo root, e.g. via gpurun):
 #   tools/profile_round.sh r02   ->  gpurun_out/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench command
 #                                     gpurun_out/<tag>_bench_under_rocprof.log   its output (the JSON line is in it)
+#                                     gpurun_out/<tag>_standalone_kernel_stats.csv  the same for `bench.py --pipeline 1` (k_synth alone)
 #                                     gpurun_out/<tag>_pmc_k_synth_all.json      PMC passes (tools/pmc_synth.sh)
 #                                     gpurun_out/<tag>_pmc_k_synth.json          HBM traffic summary read by bench.py
 # Copy the ones to be judged into profiles/ afterwards.
@@ -13,6 +14,11 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
     python bench.py --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_under_rocprof.log 2>&1
 f=$(ls gpurun_out/prof_$tag/stats/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv
+# the kernel ALONE: one handle, so no two k_synth launches overlap and the average is a per-launch cost
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag/standalone -- \
+    python bench.py --pipeline 1 --no-cpu-baseline --no-extras > gpurun_out/${tag}_standalone_under_rocprof.log 2>&1
+f=$(ls gpurun_out/prof_$tag/standalone/*/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$f" ] && cp "$f" gpurun_out/${tag}_standalone_kernel_stats.csv
 tools/pmc_synth.sh $tag > gpurun_out/prof_$tag/pmc.log 2>&1
 python3 - "$tag" <<'PY'
 import json, sys
@@ -28,4 +34,5 @@ json.dump(out, open("gpurun_out/%s_pmc_k_synth.json" % tag, "w"), indent=1)
 print(json.dumps(d, indent=1, sort_keys=True))
 PY
 head -4 gpurun_out/${tag}_bench_kernel_stats.csv
+head -3 gpurun_out/${tag}_standalone_kernel_stats.csv
 grep '"metric"' gpurun_out/${tag}_bench_under_rocprof.log | cut -c1-400
