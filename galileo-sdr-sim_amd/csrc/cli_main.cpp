@@ -72,7 +72,7 @@ void usage(const char *prog)
            "                   keeps the last valid record; the reference indexes out of bounds there)\n"
            "  --sites <file>   One line lat,lon,hgt[,outfile] per receiver site: one process per site over the GPUs of the\n"
            "                   node (--gpus N, default all; --per-gpu K processes per GPU, default 1); -o is the name stem\n"
-           "  --writers <n>    Threads that move finished batches into a regular output file (default: up to 16)\n"
+           "  --writers <n>    Threads that move finished batches into a regular output file (default: up to 8; 0: sequential write)\n"
            "  -v               Verbose\n"
            "  -U/-b/-a/-G/-p/-n/-g/-i     accepted for compatibility (file sink only)\n",
            prog);
@@ -483,7 +483,10 @@ int main(int argc, char *argv[])
 
     if (n_writers < 0) {
         const unsigned hc = std::thread::hardware_concurrency();
-        n_writers = hc >= 32 ? 16 : hc >= 4 ? (int)hc / 2 : 1;
+        // (measured on the MI355X host, 256 cores, tmpfs: 4-16 writers 1.5-3.0 G samples/s, 1-2 and 32 slower than the
+        // sequential sink's 1.37 -- the kernel's page-cache insertion for ONE file does not scale with threads,
+        // profiles/r03a_sink_probe.log)
+        n_writers = hc >= 16 ? 8 : hc >= 4 ? (int)hc / 2 : 1;
     }
     Sink sink;
     if (!sink.open(outfile, realtime ? 0 : (size_t)total * epoch_bytes, n_writers)) {  // (paced runs stream: they are slow by design)

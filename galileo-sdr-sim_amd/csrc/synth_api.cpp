@@ -129,7 +129,8 @@ struct gal_synth {
     // arena for the planned batch
     void *arena = nullptr;
     size_t arena_bytes = 0;
-    DevPlan P{};
+    DevPlan P{};   // the planned batch
+    DevPlan Pw{};  // what the walker kernels of the batch in flight see: P cut to the epochs [0, end of the executed range)
     bool planned = false;
     bool executed = false;
     bool in_flight = false;  // execute() enqueued, finish() not yet called
@@ -571,6 +572,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.translate = 1;
     P.tr_e0 = 0;
     P.tr_e1 = E;
+    P.cp_e0 = 0;
 #ifdef GAL_TEST_HOOKS
     // 0 = never translate, 2 = translate with one deliberately wrong shift (exercises the fallback)
     if (const char *env = getenv("GAL_WALK_TRANSLATE")) P.translate = atoi(env);
@@ -663,12 +665,20 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     // TRANSLATED carrier legs are covered by k_synth's replay check, which works by induction from the chain root
     // and therefore only vouches for epochs it actually replays.  Outside the executed range a leg is accepted
     // through a genuine walk + bitwise stitch only (k_carr_scan: tr_e0 / tr_e1), so the carrier state a range
-    // starts from, and the end-of-plan state finish() returns, never rest on an unchecked translation.
-    // (the walker kernels take the plan by value; k_synth's device copy does not use these two fields)
-    h->P.tr_e0 = first_epoch;
-    h->P.tr_e1 = first_epoch + n_epochs;
+    // starts from never rests on an unchecked translation.
+    // (the walker kernels take the plan by value; k_synth's device copy does not use these fields)
+    // The walkers see the plan cut to [0, first_epoch + n_epochs): the carrier chain never restarts, so the epochs in
+    // front of the range must be walked for the state the range starts from -- silently, no checkpoints (cp_e0) --
+    // and the epochs behind it not at all.  (Slot-major scratch arrays are indexed with the cut plan's strides by every
+    // kernel of this batch; checkpoint and per-epoch arrays are epoch-major and keep their places.)
+    h->Pw = h->P;
+    h->Pw.E = first_epoch + n_epochs;
+    h->Pw.LEGS = h->Pw.E * h->P.W;
+    h->Pw.tr_e0 = first_epoch;
+    h->Pw.tr_e1 = first_epoch + n_epochs;
+    h->Pw.cp_e0 = first_epoch;
     hipStream_t st = h->stream;
-    const DevPlan *P = &h->P;
+    const DevPlan *P = &h->Pw;
     // ws: the walker chain (the handle's high-priority stream, ordered after the caller's stream by an event)
     hipStream_t ws = st;
     if (h->walk_stream) {
@@ -734,7 +744,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     h->in_flight = false;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    const DevPlan *P = &h->P;
+    const DevPlan *P = &h->Pw;
     HIP_TRY(hipStreamSynchronize(st));
     float ms_walk = 0, ms_synth = 0;
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);

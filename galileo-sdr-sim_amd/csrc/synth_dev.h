@@ -62,6 +62,8 @@ struct DevPlan {
     void *scanm;         // scratch of the multi-block stitch (long batches), null: single-block k_carr_scan
     int translate;       // 1 normal; 0: always re-walk (the all-walked fallback); 2: GAL_TEST_HOOKS builds only
     int tr_e0, tr_e1;    // legs of epochs outside [tr_e0, tr_e1) are never translated (gal_synth_execute_range)
+    int cp_e0;           // the walkers emit chunk checkpoints from this epoch on only (gal_synth_execute_range: epochs in
+                         // front of the range are walked silently -- their states are needed, their checkpoints are not)
 
     // checkpoints, one per chunk + end state
     double *cp_x;     // [E][S][CP1]

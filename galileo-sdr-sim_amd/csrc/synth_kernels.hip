@@ -86,6 +86,12 @@ __global__ void k_walk_code(DevPlan P)
     double *cpx = P.cp_x + (size_t)idx * P.CP1;
     uint32_t *cpi = P.cp_ib + (size_t)idx * P.CP1;
     const double c = P.cstep[idx];
+    if (idx < P.cp_e0 * P.S) {
+        // an epoch in front of the executed range: only its page flip matters (k_pages), no checkpoint is read
+        const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], c, 1.0 / c, P.N, P.N, [](int, double, int, int) {});
+        P.flip_in[idx] = (uint8_t)end.flipped;
+        return;
+    }
     const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], c, 1.0 / c, P.N, P.R,
                                   [&](int k, double x, int ibit, int flipped) {
                                       cpx[k] = x;
@@ -360,7 +366,9 @@ __global__ void k_walk_carr(DevPlan P, int first)
     n = n > L ? L : n;
     const double d = P.dstep[idx];
     double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-    const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { cpp[c] = v; });
+    // (epochs in front of the executed range are walked without checkpoints: one stretch, nobody reads them)
+    const WalkOut o = e < P.cp_e0 ? carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {})
+                                  : carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { cpp[c] = v; });
     if (o.last_w >= 0) {
         lw = A + o.last_w;
         lr = o.last_r;

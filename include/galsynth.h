@@ -153,11 +153,12 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
 
 /*
  * The same for the epochs [first_epoch, first_epoch + n_epochs) of the planned batch only: iq_dev receives
- * n_epochs * samples_per_epoch * 4 bytes.  The NCO walk always covers the whole plan (it is what yields the
- * exact carrier state at first_epoch: 0.5 ms per 1199 epochs x 12 SVs), the synthesis only the range -- this is
- * how ONE scenario is cut into contiguous epoch ranges for several GPUs without any exchange (bench.py --shard
- * scenario): every rank plans the whole scenario and executes its own range.  gal_synth_finish returns the state
- * at the end of the PLAN, not of the range.
+ * n_epochs * samples_per_epoch * 4 bytes.  This is how ONE scenario is cut into contiguous epoch ranges for several GPUs
+ * without any exchange (bench.py --shard scenario): every rank plans the whole scenario and executes its own range.
+ * The carrier chain never restarts, so the NCO walk covers the epochs [0, first_epoch + n_epochs): those in front of the
+ * range silently (their states are needed, their checkpoints are not), those behind it not at all -- a rank's walker
+ * work grows with the prefix it needs, not with the plan.  gal_synth_finish then returns the channel state at the END OF
+ * THE EXECUTED RANGE (= the end of the plan for a range that reaches it, in particular for gal_synth_execute).
  */
 int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch, int32_t n_epochs);
 

@@ -456,7 +456,7 @@ def test_range_execute_never_rests_on_an_unreplayed_translation(pkg, monkeypatch
     """gal_synth_execute_range replays (and therefore checks) only its own epochs, so a translated leg in front of
     the range could not be caught by k_synth's self-check: such legs must be walked, never translated.  The test
     hook would corrupt the translation of (slot 0, epoch 0, leg 5); a range that starts after epoch 0 must come
-    out bit-exact WITHOUT needing the fallback, and the end-of-plan state must be exact too."""
+    out bit-exact WITHOUT needing the fallback, and the state at the end of the range must be exact too."""
     import torch
 
     n = 260000
@@ -471,8 +471,10 @@ def test_range_execute_never_rests_on_an_unreplayed_translation(pkg, monkeypatch
             st, stats = eng.finish()
             assert stats["chain_mismatch"] == 0 and eng.walk_counts()[2] == 0
             assert np.array_equal(out.cpu().numpy(), ref_iq[e0 * n * 2:(e0 + ne) * n * 2]), (e0, ne)
-            act = ref_st["prn"] > 0
-            assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+            _, end_st = oracle_run(p[: e0 + ne], n, 2.6e6)  # finish() returns the state at the end of the RANGE
+            act = end_st["prn"] > 0
+            assert np.array_equal(st["carr_phase"][act].view(np.uint64), end_st["carr_phase"][act].view(np.uint64))
+            assert np.array_equal(st["page"][act], end_st["page"][act])
         # a range that contains the bad leg is replayed, caught and repaired
         out = torch.empty(2 * n * 2, dtype=torch.int16, device="cuda")
         eng.execute(out.data_ptr(), 0, 2)
@@ -518,7 +520,9 @@ def test_batch_without_any_channel(pkg):
 def test_epoch_ranges_of_one_plan(pkg):
     """gal_synth_execute_range: one scenario cut into contiguous epoch ranges (how it shards over GPUs, bench.py
     --shard scenario): each range synthesised on its own equals the corresponding slice of the full output; the
-    walker always covers the whole plan, so a range that starts mid-run gets the exact carrier state."""
+    walker covers the epochs up to the end of the range (those in front of it silently), so a range that starts mid-run
+    gets the exact carrier state, and finish() returns the state at the end of the range: the next range, planned on its
+    own from that state, continues bit-exactly."""
     import torch
 
     n = 52000
@@ -535,7 +539,18 @@ def test_epoch_ranges_of_one_plan(pkg):
                 st, stats = eng.finish()
                 assert stats["chain_mismatch"] == 0
                 parts.append(out.cpu().numpy())
+                walked = eng.walk_counts()[0]
+                assert walked <= (e0 + ne) * 8 * 14 * 5 // 4 + 64, (walked, e0, ne)  # legs of the prefix (plus re-walks), not of the plan
             assert np.array_equal(np.concatenate(parts), ref_iq), world
+        # the state finish() returns is the one at the end of the range: a fresh plan of the remaining epochs continues from it
+        out = torch.empty(4 * n * 2, dtype=torch.int16, device="cuda")
+        eng.execute(out.data_ptr(), 3, 4)
+        st_mid, _ = eng.finish()
+        q = p[7:].copy()
+        q["flags"][0, :] = 0
+        rest, _, _ = eng.run_host(q, st_mid)
+        assert np.array_equal(rest, ref_iq[7 * n * 2:])
+        eng.plan(p)
         with pytest.raises(pkg.GalSynthError):
             eng.execute(out.data_ptr(), 10, 2)
 
