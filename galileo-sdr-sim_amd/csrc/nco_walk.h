@@ -99,8 +99,8 @@ GAL_HD Batch nco_batch(double x, double d, int n_max, double cap, double inv_ad)
 // Carrier chain: N samples with constant step d.  `emit(c, p)` receives the phase BEFORE sample
 // c*R for c = 0 .. ceil(N/R)-1; the return value is the phase after sample N-1 (what the next epoch
 // starts from).  inv_ad = 1.0 / fabs(d) (any value if d == 0).
-// Loop shape (uniform across lanes): [checkpoint?] [closed-form batch, capped at the next checkpoint]
-// [one genuine step unless the batch ended on the checkpoint].
+// Loop shape (uniform across lanes): [checkpoint at the iteration start?] [closed-form batch; checkpoints inside it are
+// emitted from the closed form] [one genuine step unless the walk is over].
 // carr_walk with wrap tracking: additionally reports the LAST wrap inside the walk -- the local sample
 // index right after the wrapping step and the residual phase there -- which is what the speculative
 // stitcher (synth_kernels.hip: k_walk_carr / k_carr_scan) uses as a leg's hand-over state: right after a
@@ -148,8 +148,8 @@ GAL_HD bool tie_step(double d)
     return t53 == (double)(long long)t53;
 }
 
-// The carrier walk proper.  Loop shape (uniform across lanes): [checkpoint?] [closed-form batch inside the
-// current binade, capped at the next checkpoint] [one genuine step unless the batch ended on the checkpoint].
+// The carrier walk proper.  Loop shape (uniform across lanes): [checkpoint at the iteration start?] [closed-form batch
+// inside the current binade; checkpoints inside it come out of the same closed form] [one genuine step unless over].
 // The batch is a specialisation of nco_batch for the case that matters -- phase and step of the same sign
 // (|p| grows towards the wrap), 2^-30 <= |d| -- with everything that depends only on d hoisted out of the
 // loop; other states (a phase still running against a step that changed sign, degenerate steps) take the
@@ -202,14 +202,20 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
             ++c;
             next_cp += R;
         }
-        const int stop = next_cp < N ? next_cp : N;  // never run past a checkpoint or the end
-        const Batch b = nco_batch(p, d, stop - i, 1.0, inv_ad);
+        const Batch b = nco_batch(p, d, N - i, 1.0, inv_ad);
         const double a0 = p;
+        // checkpoints INSIDE the batch come out of the same closed form (x_j = fma(j, inc, x) exactly for j <= n): the
+        // walk does not stop for them
+        while (next_cp <= i + b.n && next_cp < N) {
+            emit(c, fma_exact((double)(next_cp - i), b.inc, a0));
+            ++c;
+            next_cp += R;
+        }
         p = fma_exact((double)b.n, b.inc, p);
         const double m = binade_margin(a0, p);
         mg = m < mg ? m : mg;
         i += b.n;
-        if (i < stop) GAL_GENUINE_STEP()
+        if (i < N) GAL_GENUINE_STEP()
     }
     // ---- lean iterations: |p| only grows until the wrap, which keeps the sign -- the regime is permanent
     const double sd = dsign ? -1.0 : 1.0;
@@ -219,7 +225,6 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
             ++c;
             next_cp += R;
         }
-        const int stop = next_cp < N ? next_cp : N;
         const uint64_t pa = d2u(p) & ~kSign;
         const uint32_t ea = (uint32_t)(pa >> 52);
         const bool can = ea > ed;                      // above the step's binade (hence normal)
@@ -234,7 +239,7 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
         // 2^-33 / |d| <= 2^-3 of the true quotient, so it overshoots floor(t/dk) by at most one, which the
         // exact remainder test catches (n*dk is a multiple of g below 2^(k+1): exactly representable)
         double q = t * inv_ad;
-        const double qmax = (double)(stop - i);
+        const double qmax = (double)(N - i);
         q = q > qmax ? qmax : q;
         int n = (int)q;
         n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
@@ -245,9 +250,14 @@ GAL_HD WalkOut carr_walk_track(double p, double d, double inv_ad, int N, int R, 
         const double m1 = a - pk;                      // first state of the batch above the binade floor
         mg = m1 < mg ? m1 : mg;
         mg = room < mg ? room : mg;
+        while (next_cp <= i + n && next_cp < N) {      // checkpoints inside the batch: same closed form, no stop
+            emit(c, fma_exact((double)(next_cp - i) * sd, dk, p));
+            ++c;
+            next_cp += R;
+        }
         p = fma_exact(nd * sd, dk, p);
         i += n;
-        if (i < stop) GAL_GENUINE_STEP()
+        if (i < N) GAL_GENUINE_STEP()
     }
 #undef GAL_GENUINE_STEP
     const double m = binade_margin(p, p);  // the state handed over
@@ -292,11 +302,18 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
         const bool flip = ibit >= 500;
         ibit = flip ? 0 : ibit;
         flipped |= flip ? 1 : 0;
-        const int stop = next_cp < N ? next_cp : N;
-        const Batch b = nco_batch(x, cstep, stop - i, 4092.0, inv_c);
+        const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
+        // checkpoints inside the batch come out of its closed form (every state of a batch is below the wrap, so the
+        // pre-check state IS the state): the walk stops at binade crossings and wraps only -- 13 times per code period
+        // instead of once per chunk on top of that
+        while (next_cp <= i + b.n && next_cp < N) {
+            emit(c, fma_exact((double)(next_cp - i), b.inc, x), ibit, flipped);
+            ++c;
+            next_cp += R;
+        }
         x = fma_exact((double)b.n, b.inc, x);
         i += b.n;
-        if (i < stop) {
+        if (i < N) {
             x = x + cstep;
             ++i;
         }

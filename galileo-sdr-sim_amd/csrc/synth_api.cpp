@@ -42,13 +42,11 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 
 extern "C" {
 void galk_warm(hipStream_t st);
-void galk_launch_prep(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
-void galk_launch_state_phase(const DevPlan *P, hipStream_t st);
 int galk_scanm_blocks(int legs);
 size_t galk_scanm_bytes(int S, int legs);
 int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
@@ -98,10 +96,10 @@ void init_tables()
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
 constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block per slot stitches the carrier legs
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
-constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front: walk + stitch, translate, one spare -- ~60 us of no-op
-                                    // launches in front of k_synth when the chain is complete after two, as it normally is;
-                                    // a handle whose last batch got by with two enqueues two (gal_synth_finish iterates and
-                                    // repeats the synthesis if that turns out to be one too few, and the handle goes back to three)
+constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + stitch (which translates on the spot), one spare --
+                                    // no-op launches in front of k_synth when the chain is complete after one, as it normally
+                                    // is; a handle whose last batch got by with one enqueues one (gal_synth_finish iterates and
+                                    // repeats the synthesis if that turns out to be one too few, and the handle goes back to two)
 
 }  // namespace
 
@@ -493,6 +491,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_params = take(ES * sizeof(gal_chan_epoch_t));
     const size_t o_state_in = take(sizeof(gal_chan_state_t) * S);
     const size_t o_act = take((size_t)n_groups * E * kActRow), o_nact = take((size_t)n_groups * E * 4);
+    // SoA copies of the records and the NCO steps (written below, on the host: no kernel in front of the walker chain)
+    const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
+    const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
+    const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4);
     const size_t up_bytes = off;
     // zeroed region (ONE memset): checkpoints, first guesses, leg records that are read before they are written
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
@@ -502,9 +504,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t zero_end = off;
     const size_t o_clmw = take(LEGS * S * 8);  // "no claim" = -1
     const size_t o_state_out = take(sizeof(gal_chan_state_t) * S);
-    const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
-    const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
-    const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4), o_pcur = take(ES * GAL_PAGE_WORDS * 4);
+    const size_t o_pcur = take(ES * GAL_PAGE_WORDS * 4);
     const size_t o_flip = take(ES);
     const size_t o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
@@ -604,6 +604,25 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         memcpy(rows, params, ES * sizeof(gal_chan_epoch_t));
         for (size_t i = 0; i < ES; ++i)
             if (rows[i].carr_phase0 == 0.0) rows[i].carr_phase0 = 0.0;
+        {
+            // src/galileo-sdr.cpp:528,531: the product is rounded to double before it is added -- one IEEE multiplication,
+            // the same bits on the host as in the reference's loop
+            int *u_prn = (int *)(up + o_prn), *u_ib0 = (int *)(up + o_ib0);
+            uint32_t *u_flags = (uint32_t *)(up + o_flags), *u_pnext = (uint32_t *)(up + o_pnext);
+            double *u_x0 = (double *)(up + o_x0), *u_p0 = (double *)(up + o_p0);
+            double *u_cstep = (double *)(up + o_cstep), *u_dstep = (double *)(up + o_dstep);
+            for (size_t i = 0; i < ES; ++i) {
+                const gal_chan_epoch_t &r = rows[i];
+                u_prn[i] = r.prn;
+                u_flags[i] = r.flags;
+                u_ib0[i] = r.ibit0;
+                u_x0[i] = r.code_phase0;
+                u_p0[i] = r.carr_phase0;
+                u_cstep[i] = r.f_code * P.delt;
+                u_dstep[i] = r.f_carr * P.delt;
+                memcpy(u_pnext + i * GAL_PAGE_WORDS, r.page_next, sizeof(r.page_next));
+            }
+        }
         gal_chan_state_t *st = (gal_chan_state_t *)(up + o_state_in);
         if (state_in) memcpy(st, state_in, sizeof(gal_chan_state_t) * S);
         for (int i = 0; i < S; ++i)
@@ -686,16 +705,15 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
         HIP_TRY(hipEventRecord(h->ev_in, st));
         HIP_TRY(hipStreamWaitEvent(ws, h->ev_in, 0));
     }
-    HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), ws));
     HIP_TRY(hipEventRecord(h->ev[0], ws));
-    galk_launch_prep(P, ws);
     HIP_TRY(hipEventRecord(h->ev_prep, ws));
+    // Speculative carrier walk, the chain k_synth waits for: first guesses (which also reset the batch's counters), then
+    // h->enq_passes passes of walk + stitch (the stitch translates on the spot and its last block publishes the pass and
+    // the end-of-batch phase), enqueued back to back, then the synthesis kernel -- all asynchronously: the host does not
+    // wait here, so several handles can be kept in flight (the latency-bound walk of one batch then runs beside the
+    // issue-bound synthesis of another).  gal_synth_finish() looks at the counters; in the rare case that the chain was
+    // not verified by then it iterates further and repeats the synthesis.
     galk_launch_carr_guess(P, ws);
-    // Speculative carrier walk: kDefaultPasses passes are enqueued back to back (walk + stitch, then the translations,
-    // whose stitch is skipped), then the synthesis kernel, all asynchronously: the host does not wait here, so several
-    // handles can be kept in flight (the latency-bound walk of one batch then runs beside the issue-bound synthesis
-    // of another).  gal_synth_finish() looks at the counter; in the rare case that the chain was not verified by then
-    // it iterates further and repeats the synthesis.
     int n_passes = h->enq_passes;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;
@@ -703,33 +721,28 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, ws);
         galk_launch_carr_scan(P, ws);
-        if (pass == 0) {
-            // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on
-            // the carrier chain: they run on a second stream beside the carrier passes and join before k_synth
-            // (enqueued after the first carrier pass: the carrier chain is the critical path, and every launch
-            // call in front of it delays it by the 5-8 us the call takes)
-            HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
-            galk_launch_walk_code(P, h->aux_stream);
-            galk_launch_pages(P, h->aux_stream);
-            HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
-        }
     }
-    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, ws));
-    galk_launch_state_phase(P, ws);
+    // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the carrier chain:
+    // they run on a second stream beside it and join before k_synth.  (Enqueued after the carrier passes: every launch
+    // call in front of those delays the critical path by the 5-8 us the call takes.)
+    HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
+    galk_launch_walk_code(P, h->aux_stream);
+    galk_launch_pages(P, h->aux_stream);
+    HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     if (ws != st) {
         HIP_TRY(hipEventRecord(h->ev_walk, ws));
         HIP_TRY(hipStreamWaitEvent(st, h->ev_walk, 0));
     }
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
-    // the end-of-batch state is final once the walkers are (it does not depend on k_synth): fetch it now, beside the
-    // synthesis, so that finish() has it without another round trip (its repair paths fetch it again)
-    HIP_TRY(hipMemcpyAsync(h->h_state, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost, st));
-    h->state_fetched = true;
     HIP_TRY(hipEventRecord(h->ev[1], st));
     int rc = enqueue_synth(h, (uint32_t *)iq_dev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], st));
-    HIP_TRY(hipMemcpyAsync(h->h_ctr + CTR_COUNT, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+    // counters (walker passes + replay check) and the end-of-batch state, behind the synthesis: nothing in front of
+    // k_synth that it does not need (finish()'s repair paths fetch both again)
+    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->h_state, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost, st));
+    h->state_fetched = true;
     h->last_iq = (uint32_t *)iq_dev;
     h->stats.synth_runs = 1;
     h->executed = true;
@@ -749,8 +762,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     float ms_walk = 0, ms_synth = 0;
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
     hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[2]);
-    int *ctr_walk = h->h_ctr;              // counters after the enqueued walker passes
-    int *ctr_end = h->h_ctr + CTR_COUNT;   // counters after the synthesis kernel
+    int *ctr_walk = h->h_ctr, *ctr_end = h->h_ctr;  // counters after the synthesis kernel
     if (ctr_walk[CTR_UNVERIFIED] != 0) {
         // stragglers (itinerary mismatches / tie epochs beyond the enqueued passes): iterate from the host
         // until every leg is verified, then redo the end state and the synthesis with the exact checkpoints
@@ -768,7 +780,6 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         }
         HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
         h->state_fetched = false;
-        galk_launch_state_phase(P, st);
         HIP_TRY(hipEventRecord(h->ev[1], st));
         h->stats.synth_runs += 1;
         int rc = enqueue_synth(h, h->last_iq);
@@ -789,8 +800,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         DevPlan Pw = *P;
         Pw.translate = 0;
         const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
-        HIP_TRY(hipMemsetAsync(P->ctr, 0, CTR_COUNT * sizeof(int), st));
-        galk_launch_carr_guess(&Pw, st);
+        galk_launch_carr_guess(&Pw, st);  // (resets the counters)
         int first = 1;
         do {
             if (!first && ctr_walk[CTR_PASSES] >= max_passes)
@@ -804,7 +814,6 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
             HIP_TRY(hipStreamSynchronize(st));
         } while (ctr_walk[CTR_UNVERIFIED] != 0);
         h->state_fetched = false;
-        galk_launch_state_phase(P, st);
         HIP_TRY(hipEventRecord(h->ev[1], st));
         h->stats.synth_runs += 1;
         int rc = enqueue_synth(h, h->last_iq);
@@ -819,7 +828,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         h->n_fallbacks += 1;
     }
     h->stats.walk_passes = ctr_end[CTR_PASSES];
-    h->enq_passes = ctr_end[CTR_PASSES] > 2 ? kDefaultPasses : 2;
+    h->enq_passes = ctr_end[CTR_PASSES] > 1 ? kDefaultPasses : 1;
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;

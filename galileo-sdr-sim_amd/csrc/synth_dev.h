@@ -9,7 +9,7 @@
 #include "../../include/galsynth.h"
 
 enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_UNVER_NEXT = 3, CTR_WALKS = 4, CTR_SHIFTS = 5, CTR_REWALK_NEXT = 6,
-       CTR_MODE = 7, CTR_COUNT = 8 };
+       CTR_TICKET = 7, CTR_COUNT = 8 };
 
 // Everything lives in HBM; [E][S] arrays are indexed e * S + s.
 struct DevPlan {

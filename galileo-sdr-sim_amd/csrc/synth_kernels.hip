@@ -3,21 +3,22 @@
 // Replaces the per-sample loop of the reference, src/galileo-sdr.cpp:481-539.
 // Pipeline per batch of epochs (walker chain on two high-priority streams of the handle, k_synth on the
 // caller's stream, joined by events):
-//   k_prep         AoS epoch records -> SoA, NCO steps c = f_code*delt, d = f_carr*delt (one rounding each,
-//                  exactly the product the reference recomputes every sample, :528,:531)
+//   (host)         gal_synth_plan writes the SoA copies of the epoch records and the NCO steps c = f_code*delt,
+//                  d = f_carr*delt (one rounding each, exactly the product the reference recomputes every sample,
+//                  :528,:531) into the upload region
 //   k_walk_code    one lane per (epoch, slot): exact closed-form walk of the code-phase chain, emitting a
 //                  checkpoint (phase, symbol index, page-flip flag) every R samples           [nco_walk.h]
 //   k_pages        which page is in force at each epoch start (pages change only when a symbol counter
 //                  wraps inside the sample loop, :497-506)                [both on the second walker stream]
-//   k_carr_guess / k_walk_carr / k_carr_scan (+ k_carr_publish), normally 2 passes
+//   k_carr_guess / k_walk_carr / k_carr_scan (long batches: k_scanm_claims / _fold / _apply), normally ONE pass
 //                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively on LEGS
 //                  (8 per epoch): a leg is walked from its anchor = the last wrap event before it (first
 //                  guess: drift-compensated ideal arithmetic); the stitcher accepts a leg only when its
 //                  anchor is BITWISE the claim of the verified chain before it, otherwise re-anchors it at
 //                  the predicted claim (rounded-add chains commute with shifts on the 2^-52 grid every wrap
 //                  residual lives on, up to one predictable tie flip).  A re-anchored leg whose anchor only
-//                  moved by less than its binade margin is TRANSLATED in the next pass instead of walked.
-//   k_state_phase  end-of-batch carrier phase per slot
+//                  moved by less than its binade margin is TRANSLATED by the stitcher on the spot instead of
+//                  walked again; the last block of a stitch publishes the pass and the end-of-batch phase.
 //   k_synth<NCH>   the hot kernel: one lane replays R consecutive samples for ALL active channels with the
 //                  reference's exact operation sequence from its checkpoint, accumulates packed
 //                  (Q<<16)+I in a register, and stores int16 I/Q in 64-byte bursts.  PRN memory codes (as
@@ -52,27 +53,8 @@ using namespace galnco;
 #endif
 
 #if GAL_TU_WALK
-// ------------------------------------------------------------------------------------------------
-__global__ void k_prep(DevPlan P)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.E * P.S) return;
-    const gal_chan_epoch_t *r = &P.params[idx];
-    const int prn = r->prn;
-    P.prn[idx] = prn;
-    P.flags[idx] = r->flags;
-    P.ib0[idx] = r->ibit0;
-    P.x0[idx] = r->code_phase0;
-    P.p0[idx] = r->carr_phase0;
-    // src/galileo-sdr.cpp:528,531: the product is rounded to double before it is added
-    P.cstep[idx] = r->f_code * P.delt;
-    P.dstep[idx] = r->f_carr * P.delt;
-#pragma unroll
-    for (int w = 0; w < GAL_PAGE_WORDS; ++w) {
-        P.page_next[(size_t)idx * GAL_PAGE_WORDS + w] = r->page_next[w];
-    }
-}
-
+// (The SoA copies of the epoch records -- prn, flags, ib0, x0, p0, cstep, dstep, page_next -- are written by
+// gal_synth_plan on the host, into the upload region: round 2 had a kernel for it, one more launch in front of the chain.)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_walk_code(DevPlan P)
 {
@@ -248,13 +230,51 @@ __global__ __launch_bounds__(GUESS_THREADS) void k_carr_guess(DevPlan P)
         }
         __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        P.ctr[CTR_UNVERIFIED] = 1;  // force the first walk
-        P.ctr[CTR_PASSES] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) {
+        // the batch's counters start here (no memset in front of the chain); UNVERIFIED != 0 forces the first walk
+        P.ctr[threadIdx.x] = threadIdx.x == CTR_UNVERIFIED ? 1 : 0;
     }
 }
 
 __device__ __forceinline__ int d_residue_u52(double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); }
+
+// TRANSLATED acceptance of a leg (called by the stitchers, k_carr_scan / k_scanm_apply, for a leg whose anchor is the
+// same wrap event as before with a residual that moved by `dl`, a multiple of 2^-52 smaller than the leg's binade
+// margin): a walk from the new anchor would visit the same binades step by step, so every state it produces is the old
+// one plus the shift, bit for bit (nco_walk.h: binade_margin; ties: WalkOut::tdir) -- the leg's 32 checkpoints, end
+// phase and claim are shifted in place instead of walking it again.  k_synth's replay check covers it.
+__device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, const int i, double dl)
+{
+    const int e = i / P.W, w = i - e * P.W;
+    const int idx = e * P.S + s;
+    const size_t li = (size_t)s * P.LEGS + i;
+    const long long A = (long long)e * P.N + (long long)w * (P.Lc * P.R);  // global index of the leg's first sample
+#ifdef GAL_TEST_HOOKS
+    if (P.translate == 2 && li == GAL_HOOK_BAD_LEG) dl += 4.440892098500626e-16;  // a deliberately wrong shift
+#endif
+    // an odd shift flips the first tie of the walk: from that wrap on the trajectory is off by dl2
+    const int td = P.tdir[li];
+    const bool flip = td != 0 && (d_residue_u52(dl) & 1);
+    const double dl2 = flip ? dl - (double)td * 2.220446049250313e-16 : dl;
+    const long long tp = flip ? P.tpos[li] : (long long)1 << 62;  // global index right after the tie step
+    int nck = P.nchunks - w * P.Lc;
+    nck = nck > P.Lc ? P.Lc : nck;
+    double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
+    // (eight independent read-modify-writes in flight: a plain loop waits for every load)
+    for (int c0 = 0; c0 < nck; c0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = c0 + k < nck ? cpp[c0 + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < nck) cpp[c0 + k] = v[k] + ((A + (long long)(c0 + k) * P.R >= tp) ? dl2 : dl);
+    }
+    if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
+    P.pend[li] += dl2;
+    if (P.clm_w[li] >= 0) P.clm_r[li] += (P.clm_w[li] >= tp) ? dl2 : dl;
+    P.marg[li] -= __builtin_fabs(dl) + 2.220446049250313e-16;
+    if (flip) P.tdir[li] = (int8_t)-td;  // the shifted trajectory resolved that tie the other way
+}
 
 // k_walk_carr: one lane per (leg, slot).  A leg is walked from its ANCHOR -- the last wrap event at or before
 // its first sample, (omega, r): "the phase before global sample omega is r", or the chain root -- first up to
@@ -297,44 +317,7 @@ __global__ void k_walk_carr(DevPlan P, int first)
         P.anc_r[li] = p;
         P.verified[li] = 0;
     } else {
-        const int dk = P.dirty[li];
-        if (!dk) return;
-        if (dk == 2) {
-            // TRANSLATED acceptance: the stitcher moved the anchor by `shift` (same wrap event, a multiple of
-            // 2^-52 smaller than the leg's binade margin): a walk from the new anchor would visit the same
-            // binades step by step, so every state it produces is the old one plus the shift, bit for bit
-            // (nco_walk.h: binade_margin; ties: WalkOut::tdir).  k_synth's replay check covers it.
-            double dl = P.shift[li];
-#ifdef GAL_TEST_HOOKS
-            if (P.translate == 2 && li == GAL_HOOK_BAD_LEG) dl += 4.440892098500626e-16;  // a deliberately wrong shift
-#endif
-            // an odd shift flips the first tie of the walk: from that wrap on the trajectory is off by dl2
-            const int td = P.tdir[li];
-            const bool flip = td != 0 && (d_residue_u52(dl) & 1);
-            const double dl2 = flip ? dl - (double)td * 2.220446049250313e-16 : dl;
-            const long long tp = flip ? P.tpos[li] : (long long)1 << 62;  // global index right after the tie step
-            int nck = P.nchunks - w * P.Lc;
-            nck = nck > P.Lc ? P.Lc : nck;
-            double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-            // (eight independent read-modify-writes in flight: a plain loop waits for every load)
-            for (int c0 = 0; c0 < nck; c0 += 8) {
-                double v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = c0 + k < nck ? cpp[c0 + k] : 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (c0 + k < nck) cpp[c0 + k] = v[k] + ((A + (long long)(c0 + k) * P.R >= tp) ? dl2 : dl);
-            }
-            if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
-            P.pend[li] += dl2;
-            if (P.clm_w[li] >= 0) P.clm_r[li] += (P.clm_w[li] >= tp) ? dl2 : dl;
-            P.marg[li] -= __builtin_fabs(dl) + 2.220446049250313e-16;
-            if (flip) P.tdir[li] = (int8_t)-td;  // the shifted trajectory resolved that tie the other way
-            P.dirty[li] = 0;
-            const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
-            if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_SHIFTS], __builtin_popcountll(m));
-            return;
-        }
+        if (!P.dirty[li]) return;
         cur = P.anc_w[li];
         p = P.anc_r[li];
     }
@@ -528,23 +511,87 @@ __device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
     return tie_flip(o.G + D, o.tdir);
 }
 
+// What the stitch does to ONE leg once the true carries in front of it are known (sweep 3 of k_carr_scan, phase C of the
+// multi-block stitch): verified, or re-anchored at the predicted true value `nr` of the claim in front of it -- and then
+// either TRANSLATED on the spot (same wrap event, only its residual moved, and the move is provably itinerary-preserving:
+// translate_leg) or marked for another walk.  (Round 2 left the translations to the next walker pass: one more kernel and
+// a skipped stitch behind it in the chain k_synth waits for.)
+__device__ __forceinline__ void stitch_apply_leg(const DevPlan &P, const int s, const int i, const LegRec &L, const LegOp &o,
+                                                 const int allok, const double nr, int &unver, int &rewalk, int &shifts)
+{
+    const size_t li = (size_t)s * P.LEGS + i;
+    if (allok) {
+        P.verified[li] = 1;
+        return;
+    }
+    ++unver;
+    if (o.have && (L.aw != o.nw || d2u(L.ar) != d2u(nr))) {
+        const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
+        const int el = i / P.W;
+        const bool tr = P.translate && el >= P.tr_e0 && el < P.tr_e1 && L.aw == o.nw &&
+                        __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
+        P.anc_w[li] = o.nw;
+        P.anc_r[li] = nr;
+        P.dirty[li] = tr ? 0 : 1;
+        if (tr) {
+            translate_leg(P, s, i, dl);
+            ++shifts;
+        }
+        rewalk += tr ? 0 : 1;
+    }
+    rewalk += o.have ? 0 : 1;
+}
+
+// End of a stitch: the LAST block to get here (a ticket; every block has fenced its writes before taking one) publishes
+// the count the next pass looks at and the end-of-batch carrier phase.  When the stitcher only TRANSLATED (no leg has to
+// be walked again), the translated claims are by construction the anchors it predicted for their successors: the chain is
+// complete (what stands behind this is the same argument as for a single translated leg, and k_synth's replay check).
+__device__ __forceinline__ void stitch_publish(const DevPlan &P, const int t, const int nblocks, const int unver, const int rewalk,
+                                               const int shifts, int *s_last)
+{
+    if (t == 0) {
+        if (unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], unver);
+        if (rewalk) atomicAdd(&P.ctr[CTR_REWALK_NEXT], rewalk);
+        if (shifts) atomicAdd(&P.ctr[CTR_SHIFTS], shifts);
+        __threadfence();
+        *s_last = atomicAdd(&P.ctr[CTR_TICKET], 1) == nblocks - 1;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __threadfence();
+    if (t == 0) {
+        const int unv = atomicAdd(&P.ctr[CTR_UNVER_NEXT], 0), rw = atomicAdd(&P.ctr[CTR_REWALK_NEXT], 0);
+        P.ctr[CTR_UNVERIFIED] = rw == 0 ? 0 : unv;
+        P.ctr[CTR_UNVER_NEXT] = 0;
+        P.ctr[CTR_REWALK_NEXT] = 0;
+        P.ctr[CTR_TICKET] = 0;
+        P.ctr[CTR_PASSES] += 1;
+    }
+    if (t < P.S) {  // end-of-batch carrier phase per slot (final once the chain is verified; rewritten by later passes)
+        const int prn = P.prn[(P.E - 1) * P.S + t];
+        // (device-scope load: the leg may have been translated by a block on another CU a moment ago)
+        const double pe = __hip_atomic_load(&P.pend[(size_t)t * P.LEGS + (P.LEGS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.state_out[t].carr_phase = prn > 0 ? pe : 0.0;
+    }
+}
+
 #define SCAN_THREADS 1024
 __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    if (P.ctr[CTR_MODE] == 1) return;  // the pass before only translated: nothing new to stitch (k_carr_publish)
     __shared__ int s_kind[SCAN_THREADS];
     __shared__ long long s_w[SCAN_THREADS];
     __shared__ double s_r[SCAN_THREADS];
     __shared__ int s_fv[SCAN_THREADS], s_v[SCAN_THREADS], s_ic[SCAN_THREADS];
     __shared__ double s_K[SCAN_THREADS], s_c[4][SCAN_THREADS];
-    __shared__ int s_unver, s_rewalk;
+    __shared__ int s_unver, s_rewalk, s_shifts, s_last;
     const int s = blockIdx.x;
     const int t = threadIdx.x;
     if (t == 0) {
         s_unver = 0;
         s_rewalk = 0;
+        s_shifts = 0;
     }
     const double start0 = P.state_in[s].carr_phase;
     const int K = (P.LEGS + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -669,7 +716,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
             allok = s_fv[t - 1] ? s_v[t - 1] : 0;
             D = s_ic[t - 1] ? s_K[t - 1] : s_c[0][t - 1];  // the prefix map applied to D = 0
         }
-        int unver = 0, rewalk = 0;
+        int unver = 0, rewalk = 0, shifts = 0;
         for (int i = i0; i < i1; ++i) {
             const LegRec L = leg_load(P, s, i, start0);
             const LegOp o = leg_op(P, s, L, lc);
@@ -684,34 +731,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
             }
             allok &= o.link_ok ? 1 : 0;
             const double nr = o.base + D;
-            const size_t li = (size_t)s * P.LEGS + i;
-            if (allok) {
-                P.verified[li] = 1;
-            } else {
-                ++unver;
-                if (o.have && (L.aw != o.nw || d2u(L.ar) != d2u(nr))) {
-                    // same wrap event, only its residual moved: translate the leg instead of walking it again
-                    // when the move is provably itinerary-preserving (k_walk_carr, dirty == 2)
-                    const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
-                    const int el = i / P.W;
-                    const bool tr = P.translate && el >= P.tr_e0 && el < P.tr_e1 && L.aw == o.nw &&
-                                    __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
-                    P.anc_w[li] = o.nw;
-                    P.anc_r[li] = nr;
-                    P.dirty[li] = tr ? 2 : 1;
-                    if (tr) P.shift[li] = dl;
-                    rewalk += tr ? 0 : 1;
-                }
-                rewalk += o.have ? 0 : 1;
-            }
             D = leg_d_out(o, D);
+            stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts);
         }
         if (unver) atomicAdd(&s_unver, unver);
         if (rewalk) atomicAdd(&s_rewalk, rewalk);
+        if (shifts) atomicAdd(&s_shifts, shifts);
     }
     __syncthreads();
-    if (t == 0 && s_unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], s_unver);
-    if (t == 0 && s_rewalk) atomicAdd(&P.ctr[CTR_REWALK_NEXT], s_rewalk);
+    stitch_publish(P, t, (int)gridDim.x, s_unver, s_rewalk, s_shifts, &s_last);
 }
 
 // ---- The same stitch as k_carr_scan for LONG batches, in 256-thread blocks.  k_carr_scan needs 16 waves and 72 KB of
@@ -743,7 +771,7 @@ __device__ __forceinline__ void scanm_range(const DevPlan &P, int g, int *i0, in
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_claims(DevPlan P, ScanM M)
 {
     __builtin_amdgcn_s_setprio(3);
-    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_kind[SCANM_THREADS];
     __shared__ long long s_w[SCANM_THREADS];
     __shared__ double s_r[SCANM_THREADS];
@@ -839,7 +867,7 @@ __device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, in
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M)
 {
     __builtin_amdgcn_s_setprio(3);
-    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
+    if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_fv[SCANM_THREADS], s_v[SCANM_THREADS], s_ic[SCANM_THREADS];
     __shared__ double s_K[SCANM_THREADS], s_c[4][SCANM_THREADS];
     __shared__ ClaimState s_carry;
@@ -931,13 +959,14 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM M)
 {
     __builtin_amdgcn_s_setprio(3);
-    if (P.ctr[CTR_UNVERIFIED] == 0 || P.ctr[CTR_MODE] == 1) return;
-    __shared__ int s_unver, s_rewalk;
+    if (P.ctr[CTR_UNVERIFIED] == 0) return;
+    __shared__ int s_unver, s_rewalk, s_shifts, s_last;
     const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     const int g = b * SCANM_THREADS + t;
     if (t == 0) {
         s_unver = 0;
         s_rewalk = 0;
+        s_shifts = 0;
     }
     __syncthreads();
     const double start0 = P.state_in[s].carr_phase;
@@ -993,7 +1022,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
     ClaimState lc = scanm_lc0(M, s, b, t, s_carry);
     int allok = pfv ? pv : 0;  // nothing is verified before the first root
     double D = pm.isconst ? pm.K : pm.c[0];  // the prefix map applied to D = 0
-    int unver = 0, rewalk = 0;
+    int unver = 0, rewalk = 0, shifts = 0;
     for (int i = i0; i < i1; ++i) {
         const LegRec L = leg_load(P, s, i, start0);
         const LegOp o = leg_op(P, s, L, lc);
@@ -1008,52 +1037,14 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
         }
         allok &= o.link_ok ? 1 : 0;
         const double nr = o.base + D;
-        const size_t li = (size_t)s * P.LEGS + i;
-        if (allok) {
-            P.verified[li] = 1;
-        } else {
-            ++unver;
-            if (o.have && (L.aw != o.nw || d2u(L.ar) != d2u(nr))) {
-                const double dl = nr - L.ar;  // both residuals are multiples of 2^-52: exact
-                const int el = i / P.W;
-                const bool tr = P.translate && el >= P.tr_e0 && el < P.tr_e1 && L.aw == o.nw &&
-                                __builtin_fabs(dl) + 8.881784197001252e-16 /* 2^-50 */ < P.marg[li];
-                P.anc_w[li] = o.nw;
-                P.anc_r[li] = nr;
-                P.dirty[li] = tr ? 2 : 1;
-                if (tr) P.shift[li] = dl;
-                rewalk += tr ? 0 : 1;
-            }
-            rewalk += o.have ? 0 : 1;
-        }
         D = leg_d_out(o, D);
+        stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts);
     }
     if (unver) atomicAdd(&s_unver, unver);
     if (rewalk) atomicAdd(&s_rewalk, rewalk);
+    if (shifts) atomicAdd(&s_shifts, shifts);
     __syncthreads();
-    if (t == 0 && s_unver) atomicAdd(&P.ctr[CTR_UNVER_NEXT], s_unver);
-    if (t == 0 && s_rewalk) atomicAdd(&P.ctr[CTR_REWALK_NEXT], s_rewalk);
-}
-
-// after every slot's scan: publish the count the next pass looks at.  When the stitcher asked for translations
-// only (no leg has to be walked again), the translated claims are by construction the anchors it predicted
-// for their successors, so the next pass completes the chain and its scan is skipped (CTR_MODE); what stands
-// behind this shortcut is the same argument as for a single translated leg, and k_synth's replay check.
-__global__ void k_carr_publish(DevPlan P)
-{
-    if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    if (P.ctr[CTR_MODE] == 1) {
-        P.ctr[CTR_UNVERIFIED] = 0;
-        P.ctr[CTR_MODE] = 0;
-        P.ctr[CTR_PASSES] += 1;
-        return;
-    }
-    const int unv = P.ctr[CTR_UNVER_NEXT], rw = P.ctr[CTR_REWALK_NEXT];
-    P.ctr[CTR_UNVERIFIED] = unv;
-    P.ctr[CTR_UNVER_NEXT] = 0;
-    P.ctr[CTR_REWALK_NEXT] = 0;
-    P.ctr[CTR_PASSES] += 1;
-    if (unv > 0 && rw == 0 && P.translate) P.ctr[CTR_MODE] = 1;
+    stitch_publish(P, t, (int)(gridDim.x * gridDim.y), s_unver, s_rewalk, s_shifts, &s_last);
 }
 
 // Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88: the page
@@ -1118,15 +1109,6 @@ __global__ __launch_bounds__(GUESS_THREADS) void k_pages(DevPlan P)
         P.state_out[s].prn = prn > 0 ? prn : 0;
         P.state_out[s].reserved = 0;
     }
-}
-
-// end-of-batch carrier phase per slot (after the carrier chain is verified)
-__global__ void k_state_phase(DevPlan P)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P.S) return;
-    const int prn = P.prn[(P.E - 1) * P.S + s];
-    P.state_out[s].carr_phase = prn > 0 ? P.pend[(size_t)s * P.LEGS + (P.LEGS - 1)] : 0.0;
 }
 
 #endif  // GAL_TU_WALK
@@ -2123,12 +2105,6 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // Launchers (called from synth_api.cpp, which is plain C++ and does not see <<<>>>).
 #if GAL_TU_WALK
 
-extern "C" void galk_launch_prep(const DevPlan *P, hipStream_t st)
-{
-    const int n = P->E * P->S;
-    hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, *P);
-}
-
 extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 {
     const int n = P->E * P->S;
@@ -2180,12 +2156,6 @@ extern "C" void galk_launch_carr_scan(const DevPlan *P, hipStream_t st)
         hipLaunchKernelGGL(k_scanm_fold, grid, blk, 0, st, *P, M);
         hipLaunchKernelGGL(k_scanm_apply, grid, blk, 0, st, *P, M);
     }
-    hipLaunchKernelGGL(k_carr_publish, dim3(1), dim3(1), 0, st, *P);
-}
-
-extern "C" void galk_launch_state_phase(const DevPlan *P, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_state_phase, dim3(1), dim3(64), 0, st, *P);
 }
 
 extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)

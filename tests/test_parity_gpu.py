@@ -243,37 +243,49 @@ def test_invalid_batches_are_rejected(pkg):
             eng.run_host(bad)
 
 
-def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
-    """With a single enqueued walker pass the chain is never verified in time: gal_synth_finish() must iterate
-    from the host and redo the synthesis -- the result is still bit-exact."""
-    monkeypatch.setenv("GAL_WALK_PASSES", "1")  # honoured by the GAL_TEST_HOOKS build only
-    p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=77)
-    iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
-    assert stats["walk_passes"] >= 2 and stats["synth_runs"] == 2
-    monkeypatch.delenv("GAL_WALK_PASSES")
-    iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
-    assert stats["walk_passes"] == 2 and stats["synth_runs"] == 1
-
-
-def test_enqueued_carrier_passes_adapt_to_the_previous_batch(pkg):
-    """A handle enqueues three carrier passes for its first batch and two after a batch that got by with two.  If a batch
-    then needs the third after all, gal_synth_finish() iterates and repeats the synthesis (synth_runs == 2), and the next
-    batch gets three again.  The three-pass batch is case 35 of tools/find_three_pass_batch.py 4000 5 (the fuzz generator)."""
+def _hard_batch(pkg):
+    """A batch whose carrier chain is NOT complete after one walk + stitch (some legs have to be walked again): case 35 of
+    tools/find_three_pass_batch.py 4000 5 (the fuzz generator)."""
     from fuzz_cases import random_case
 
     hard, n_samp, rate, chunk = random_case(pkg, np.random.default_rng([5, 35]), False)
     assert (rate, n_samp, chunk, hard.shape) == (2.6e6, 260000, 1360, (3, 8))
+    return hard, n_samp, rate, chunk
+
+
+def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
+    """With a single enqueued walker pass a batch that needs two is not verified in time: gal_synth_finish() must
+    iterate from the host and redo the synthesis -- the result is still bit-exact.  (An ordinary batch is complete after
+    ONE pass: the stitch translates re-anchored legs on the spot.)"""
+    hard, n_samp, rate, chunk = _hard_batch(pkg)
+    monkeypatch.setenv("GAL_WALK_PASSES", "1")  # honoured by the GAL_TEST_HOOKS build only
+    iq, st, stats = _compare(pkg, hard, n_samp, rate=rate, chunk_samples=chunk, test_hooks=True)
+    assert stats["walk_passes"] >= 2 and stats["synth_runs"] == 2
+    monkeypatch.delenv("GAL_WALK_PASSES")
+    iq, st, stats = _compare(pkg, hard, n_samp, rate=rate, chunk_samples=chunk, test_hooks=True)
+    assert stats["walk_passes"] >= 2 and stats["synth_runs"] == 1
+    p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=77)
+    monkeypatch.setenv("GAL_WALK_PASSES", "1")
+    iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["walk_passes"] == 1 and stats["synth_runs"] == 1
+
+
+def test_enqueued_carrier_passes_adapt_to_the_previous_batch(pkg):
+    """A handle enqueues two carrier passes for its first batch and one after a batch that got by with one.  If a batch
+    then needs the second after all, gal_synth_finish() iterates and repeats the synthesis (synth_runs == 2), and the next
+    batch gets two again."""
+    hard, n_samp, rate, chunk = _hard_batch(pkg)
     easy = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=8, samples_per_epoch=n_samp, seed=12)
     ref_hard, _ = oracle_run(hard, n_samp, rate)
     ref_easy, _ = oracle_run(easy, n_samp, rate)
     with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=8, device=0, chunk_samples=chunk) as eng:
-        iq, _, stats = eng.run_host(hard)  # first batch: three passes enqueued
-        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 3 and stats["synth_runs"] == 1
-        iq, _, stats = eng.run_host(easy)  # still three enqueued (the batch before needed them); needs two
-        assert np.array_equal(iq, ref_easy) and stats["walk_passes"] == 2 and stats["synth_runs"] == 1
-        iq, _, stats = eng.run_host(hard)  # two enqueued, three needed: repaired
-        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 3 and stats["synth_runs"] == 2
-        iq, _, stats = eng.run_host(hard)  # three enqueued again
+        iq, _, stats = eng.run_host(hard)  # first batch: two passes enqueued
+        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 2 and stats["synth_runs"] == 1
+        iq, _, stats = eng.run_host(easy)  # still two enqueued (the batch before needed them); needs one
+        assert np.array_equal(iq, ref_easy) and stats["walk_passes"] == 1 and stats["synth_runs"] == 1
+        iq, _, stats = eng.run_host(hard)  # one enqueued, two needed: repaired
+        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 2 and stats["synth_runs"] == 2
+        iq, _, stats = eng.run_host(hard)  # two enqueued again
         assert np.array_equal(iq, ref_hard) and stats["synth_runs"] == 1
 
 

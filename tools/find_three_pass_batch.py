@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Search seeds of the fuzz generator for batches whose carrier chain needs a third walker pass (tests of the
-adaptive number of enqueued passes): python tools/find_three_pass_batch.py [n_cases] [seed]"""
+"""Search seeds of the fuzz generator for batches whose carrier chain is not complete after one walker pass (tests of
+the adaptive number of enqueued passes; round 2, when translations took a pass of their own: after two):
+python tools/find_three_pass_batch.py [n_cases] [seed]"""
 import os
 import sys
 
@@ -24,7 +25,7 @@ for c in range(n_cases):
             iq, st, stats = eng.run_host(p)
     except pkg.GalSynthError:
         continue
-    if stats["walk_passes"] >= 3:
+    if stats["walk_passes"] >= 2:  # (round 3: the stitch translates on the spot, an ordinary batch needs ONE pass)
         found += 1
         print("case %d: passes %d rate %.4g slots %d epochs %d samples %d chunk %d" % (
             c, stats["walk_passes"], rate, p.shape[1], p.shape[0], n_samp, chunk))
