@@ -425,6 +425,7 @@ def main():
                 "walk_passes": stats["walk_passes"], "synth_runs_max": max(s.get("synth_runs", 1) for s in step_stats),
                 "chain_mismatch": stats["chain_mismatch"],
                 "pipeline_depth": depth, **({"hooks_build": True} if HOOKS_BUILD else {}),
+                **({"variant_lib": os.environ["GAL_SYNTH_LIB"]} if os.environ.get("GAL_SYNTH_LIB") else {}),
                 "window_mode": stats.get("window_mode"),  # 1: k_synth's resampled-window fast body (galsynth.h)
                 "output_checksum": "%08x" % chk,
             },

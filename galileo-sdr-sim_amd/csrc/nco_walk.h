@@ -290,6 +290,15 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
     int i = 0;
     int next_cp = 0, c = 0;
     int flipped = 0;
+    // The batch is nco_batch specialised for this chain -- phase and step positive, the phase only grows until the wrap,
+    // cap 4092 -- with everything that depends only on the step hoisted out of the loop (the walk is one long dependency
+    // chain per lane: its length in instructions IS its run time).  Steps outside (2^-40, 4) chips take the general
+    // nco_batch: same results either way, bit for bit (tests/test_walker_cpu.py against brute-force stepping).
+    const uint64_t cb = d2u(cstep);
+    const uint32_t ed = (uint32_t)(cb >> 52);
+    const bool lean = (cstep > 9.094947017729282e-13) && (cstep < 4.0) && (x >= 0.0);
+    // the one binade in which the step is an odd multiple of half an ulp (round-to-even ties inside a batch)
+    const uint32_t e_tie = ed + 1u + (uint32_t)__builtin_ctzll(cb | (1ull << 52));
     while (i < N) {
         if (next_cp == i) {
             emit(c, x, ibit, flipped);
@@ -302,17 +311,44 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
         const bool flip = ibit >= 500;
         ibit = flip ? 0 : ibit;
         flipped |= flip ? 1 : 0;
-        const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
+        int n;
+        double inc;
+        if (lean) {
+            const uint64_t xb = d2u(x);
+            const uint32_t ea = (uint32_t)(xb >> 52);
+            const bool can = ea > ed;                          // above the step's binade (hence normal)
+            const uint64_t pkb = (uint64_t)ea << 52;
+            const double pk = u2d(pkb);                        // binade floor 2^k
+            // largest state a batch may visit: the last double of the binade, or the last one below the wrap
+            const double top = ea == 1034u ? 4091.9999999999995 : u2d(pkb | 0x000fffffffffffffull);
+            const double dk = (cstep + pk) - pk;               // RN_g(step), ties to even; > 0 (step > g / 2 by far)
+            const bool odd_tie = (ea == e_tie) & ((uint32_t)xb & 1u);  // a tie binade needs x / g even
+            const double t = top - x;                          // room, exact
+            // t / dk through the caller's reciprocal of the step: overshoots floor(t / dk) by at most one, which the
+            // exact remainder test catches (n * dk is a multiple of g below 2^(k+1): exactly representable)
+            double q = t * inv_c;
+            const double qmax = (double)(N - i);
+            q = q > qmax ? qmax : q;
+            n = (int)q;
+            n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
+            n = n < 0 ? 0 : n;
+            n = (can & !odd_tie & (t >= 0.0)) ? n : 0;
+            inc = dk;
+        } else {
+            const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
+            n = b.n;
+            inc = b.inc;
+        }
         // checkpoints inside the batch come out of its closed form (every state of a batch is below the wrap, so the
         // pre-check state IS the state): the walk stops at binade crossings and wraps only -- 13 times per code period
         // instead of once per chunk on top of that
-        while (next_cp <= i + b.n && next_cp < N) {
-            emit(c, fma_exact((double)(next_cp - i), b.inc, x), ibit, flipped);
+        while (next_cp <= i + n && next_cp < N) {
+            emit(c, fma_exact((double)(next_cp - i), inc, x), ibit, flipped);
             ++c;
             next_cp += R;
         }
-        x = fma_exact((double)b.n, b.inc, x);
-        i += b.n;
+        x = fma_exact((double)n, inc, x);
+        i += n;
         if (i < N) {
             x = x + cstep;
             ++i;

@@ -746,11 +746,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 // LDS on ONE CU; beside a running k_synth (3 x 168 VGPRs per SIMD, 96 KB of LDS per CU) that means waiting for a CU to
 // drain completely, and with 2999 epochs the walker chain of the next step then takes longer than the synthesis it is
 // supposed to hide behind (2.9 ms against 2.5 ms).  Here the legs of a slot are spread over B blocks of 256 threads
-// (one wave per SIMD: such a block starts as soon as ONE synthesis block retires), SCANM_K legs per thread; what the
+// (one wave per SIMD: such a block starts as soon as ONE synthesis block retires), SCANM_K legs per thread (one: the
+// apply phase translates legs on the spot, 33 read-modify-writes each -- round 2 had four with the translations elsewhere); what the
 // single block did with two block-wide scans is done with block-local scans plus a serial fold of the (few) block
 // totals in front of each block -- three short launches instead of one long one, the same sequential statement.
 #define SCANM_THREADS 256
-#define SCANM_K 4
+#define SCANM_K 1
 
 struct ScanM {  // scratch of the multi-block stitch, per slot: G = B * SCANM_THREADS thread records, B block records
     int B, G;
@@ -832,21 +833,40 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_claims(DevPlan P, ScanM
     }
 }
 
-// claim carry in front of block b: the last block before it whose total says anything (B is small: one thread walks
-// the totals, the block shares the result)
-__device__ __forceinline__ ClaimState scanm_claim_carry(const ScanM &M, int s, int b)
+// claim carry in front of block b: the last block before it whose total says anything.  The totals are staged through
+// LDS by the whole block (one record per thread, all loads in flight together), then one thread walks them: a serial
+// walk over global memory costs a round trip per block total, which is what tied the stitch to few, fat blocks.
+struct ScanCarryLds {
+    int kind[SCANM_THREADS];
+    long long w[SCANM_THREADS];
+    double r[SCANM_THREADS];
+};
+
+__device__ __forceinline__ void scanm_claim_carry(const ScanM &M, int s, int b, int t, ScanCarryLds &L, ClaimState *out)
 {
     ClaimState c = {0, 0, 0.0};
-    for (int bb = 0; bb < b; ++bb) {
-        const size_t ob = (size_t)s * M.B + bb;
-        const int k = M.b1_kind[ob];
-        if (k != 0) {
-            c.kind = k;
-            c.w = M.b1_w[ob];
-            c.r = M.b1_r[ob];
+    for (int base = 0; base < b; base += SCANM_THREADS) {
+        const int bb = base + t;
+        if (bb < b) {
+            const size_t ob = (size_t)s * M.B + bb;
+            L.kind[t] = M.b1_kind[ob];
+            L.w[t] = M.b1_w[ob];
+            L.r[t] = M.b1_r[ob];
         }
+        __syncthreads();
+        if (t == 0) {
+            const int n = b - base < SCANM_THREADS ? b - base : SCANM_THREADS;
+            for (int k = 0; k < n; ++k)
+                if (L.kind[k] != 0) {
+                    c.kind = L.kind[k];
+                    c.w = L.w[k];
+                    c.r = L.r[k];
+                }
+        }
+        __syncthreads();
     }
-    return c;
+    if (t == 0) *out = c;
+    __syncthreads();
 }
 
 __device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, int t, const ClaimState &carry)
@@ -876,8 +896,8 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M
     const double start0 = P.state_in[s].carr_phase;
     int i0, i1;
     scanm_range(P, g, &i0, &i1);
-    if (t == 0) s_carry = scanm_claim_carry(M, s, b);
-    __syncthreads();
+    __shared__ ScanCarryLds s_stage;
+    scanm_claim_carry(M, s, b, t, s_stage, &s_carry);
     {
         ClaimState lc = scanm_lc0(M, s, b, t, s_carry);
         int allok = 1, fv = 0, isconst = 0;
@@ -972,31 +992,52 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
     const double start0 = P.state_in[s].carr_phase;
     int i0, i1;
     scanm_range(P, g, &i0, &i1);
-    // carries in front of my block (thread 0 folds the totals of the blocks before it: B is small)
+    // carries in front of my block: the totals of the blocks before it, staged through LDS and folded by thread 0
     __shared__ ClaimState s_carry;
     __shared__ int s_cfv, s_cv, s_cic;
     __shared__ double s_cK, s_cc[4];
-    if (t == 0) {
-        s_carry = scanm_claim_carry(M, s, b);
+    __shared__ ScanCarryLds s_stage;
+    __shared__ int s_bfv[SCANM_THREADS], s_bv[SCANM_THREADS], s_bic[SCANM_THREADS];
+    __shared__ double s_bK[SCANM_THREADS], s_bc[SCANM_THREADS][4];
+    scanm_claim_carry(M, s, b, t, s_stage, &s_carry);
+    {
         int cfv = 0, cv = 1;
         DMap cm;
         cm.isconst = 0; cm.K = 0.0; cm.c[0] = cm.c[1] = cm.c[2] = cm.c[3] = 0.0;
-        for (int bb = 0; bb < b; ++bb) {
-            const size_t ob = (size_t)s * M.B + bb;
-            const int bfv = M.b2_fv[ob], bv = M.b2_v[ob];
-            DMap bm;
-            bm.isconst = M.b2_ic[ob];
-            bm.K = M.b2_K[ob];
+        for (int base = 0; base < b; base += SCANM_THREADS) {
+            const int bb = base + t;
+            if (bb < b) {
+                const size_t ob = (size_t)s * M.B + bb;
+                s_bfv[t] = M.b2_fv[ob];
+                s_bv[t] = M.b2_v[ob];
+                s_bic[t] = M.b2_ic[ob];
+                s_bK[t] = M.b2_K[ob];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) bm.c[m] = M.b2_c[ob * 4 + m];
-            const DMap r = dmap_combine(cm, bm);
-            cv = bfv ? bv : (cv & bv);
-            cfv = cfv | bfv;
-            cm = r;
+                for (int m = 0; m < 4; ++m) s_bc[t][m] = M.b2_c[ob * 4 + m];
+            }
+            __syncthreads();
+            if (t == 0) {
+                const int n = b - base < SCANM_THREADS ? b - base : SCANM_THREADS;
+                for (int k = 0; k < n; ++k) {
+                    const int bfv = s_bfv[k], bv = s_bv[k];
+                    DMap bm;
+                    bm.isconst = s_bic[k];
+                    bm.K = s_bK[k];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) bm.c[m] = s_bc[k][m];
+                    const DMap r = dmap_combine(cm, bm);
+                    cv = bfv ? bv : (cv & bv);
+                    cfv = cfv | bfv;
+                    cm = r;
+                }
+            }
+            __syncthreads();
         }
-        s_cfv = cfv; s_cv = cv; s_cic = cm.isconst; s_cK = cm.K;
+        if (t == 0) {
+            s_cfv = cfv; s_cv = cv; s_cic = cm.isconst; s_cK = cm.K;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) s_cc[m] = cm.c[m];
+            for (int m = 0; m < 4; ++m) s_cc[m] = cm.c[m];
+        }
     }
     __syncthreads();
     // prefix in front of my legs = (carry of my block) then (local inclusive scan of the thread before me)
