@@ -243,7 +243,14 @@ __device__ __forceinline__ int d_residue_u52(double D) { return (int)((long long
 // margin): a walk from the new anchor would visit the same binades step by step, so every state it produces is the old
 // one plus the shift, bit for bit (nco_walk.h: binade_margin; ties: WalkOut::tdir) -- the leg's 32 checkpoints, end
 // phase and claim are shifted in place instead of walking it again.  k_synth's replay check covers it.
-__device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, const int i, double dl)
+struct TrRec {       // a translation whose checkpoint updates are left to the caller (k_scanm_apply: the block does them together)
+    double dl, dl2;  // shift before / from the tie step on
+    long long tp, A; // global sample index right after the tie step; of the leg's first sample
+    size_t base;     // element offset of the leg's first checkpoint in cp_p
+    int nck;         // checkpoints of the leg (0: nothing to do)
+};
+
+__device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, const int i, double dl, TrRec *defer)
 {
     const int e = i / P.W, w = i - e * P.W;
     const int idx = e * P.S + s;
@@ -259,15 +266,20 @@ __device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, con
     const long long tp = flip ? P.tpos[li] : (long long)1 << 62;  // global index right after the tie step
     int nck = P.nchunks - w * P.Lc;
     nck = nck > P.Lc ? P.Lc : nck;
-    double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-    // (eight independent read-modify-writes in flight: a plain loop waits for every load)
-    for (int c0 = 0; c0 < nck; c0 += 8) {
-        double v[8];
+    const size_t base = (size_t)idx * P.CP1 + (size_t)w * P.Lc;
+    double *cpp = P.cp_p + base;
+    if (defer) {
+        defer->dl = dl; defer->dl2 = dl2; defer->tp = tp; defer->A = A; defer->base = base; defer->nck = nck;
+    } else {
+        // (eight independent read-modify-writes in flight: a plain loop waits for every load)
+        for (int c0 = 0; c0 < nck; c0 += 8) {
+            double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = c0 + k < nck ? cpp[c0 + k] : 0.0;
+            for (int k = 0; k < 8; ++k) v[k] = c0 + k < nck ? cpp[c0 + k] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (c0 + k < nck) cpp[c0 + k] = v[k] + ((A + (long long)(c0 + k) * P.R >= tp) ? dl2 : dl);
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < nck) cpp[c0 + k] = v[k] + ((A + (long long)(c0 + k) * P.R >= tp) ? dl2 : dl);
+        }
     }
     if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
     P.pend[li] += dl2;
@@ -517,7 +529,8 @@ __device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
 // translate_leg) or marked for another walk.  (Round 2 left the translations to the next walker pass: one more kernel and
 // a skipped stitch behind it in the chain k_synth waits for.)
 __device__ __forceinline__ void stitch_apply_leg(const DevPlan &P, const int s, const int i, const LegRec &L, const LegOp &o,
-                                                 const int allok, const double nr, int &unver, int &rewalk, int &shifts)
+                                                 const int allok, const double nr, int &unver, int &rewalk, int &shifts,
+                                                 TrRec *defer = nullptr)
 {
     const size_t li = (size_t)s * P.LEGS + i;
     if (allok) {
@@ -534,7 +547,7 @@ __device__ __forceinline__ void stitch_apply_leg(const DevPlan &P, const int s, 
         P.anc_r[li] = nr;
         P.dirty[li] = tr ? 0 : 1;
         if (tr) {
-            translate_leg(P, s, i, dl);
+            translate_leg(P, s, i, dl, defer);
             ++shifts;
         }
         rewalk += tr ? 0 : 1;
@@ -1064,6 +1077,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
     int allok = pfv ? pv : 0;  // nothing is verified before the first root
     double D = pm.isconst ? pm.K : pm.c[0];  // the prefix map applied to D = 0
     int unver = 0, rewalk = 0, shifts = 0;
+    TrRec tr = {0.0, 0.0, 0, 0, 0, 0};
     for (int i = i0; i < i1; ++i) {
         const LegRec L = leg_load(P, s, i, start0);
         const LegOp o = leg_op(P, s, L, lc);
@@ -1079,11 +1093,39 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
         allok &= o.link_ok ? 1 : 0;
         const double nr = o.base + D;
         D = leg_d_out(o, D);
-        stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts);
+        stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts, &tr);
     }
     if (unver) atomicAdd(&s_unver, unver);
     if (rewalk) atomicAdd(&s_rewalk, rewalk);
     if (shifts) atomicAdd(&s_shifts, shifts);
+    // The checkpoint shifts of the block's translated legs, done by the whole block: thread t takes checkpoint t % 32 (+ 32,
+    // + 64 ...) of leg t / 32 (+ 8, + 16 ...), so a wave touches two runs of 256 contiguous bytes per access instead of 64
+    // cache lines (one leg per lane, as the walker kernel did it in round 2: 16x the traffic, 77 us of the chain)
+    static_assert(SCANM_K == 1, "the cooperative translation below assumes one leg per thread");
+    __shared__ double s_dl[SCANM_THREADS], s_dl2[SCANM_THREADS];
+    __shared__ long long s_tp[SCANM_THREADS], s_A[SCANM_THREADS];
+    __shared__ size_t s_base[SCANM_THREADS];
+    __shared__ int s_nck[SCANM_THREADS];
+    s_dl[t] = tr.dl; s_dl2[t] = tr.dl2; s_tp[t] = tr.tp; s_A[t] = tr.A; s_base[t] = tr.base; s_nck[t] = tr.nck;
+    __syncthreads();
+    for (int c0 = 0; c0 < P.Lc; c0 += 32) {
+        const int c = c0 + (t & 31);
+        for (int l0 = 0; l0 < SCANM_THREADS; l0 += 64) {  // 8 legs per step, 8 steps in flight
+            double v[8];
+            bool on[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int leg = l0 + 8 * k + (t >> 5);
+                on[k] = c < s_nck[leg];
+                v[k] = on[k] ? P.cp_p[s_base[leg] + c] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int leg = l0 + 8 * k + (t >> 5);
+                if (on[k]) P.cp_p[s_base[leg] + c] = v[k] + ((s_A[leg] + (long long)c * P.R >= s_tp[leg]) ? s_dl2[leg] : s_dl[leg]);
+            }
+        }
+    }
     __syncthreads();
     stitch_publish(P, t, (int)(gridDim.x * gridDim.y), s_unver, s_rewalk, s_shifts, &s_last);
 }

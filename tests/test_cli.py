@@ -85,8 +85,10 @@ def test_cli_realtime_pacing_and_live_position(tmp_path):
     assert wall >= 2.7  # 29 epochs of 0.1 s, paced
     a = np.fromfile(str(static), dtype=np.int16).reshape(29, -1)
     b = np.fromfile(str(live), dtype=np.int16).reshape(29, -1)
-    same = [bool(np.array_equal(a[e], b[e])) for e in range(29)]
-    assert all(same[:8]) and not any(same[-5:]), same
+    same = "".join("=" if np.array_equal(a[e], b[e]) else "x" for e in range(29))
+    assert "Location Update" in r.stderr, r.stderr[-400:]
+    # (the datagram leaves 1.5 s after the process was started; how much of that is start-up varies with the box)
+    assert same.startswith("=====") and same.endswith("xxxxx") and "x=" not in same, same
 
 
 @pytest.mark.gpu
