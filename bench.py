@@ -386,6 +386,14 @@ def main():
     elapsed, total_samples, chk = pkg.shard.reduce_report(dist, "cuda" if backend == "nccl" else "cpu", elapsed,
                                                           samples_per_step * args.steps, chk)
     value = total_samples / elapsed / 1e6
+    # per-rank detail (N > 1): the epoch range, the walker and kernel time of this rank's steps and the carrier legs it walked --
+    # in the strong split (--shard scenario) a rank walks the prefix [0, end of its range) of the scenario, not the whole of it
+    per_rank = None
+    if dist is not None:
+        mine = {"rank": rank, "epochs": [int(e_first), int(e_first + e_count)], "avg_walk_ms": round(ms_walk / args.steps, 4),
+                "avg_kernel_ms": round(ms_synth / args.steps, 4), "legs_walked": int(engines[0].walk_counts()[0])}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         avg_synth_ms = ms_synth / args.steps
@@ -404,6 +412,7 @@ def main():
             "n_gpus": world,
             **({"rehearsal": "all %d ranks on GPU %d, backend %s: launch-path check, NOT a scaling measurement" % (
                 world, local_rank, backend)} if os.environ.get("GAL_BENCH_DEVICE") and world > 1 else {}),
+            **({"ranks": per_rank} if per_rank else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),

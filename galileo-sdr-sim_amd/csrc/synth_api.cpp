@@ -34,6 +34,8 @@ static double rw_threshold_gap(double s)
     return g;
 }
 static constexpr double kRwMinGap = 1.0 / 128.0 + 4e-6;
+// the CBOC mode keeps two bin tables per channel (chip holds, BOC(6,1) half-period parity) of 64 bins each
+static constexpr double kRwMinGapCboc = 1.0 / 64.0 + 4e-6;
 #ifdef GAL_TEST_HOOKS
 // tests/test_walker_cpu.py checks the gate against an independent evaluation (no device needed)
 extern "C" double gal_hooks_rw_threshold_gap(double s) { return rw_threshold_gap(s); }
@@ -355,6 +357,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                       // (<= 0.266); one form per batch
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); }
     const double delt = 1.0 / h->cfg.sample_rate;
+    const bool cboc = (h->cfg.flags & GAL_CFG_CBOC) != 0;
     for (int e = 0; e < E; ++e) {
         int n = 0;
         for (int s = 0; s < S; ++s) {
@@ -395,8 +398,10 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 if (rw_ok && cs2 != h->rw_s0[s]) {
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
+                    // CBOC: the half-period parity pattern steps by 6 s per sample; only the hold form (1) exists there
+                    if (cboc) h->rw_g0[s] = mode == 1 ? std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2)) : 0.0;
                 }
-                if (rw_ok) rw_ok = h->rw_g0[s] > kRwMinGap;
+                if (rw_ok) rw_ok = h->rw_g0[s] > (cboc ? kRwMinGapCboc : kRwMinGap);
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;
@@ -582,13 +587,13 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
-    P.rw = (rw_ok && P.signal == 0) ? rw_mode : 0;
+    P.rw = rw_ok ? rw_mode : 0;  // (CBOC: form 1 only -- the gate above leaves rw_ok false for the others)
 #ifdef GAL_TEST_HOOKS
     // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)
     if (const char *env = getenv("GAL_SYNTH_RW")) {
         const int v = atoi(env);
-        P.rw = v == 0 ? 0 : (v >= 11 && v <= 13) ? (P.signal == 0 ? v - 10 : 0) : P.rw;
+        P.rw = v == 0 ? 0 : (v >= 11 && v <= 13) ? (P.signal == 0 || v == 11 ? v - 10 : 0) : P.rw;
     }
 #endif
 

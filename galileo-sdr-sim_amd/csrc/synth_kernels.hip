@@ -34,10 +34,10 @@
 
 using namespace galnco;
 
-// The file is compiled as six translation units, side by side (Makefile: -DGAL_TU=0..5), because the instantiations of
+// The file is compiled as seven translation units, side by side (Makefile: -DGAL_TU=0..6), because the instantiations of
 // k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
 // GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
-// by both libraries; TU 5 the family (0, 3).  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
+// by both libraries; TU 5 the family (0, 3), TU 6 (1, 1): CBOC on resampled windows.  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
 #if !defined(GAL_TU)
 #define GAL_TU_WALK 1
 #define GAL_TU_SYNTH 1
@@ -1230,6 +1230,8 @@ __global__ __launch_bounds__(GUESS_THREADS) void k_pages(DevPlan P)
 #define STR_PITCH 513  // LDS words per channel: one pad word (= word 0) so that "the next word" never wraps
 #define RW_BINS 128        // bins of the group-start fraction (k_synth<.., RW = 1>)
 #define RW_BIN_PITCH 130   // 129 entries used: a fraction that rounds to 1.0f lands in the (undecidable) entry 128
+#define CB_BINS 64         // the same for the CBOC mode, which keeps TWO bin tables per channel (chip holds, BOC(6,1) parity)
+#define CB_BIN_PITCH 66
 #define RW_EDGE 9.5367431640625e-07f    // 2^-20: a threshold this close outside a bin is registered in the bin as well
 #define RW_DELTA 2.384185791015625e-07f  // 2^-22: a fraction this close to its threshold is not decided by the table
 #ifndef SYN_WAVES
@@ -1347,18 +1349,36 @@ struct RwTmp {  // one channel's group-start temporaries between the phases belo
     uint2 be;
     uint32_t lo, hi;
     uint4 M;
+    // CBOC only: the BOC(6,1) half-period parity pattern of the group
+    float f6;
+    uint2 be6;
+    uint32_t p6;  // bit 2u+1: parity of the half-period index of sample u relative to sample 0's ... plus that one (phase B)
+    int i12;
 };
 
 // The group start in three phases, each run for the four channels of a part before the next one starts, so that the
 // part waits ONCE for each round of LDS reads instead of once per channel: (A) addresses, bin entry + stream words in
 // flight; (B) threshold compare, pattern masks in flight, signed window; (C) the spread.
-template <int J>
+template <int J, int BINS = RW_BINS, int PITCH = RW_BIN_PITCH>
 __device__ __forceinline__ void rw_phase_a(const ChanState &c, RwTmp &t, const uint2 *s_bin)
 {
     t.ic0 = (int)c.y;  // y < 8184 - 16*cs2: no wrap before the group ends
     t.f = (float)__builtin_amdgcn_fract(c.y);
-    const int bi = (int)(t.f * (float)RW_BINS);
-    t.be = s_bin[J * RW_BIN_PITCH + bi];
+    const int bi = (int)(t.f * (float)BINS);
+    t.be = s_bin[J * PITCH + bi];
+}
+
+// CBOC: sample u's BOC(6,1) half period is (int)(6 y_u) = i12_0 + floor(f6 + u 6s), f6 = frac(6 y_0): its PARITY over the
+// 16 samples depends on f6 only through the 15 thresholds 1 - frac(u 6s) -- the same look-up as for the chip holds, on
+// a second pair of tables (s_bin6, s_pat6).  6 y is formed the way the per-sample step forms it (one rounded product).
+template <int J>
+__device__ __forceinline__ void rw_phase_a6(const ChanState &c, RwTmp &t, const uint2 *s_bin6)
+{
+    const double y6 = 6.0 * c.y;
+    t.i12 = (int)y6;
+    t.f6 = (float)__builtin_amdgcn_fract(y6);
+    const int bi = (int)(t.f6 * (float)CB_BINS);
+    t.be6 = s_bin6[J * CB_BIN_PITCH + bi];
 }
 
 template <int J>
@@ -1375,6 +1395,15 @@ __device__ __forceinline__ bool rw_phase_b(RwTmp &t, const uint32_t str0, const 
     t.lo = ((lds_u32_ptr)(uintptr_t)wa)[0];
     t.hi = ((lds_u32_ptr)(uintptr_t)wa)[1];
     return !(__builtin_fabsf(t.f - thr) >= RW_DELTA);  // too close to call (a NaN threshold = undecidable bin)
+}
+
+template <int J>
+__device__ __forceinline__ bool rw_phase_b6(RwTmp &t, const uint32_t *s_pat6)
+{
+    const float thr = __uint_as_float(t.be6.x);
+    const uint32_t po = t.be6.y + (t.f6 >= thr ? 4u : 0u);  // be6.y = 4 x (thresholds below the bin): byte offset of the word
+    t.p6 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_pat6 + J * 16) + po);
+    return !(__builtin_fabsf(t.f6 - thr) >= RW_DELTA);
 }
 
 // all 16 fields = field d of w (a two's-complement 2-bit value 00 / 01 / 11)
@@ -1411,6 +1440,30 @@ __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &
         x = gal_bfi(t.M.w, x << 2, x);
     }
     return x;
+}
+
+// CBOC group start, phase C: from the raw window (fields (B != C, sign of C x secondary) per half chip, symbol signs
+// applied) to the two words the samples read -- XA: field u = the (B - C) term's factor of sample u, 0 / +1 / -1 as a
+// two's-complement 2-bit value (what the BOC(1,1) path calls the signed window); XB: the same for the (B + C) term, whose
+// sign is that of C x secondary x BOC(1,1) sub-carrier x BOC(6,1) sub-carrier, i.e. bit 1 ^ 1 ^ parity(half chip) ^
+// parity(half period) (chan_step_cboc).  The half chip of sample u is ic0 + u - (holds before u): its parity comes out of
+// the hold masks; the half-period parity out of the second pattern table (rw_phase_a6 / b6).
+__device__ __forceinline__ void rw_phase_c_cboc(const ChanState &c, const RwTmp &t, uint32_t &xa, uint32_t &xb)
+{
+    const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
+    uint32_t x = __builtin_amdgcn_alignbit(t.hi, t.lo, (uint32_t)t.ic0 << 1) ^ mask;
+    x = gal_bfi(t.M.x, x << 2, x);
+    x = gal_bfi(t.M.y, x << 2, x);
+    x = gal_bfi(t.M.z, x << 2, x);
+    x = gal_bfi(t.M.w, x << 2, x);  // field u = (nz, s1) of SAMPLE u
+    xa = window_signed(x);
+    // bit 2u+1 of hp: (holds before u) & 1; of 0x88888888: u & 1; so the half chip's parity is their XOR with ic0's
+    const uint32_t hp = (t.M.x ^ t.M.y ^ t.M.z ^ t.M.w) & 0xAAAAAAAAu;
+    const uint32_t base = ((uint32_t)(t.ic0 ^ t.i12) & 1u) ? 0xAAAAAAAAu : 0u;
+    // sign bit of the (B + C) factor: s1 ^ 1 ^ parity(half chip) ^ parity(half period); 0xAAAAAAAA ^ 0x88888888 = 0x22222222
+    const uint32_t sb = x ^ 0x22222222u ^ hp ^ t.p6 ^ base;
+    const uint32_t lo = ~x & 0x55555555u;  // B == C: this term is the one that is non-zero
+    xb = lo | (sb & (lo << 1));
 }
 
 template <int J>
@@ -1513,6 +1566,23 @@ __device__ __forceinline__ void chan_step_rw(ChanState &c, const uint32_t X, con
     c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));
 }
 
+// one sample of one channel in a resampled CBOC group: both factors from constant fields, one 8-byte table entry (TA[k],
+// TB[k]), two packed multiply-adds (exactly one of the factors is non-zero); carrier as in chan_step_fast
+__device__ __forceinline__ void chan_step_rw_cboc(ChanState &c, const uint32_t XA, const uint32_t XB, const int U, const double ds,
+                                                  const uint32_t lutb, int &acc)
+{
+    const int va = __builtin_amdgcn_sbfe((int)XA, (uint32_t)(2 * U), 2);
+    const int vb = __builtin_amdgcn_sbfe((int)XB, (uint32_t)(2 * U), 2);
+    const int k = (int)(511.0 * c.p);
+    uint32_t a;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(a) : "v"(k), "s"(lutb));
+    typedef int gal_i2 __attribute__((ext_vector_type(2)));
+    const gal_i2 tt = *(const __attribute__((address_space(3))) gal_i2 *)(uintptr_t)a;  // ds_read_b64
+    gal_acc(acc, tt.x, va);
+    gal_acc(acc, tt.y, vb);
+    c.p = __builtin_amdgcn_fract(c.p + __builtin_fabs(ds));
+}
+
 // The same with the symbol advance of :491-507: x -= 4092 when x >= 4092 (subtracting +0.0 otherwise is exact);
 // the symbol counter is advanced in the group epilogue.
 __device__ __forceinline__ void chan_step_wrap(ChanState &c, ChanGroup &g, const double cs2, const double ds,
@@ -1541,7 +1611,9 @@ __device__ __forceinline__ void group_end(ChanState &c, const ChanGroup &g, cons
 // (GAL_CFG_CBOC) carries the definition, the test suite's CPU checker restates it.  One plain per-sample loop, no windows:
 // about 3.5x the instructions of the BOC(1,1) path.  lutb: LDS byte address of entry k = 0 of the channel's A table
 // (plain or conjugate); the B tables follow 8 KB later.
-template <int J>
+// LAY = 1 (the resampled-window build of the mode): one 512-entry table of 8-byte entries (TA[k], TB[k]) per Doppler
+// sign, indexed with k & 511 (plain: LUT[k & 511]; conjugate: entry j holds LUT[-j & 511], and (k & 511) = k mod 512).
+template <int J, int LAY = 0>
 __device__ __forceinline__ void chan_step_cboc(ChanState &c, const double cs2, const double ds, const uint32_t lutb,
                                                const uint32_t str0, const DevPlan *Pd, const int idx, int &acc)
 {
@@ -1558,7 +1630,7 @@ __device__ __forceinline__ void chan_step_cboc(ChanState &c, const double cs2, c
     const uint32_t nz = f & 1u;  // B != C: the (B - C) term, else the (B + C) term
     const uint32_t sign = nz ? (f >> 1) : ((f >> 1) ^ 1u ^ ((uint32_t)(h ^ i12) & 1u));
     const int k = (int)(511.0 * c.p);
-    const uint32_t a = lutb + (nz ? 0u : 8192u) + (uint32_t)(k << 2);
+    const uint32_t a = LAY == 1 ? lutb + (nz ? 0u : 4u) + (((uint32_t)k & 511u) << 3) : lutb + (nz ? 0u : 8192u) + (uint32_t)(k << 2);
     const int t = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
     gal_acc(acc, t, sign ? -1 : 1);
     c.y = c.y + cs2;
@@ -1615,12 +1687,18 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
     __shared__ uint32_t s_str[NCH * STR_PITCH];
     // entry k + 512 of table 0: LUT[k & 511], of table 1: LUT[-k & 511]; CBOC: the same pair for TA, then for TB
-    constexpr int LUT_TABLES = SIG == 1 ? 4 : 2;
-    __shared__ int s_lut[LUT_TABLES * 1024];
+    constexpr bool CBRW = SIG == 1 && RW != 0;  // CBOC on resampled windows: 8-byte (TA, TB) entries, k >= 0 tables only
+    constexpr int LUT_TABLES = CBRW ? 1 : SIG == 1 ? 4 : 2;
+    __shared__ int s_lut[LUT_TABLES * 1024 * (CBRW ? 2 : 1)];
     // RW: per channel the hold patterns of a 16-sample group (see rw_phase_a)
-    __shared__ uint2 s_bin[RW ? NCH * RW_BIN_PITCH : 1];
+    constexpr int BINS = CBRW ? CB_BINS : RW_BINS, BPITCH = CBRW ? CB_BIN_PITCH : RW_BIN_PITCH;
+    __shared__ uint2 s_bin[RW ? NCH * BPITCH : 1];
     __shared__ uint4 s_pat[RW ? NCH * 16 : 1];
     __shared__ float s_thr[RW ? NCH * 16 : 1];
+    // CBOC: the same for the BOC(6,1) half-period parity (rw_phase_a6)
+    __shared__ uint2 s_bin6[CBRW ? NCH * CB_BIN_PITCH : 1];
+    __shared__ uint32_t s_pat6[CBRW ? NCH * 16 : 1];
+    __shared__ float s_thr6[CBRW ? NCH * 16 : 1];
     __shared__ double s_tie[GAL_MAX_NCH];
     __shared__ int s_rwbad;  // RW: a channel's group has more holds / advances than the pattern masks hold (the host's
                              // gate excludes it; if it happens all the same, every group of the block runs the slow body)
@@ -1657,7 +1735,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // ---- phase 1: LDS tables.  Per thread 2 stream words per channel + 8 LUT entries, all loads first, then the stores
     {
         uint32_t w0[NCH], w1[NCH];
-        int lv[LUT_TABLES * 1024 / SYN_BLOCK];
+        constexpr int LUT_PER_THREAD = (int)(sizeof(s_lut) / sizeof(int)) / SYN_BLOCK;
+        int lv[LUT_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             int prn = p_prn[ixs[j]];
@@ -1667,10 +1746,15 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             w1[j] = src[tid + SYN_BLOCK];
         }
 #pragma unroll
-        for (int q = 0; q < LUT_TABLES * 1024 / SYN_BLOCK; ++q) {
+        for (int q = 0; q < LUT_PER_THREAD; ++q) {
             const int i = tid + q * SYN_BLOCK;
-            const int k = (i & 1023) - 512;
-            lv[q] = p_lut[((i >> 11) << 9) + ((((i >> 10) & 1) ? -k : k) & 511)];
+            if constexpr (CBRW) {  // int i = (table (plain / conjugate) x 512 + k) x 2 + (0: TA, 1: TB)
+                const int k = (i >> 1) & 511;
+                lv[q] = p_lut[((i & 1) << 9) + (((i >> 10) ? -k : k) & 511)];
+            } else {
+                const int k = (i & 1023) - 512;
+                lv[q] = p_lut[((i >> 11) << 9) + ((((i >> 10) & 1) ? -k : k) & 511)];
+            }
         }
         // idle positions (epochs with fewer than NCH active channels) run the same branch-free group code on an
         // all-zero state and an all-zero stream: window 0 -> every field 0 -> no contribution; steps 0 keep the state
@@ -1683,7 +1767,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             if (tid == 0) s_str[j * STR_PITCH + STR_WORDS] = on ? w0[j] : 0u;  // pad word = word 0
         }
 #pragma unroll
-        for (int q = 0; q < LUT_TABLES * 1024 / SYN_BLOCK; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
+        for (int q = 0; q < LUT_PER_THREAD; ++q) s_lut[tid + q * SYN_BLOCK] = lv[q];
     }
     [[maybe_unused]] double rw_s[NCH];  // RW: the channels' code steps in half chips (wave-uniform)
     if constexpr (RW) {
@@ -1728,14 +1812,30 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 }
                 s_tie[j] = tl;
             }
+            if constexpr (CBRW) {  // the same ranking for the BOC(6,1) half periods: step 6 s per sample
+                const double s6 = 6.0 * s;
+                if (u <= 15) {
+                    const double us = (double)u * s6;
+                    const double T = 1.0 - (us - __builtin_floor(us));
+                    int rank = 0;
+                    for (int v = 1; v <= 15; ++v) {
+                        const double vs = (double)v * s6;
+                        const double Tv = 1.0 - (vs - __builtin_floor(vs));
+                        rank += (Tv < T) || (Tv == T && v < u);
+                    }
+                    s_thr6[j * 16 + rank] = (float)T;
+                } else {
+                    s_thr6[j * 16 + 15] = 2.0f;
+                }
+            }
         }
     }
     __syncthreads();
     if constexpr (RW) {
         // ---- step B: the bin tables (NCH x 129 entries over all threads) and the 16 patterns of each channel
-        for (int t = tid; t < NCH * (RW_BINS + 1); t += SYN_BLOCK) {
-            const int j = t / (RW_BINS + 1), b = t - j * (RW_BINS + 1);
-            const float lo = (float)b * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / RW_BINS) + RW_EDGE;
+        for (int t = tid; t < NCH * (BINS + 1); t += SYN_BLOCK) {
+            const int j = t / (BINS + 1), b = t - j * (BINS + 1);
+            const float lo = (float)b * (1.0f / BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / BINS) + RW_EDGE;
             int cnt = 0, idb = 0;
             float thr = 4.0f;  // "no threshold near this bin": never reached, never close
             for (int i = 0; i < 15; ++i) {
@@ -1745,9 +1845,41 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 cnt += in;
                 thr = in ? th : thr;
             }
-            if (cnt >= 2 || b == RW_BINS) thr = __builtin_nanf("");  // undecidable here: the group runs the slow body
+            if (cnt >= 2 || b == BINS) thr = __builtin_nanf("");  // undecidable here: the group runs the slow body
             if (j >= nact) { thr = 4.0f; idb = 0; }
-            s_bin[j * RW_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
+            s_bin[j * BPITCH + b] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
+        }
+        if constexpr (CBRW) {
+            for (int t = tid; t < NCH * (CB_BINS + 1); t += SYN_BLOCK) {
+                const int j = t / (CB_BINS + 1), b = t - j * (CB_BINS + 1);
+                const float lo = (float)b * (1.0f / CB_BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / CB_BINS) + RW_EDGE;
+                int cnt = 0, idb = 0;
+                float thr = 4.0f;
+                for (int i = 0; i < 15; ++i) {
+                    const float th = s_thr6[j * 16 + i];
+                    idb += th < lo;
+                    const bool in = th >= lo && th < hi;
+                    cnt += in;
+                    thr = in ? th : thr;
+                }
+                if (cnt >= 2 || b == CB_BINS) thr = __builtin_nanf("");
+                if (j >= nact) { thr = 4.0f; idb = 0; }
+                s_bin6[j * CB_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 4u);
+            }
+            if (tid < NCH * 16) {
+                // pattern `id` (id thresholds <= f6): bit 2u+1 = parity of floor(f6 + u 6s), the number of half periods
+                // sample u lies beyond sample 0's
+                const int j = tid >> 4, id = tid & 15;
+                const double s6 = 6.0 * rw_step_of(j);
+                const double Tlo = id ? (double)s_thr6[j * 16 + id - 1] : 0.0;
+                double Thi = (double)s_thr6[j * 16 + id];
+                Thi = Thi > 1.0 ? 1.0 : Thi;
+                const double f = 0.5 * (Tlo + Thi);
+                uint32_t w = 0u;
+                for (int u = 1; u <= 15; ++u)
+                    if ((long long)__builtin_floor(f + (double)u * s6) & 1LL) w |= 2u << (2 * u);
+                s_pat6[tid] = j < nact ? w : 0u;
+            }
         }
         if (tid < NCH * 16) {
             const int j = tid >> 4, id = tid & 15;  // id = number of thresholds <= f
@@ -1853,7 +1985,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // LDS byte address of s_lut[512] (entry k = 0 of the plain table), wave-uniform
     typedef const __attribute__((address_space(3))) int *lds_int_ptr;
     // (cast first, offset second: the generic-pointer offset in between is not always folded away by the compiler)
-    const uint32_t lut0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)s_lut + 512u * 4u);
+    // (CBOC on resampled windows: 512-entry tables of 8-byte entries, entry k = 0 first)
+    const uint32_t lut0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)s_lut + (CBRW ? 0u : 512u * 4u));
     uint32_t *out = iq + (size_t)er * G.N + n0;  // iq holds the executed range only
     // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
     // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
@@ -1948,7 +2081,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                                     else chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); }
 // CBOC slow groups: the per-sample step that tests the wrap and reads the stream itself (idle positions skipped: a CBOC
 // channel never contributes zero)
-#define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j>(ch##j, cs##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
+#define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j, CBRW ? 1 : 0>(ch##j, cs##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
 #define GAL_STEP_S(j) if (j < NCH) chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
 #define GAL_END(j) if (j < NCH) group_end(ch##j, gr##j, Pd, ix##j);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
@@ -1960,10 +2093,13 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // dependency chains give the scheduler enough ILP to cover FP64 and LDS latency, while only four channels'
 // group temporaries are live at once.  sched_barrier keeps the parts apart.  `near` is wave-uniform after the
 // ballot: no lane of the wave has any of the four codes within 16 samples of its wrap -> fast body.
-#define GAL_RW_A(j) if (j < NCH) rw_phase_a<j>(ch##j, rt##j, s_bin);
-#define GAL_RW_B(j) if (j < NCH) unsafe##j = rw_phase_b<j>(rt##j, str0, s_pat);
-#define GAL_RW_C(j) if (j < NCH) gx##j = rw_phase_c<RW>(ch##j, rt##j);
-#define GAL_STEP_R(j) if (j < NCH) chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc);
+#define GAL_RW_A(j) if (j < NCH) { rw_phase_a<j, BINS, BPITCH>(ch##j, rt##j, s_bin); if constexpr (CBRW) rw_phase_a6<j>(ch##j, rt##j, s_bin6); }
+#define GAL_RW_B(j) if (j < NCH) { unsafe##j = rw_phase_b<j>(rt##j, str0, s_pat); if constexpr (CBRW) unsafe##j |= rw_phase_b6<j>(rt##j, s_pat6); }
+/* CBOC: an idle position (all-zero stream row) has B == C everywhere, so its (B + C) word is cleared by hand */
+#define GAL_RW_C(j) if (j < NCH) { if constexpr (CBRW) { rw_phase_c_cboc(ch##j, rt##j, gx##j, gxb##j); gxb##j = j < nact ? gxb##j : 0u; } \
+                                   else gx##j = rw_phase_c<RW>(ch##j, rt##j); }
+#define GAL_STEP_R(j) if (j < NCH) { if constexpr (CBRW) chan_step_rw_cboc(ch##j, gx##j, gxb##j, u, ds##j, sg4##j, acc); \
+                                     else chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc); }
 #define GAL_PIN_R(a, b, c, d) asm volatile("" : "+v"(acc), "+v"(ch##a.p), "+v"(ch##b.p), "+v"(ch##c.p), "+v"(ch##d.p));
 // RW: the code NCO over the 16 samples of a fast group in three instructions.  Within a binade (and outside the tie
 // binade, which GAL_ROOM keeps away) every sequential step adds the same S = RN_q(cs2) = fl(y + cs2) - y, and y + 16 S
@@ -1991,6 +2127,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         bool fast = __builtin_amdgcn_ballot_w64(near) == 0;                      \
         if constexpr (RW != 0) {                                                 \
             [[maybe_unused]] uint32_t gx##a = 0u, gx##b = 0u, gx##c = 0u, gx##d = 0u; \
+            [[maybe_unused]] uint32_t gxb##a = 0u, gxb##b = 0u, gxb##c = 0u, gxb##d = 0u; \
             [[maybe_unused]] RwTmp rt##a = {}, rt##b = {}, rt##c = {}, rt##d = {}; \
             if (fast) {                                                          \
                 [[maybe_unused]] bool unsafe##a = false, unsafe##b = false, unsafe##c = false, unsafe##d = false; \
@@ -2308,6 +2445,9 @@ GAL_FAMILY(4, 1, 0)
 #if GAL_TU_FAMILY(5)
 GAL_FAMILY(5, 0, 3)
 #endif
+#if GAL_TU_FAMILY(6)
+GAL_FAMILY(6, 1, 1)
+#endif
 #undef GAL_FAMILY
 #endif  // GAL_TU_SYNTH
 
@@ -2316,7 +2456,7 @@ GAL_FAMILY(5, 0, 3)
     extern "C" void galk_warm_f##K(hipStream_t st);                                                                  \
     extern "C" int galk_launch_synth_f##K(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate,               \
                                           const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st);
-GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_FAMILY_DECL(5)
+GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_FAMILY_DECL(5) GAL_FAMILY_DECL(6)
 #undef GAL_FAMILY_DECL
 
 __global__ void k_warm() {}
@@ -2328,12 +2468,15 @@ extern "C" void galk_warm(hipStream_t st)
     galk_warm_f3(st);
     galk_warm_f4(st);
     galk_warm_f5(st);
+    galk_warm_f6(st);
 }
 
 extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
                                  const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st)
 {
-    if (P->signal == 1) return galk_launch_synth_f4(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->signal == 1)
+        return P->rw == 1 ? galk_launch_synth_f6(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st)
+                          : galk_launch_synth_f4(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
     if (P->rw == 1) return galk_launch_synth_f2(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
     if (P->rw == 2) return galk_launch_synth_f3(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
     if (P->rw == 3) return galk_launch_synth_f5(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);

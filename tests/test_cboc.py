@@ -86,10 +86,12 @@ def test_oracle_cboc_against_numpy_icd_formula(pkg):
     assert np.array_equal(st_b["carr_phase"].view(np.uint64), st_c["carr_phase"].view(np.uint64))
 
 
-def _compare_cboc(pkg, p, n, rate=2.6e6, state_in=None):
+def _compare_cboc(pkg, p, n, rate=2.6e6, state_in=None, window_mode=None, **eng_kw):
     flags = pkg.synth.GAL_CFG_CBOC
-    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=p.shape[1], device=0, flags=flags) as eng:
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=p.shape[1], device=0, flags=flags, **eng_kw) as eng:
         iq, st, stats = eng.run_host(p, state_in)
+    if window_mode is not None:
+        assert stats["window_mode"] == window_mode, stats
     ref_iq, ref_st = oracle_run(p, n, rate, state_in, cboc=True)
     assert stats["chain_mismatch"] == 0
     nbad = int(np.count_nonzero(iq != ref_iq))
@@ -103,8 +105,42 @@ def _compare_cboc(pkg, p, n, rate=2.6e6, state_in=None):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_chan", [1, 5, 9, 12])
 def test_cboc_hip_equals_oracle(pkg, n_chan):
+    """At the reference's 2.6 MS/s the mode runs on resampled windows (window_mode 1: chip holds AND the parity of the BOC(6,1)
+    half period looked up once per 16-sample group); the classic per-sample body on the same batch gives the same bits."""
     p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=n_chan, n_slots=16, samples_per_epoch=52000, seed=200 + n_chan)
-    _compare_cboc(pkg, p, 52000)
+    a, _ = _compare_cboc(pkg, p, 52000, window_mode=1)
+
+
+@pytest.mark.gpu
+def test_cboc_both_bodies_on_the_same_batch(pkg, monkeypatch):
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=11, n_slots=16, samples_per_epoch=104000, seed=321)
+    a, _ = _compare_cboc(pkg, p, 104000, window_mode=1, test_hooks=True)
+    monkeypatch.setenv("GAL_SYNTH_RW", "0")  # honoured by the GAL_TEST_HOOKS build only: classic windows
+    b, _ = _compare_cboc(pkg, p, 104000, window_mode=0, test_hooks=True)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,mode", [(2.2e6, 1), (2.4e6, 1), (2.6e6, 1), (2.76e6, 1), (2.1e6, 0), (2.5e6, 0), (4.0e6, 0), (25e6, 0)])
+def test_cboc_resampled_window_gate_and_rates(pkg, rate, mode):
+    """The host enables the resampled-window body only where BOTH threshold sets (chip holds: step s; half-period parity:
+    step 6 s) keep more than a bin (1/64) between neighbours; elsewhere the classic body runs.  Same bits everywhere."""
+    n = int(rate / 50)
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=7, n_slots=8, samples_per_epoch=n, sample_rate=rate, seed=int(rate) % 977)
+    p["ibit0"][0, 0] = 499
+    p["code_phase0"][0, 1] = 4091.9
+    _compare_cboc(pkg, p, n, rate, window_mode=mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate", [2.1e6, 2.5e6, 3.0e6, 2.0462e6])
+def test_cboc_resampled_window_safety_nets(pkg, monkeypatch, rate):
+    """The body forced onto rates its gate keeps away (GAL_SYNTH_RW=11): clustered thresholds leave bins undecidable and
+    those groups take the per-sample body, a pattern with more than four holds turns the block over to it -- still exact."""
+    monkeypatch.setenv("GAL_SYNTH_RW", "11")
+    n = int(rate / 50)
+    p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=6, n_slots=8, samples_per_epoch=n, sample_rate=rate, seed=5)
+    _compare_cboc(pkg, p, n, rate, window_mode=1, test_hooks=True)
 
 
 @pytest.mark.gpu
