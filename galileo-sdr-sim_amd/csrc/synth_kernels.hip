@@ -1352,8 +1352,10 @@ struct RwTmp {  // one channel's group-start temporaries between the phases belo
     // CBOC only: the BOC(6,1) half-period parity pattern of the group
     float f6;
     uint2 be6;
-    uint32_t p6;  // bit 2u+1: parity of the half-period index of sample u relative to sample 0's ... plus that one (phase B)
+    uint32_t p6;  // bit 2u+1: parity of the half-period index of sample u
     int i12;
+    uint32_t x, hw;  // the spread window (fields (B != C, sign bit) of SAMPLE u) and the sign correction that does not
+                     // depend on the half period: 1 ^ parity of sample u's half chip, at bit 2u+1
 };
 
 // The group start in three phases, each run for the four channels of a part before the next one starts, so that the
@@ -1402,7 +1404,9 @@ __device__ __forceinline__ bool rw_phase_b6(RwTmp &t, const uint32_t *s_pat6)
 {
     const float thr = __uint_as_float(t.be6.x);
     const uint32_t po = t.be6.y + (t.f6 >= thr ? 4u : 0u);  // be6.y = 4 x (thresholds below the bin): byte offset of the word
-    t.p6 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_pat6 + J * 16) + po);
+    // (pattern: parity relative to sample 0's half period, whose own parity is added here)
+    t.p6 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_pat6 + J * 16) + po) ^
+           (((uint32_t)t.i12 & 1u) ? 0xAAAAAAAAu : 0u);
     return !(__builtin_fabsf(t.f6 - thr) >= RW_DELTA);
 }
 
@@ -1442,27 +1446,33 @@ __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &
     return x;
 }
 
-// CBOC group start, phase C: from the raw window (fields (B != C, sign of C x secondary) per half chip, symbol signs
-// applied) to the two words the samples read -- XA: field u = the (B - C) term's factor of sample u, 0 / +1 / -1 as a
-// two's-complement 2-bit value (what the BOC(1,1) path calls the signed window); XB: the same for the (B + C) term, whose
-// sign is that of C x secondary x BOC(1,1) sub-carrier x BOC(6,1) sub-carrier, i.e. bit 1 ^ 1 ^ parity(half chip) ^
-// parity(half period) (chan_step_cboc).  The half chip of sample u is ic0 + u - (holds before u): its parity comes out of
-// the hold masks; the half-period parity out of the second pattern table (rw_phase_a6 / b6).
-__device__ __forceinline__ void rw_phase_c_cboc(const ChanState &c, const RwTmp &t, uint32_t &xa, uint32_t &xb)
+// CBOC group start after the chip-hold look-up.  (C1) the raw window -- fields (B != C, sign of C x secondary) per half
+// chip, symbol signs applied -- is spread like the BOC(1,1) one, so that field u belongs to SAMPLE u; the half chip of
+// sample u is ic0 + u - (holds before u), and its parity comes out of the hold masks.  Then the second look-up (rw_phase_a6 /
+// b6: parity of the BOC(6,1) half period) runs with only two words per channel still live, and (D) forms the two words the
+// samples read -- XA: field u = the (B - C) term's factor of sample u, 0 / +1 / -1 as a two's-complement 2-bit value (what
+// the BOC(1,1) path calls the signed window); XB: the same for the (B + C) term, whose sign is that of C x secondary x
+// BOC(1,1) sub-carrier x BOC(6,1) sub-carrier, i.e. bit 1 ^ 1 ^ parity(half chip) ^ parity(half period) (chan_step_cboc).
+__device__ __forceinline__ void rw_phase_c1_cboc(const ChanState &c, RwTmp &t)
 {
     const uint32_t mask = GAL_SIGN_MASK((c.st >> 10) & 3u);
     uint32_t x = __builtin_amdgcn_alignbit(t.hi, t.lo, (uint32_t)t.ic0 << 1) ^ mask;
     x = gal_bfi(t.M.x, x << 2, x);
     x = gal_bfi(t.M.y, x << 2, x);
     x = gal_bfi(t.M.z, x << 2, x);
-    x = gal_bfi(t.M.w, x << 2, x);  // field u = (nz, s1) of SAMPLE u
-    xa = window_signed(x);
-    // bit 2u+1 of hp: (holds before u) & 1; of 0x88888888: u & 1; so the half chip's parity is their XOR with ic0's
+    x = gal_bfi(t.M.w, x << 2, x);
+    t.x = x;
+    // bit 2u+1 of hp: (holds before u) & 1; of 0x88888888: u & 1; their XOR with ic0's parity is the half chip's parity, and
+    // 0xAAAAAAAA (the "^ 1") ^ 0x88888888 = 0x22222222
     const uint32_t hp = (t.M.x ^ t.M.y ^ t.M.z ^ t.M.w) & 0xAAAAAAAAu;
-    const uint32_t base = ((uint32_t)(t.ic0 ^ t.i12) & 1u) ? 0xAAAAAAAAu : 0u;
-    // sign bit of the (B + C) factor: s1 ^ 1 ^ parity(half chip) ^ parity(half period); 0xAAAAAAAA ^ 0x88888888 = 0x22222222
-    const uint32_t sb = x ^ 0x22222222u ^ hp ^ t.p6 ^ base;
-    const uint32_t lo = ~x & 0x55555555u;  // B == C: this term is the one that is non-zero
+    t.hw = hp ^ 0x22222222u ^ (((uint32_t)t.ic0 & 1u) ? 0xAAAAAAAAu : 0u);
+}
+
+__device__ __forceinline__ void rw_phase_d_cboc(const RwTmp &t, uint32_t &xa, uint32_t &xb)
+{
+    xa = window_signed(t.x);
+    const uint32_t sb = t.x ^ t.hw ^ t.p6;   // (odd bits: the sign of the (B + C) factor)
+    const uint32_t lo = ~t.x & 0x55555555u;  // B == C: this term is the one that is non-zero
     xb = lo | (sb & (lo << 1));
 }
 
@@ -1699,6 +1709,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     __shared__ uint2 s_bin6[CBRW ? NCH * CB_BIN_PITCH : 1];
     __shared__ uint32_t s_pat6[CBRW ? NCH * 16 : 1];
     __shared__ float s_thr6[CBRW ? NCH * 16 : 1];
+    // CBOC on resampled windows: the code steps (used once per 16-sample group) live here instead of in 24 VGPRs -- this
+    // instantiation needs two spread words per channel and 8-byte table reads, and spilled inside the group loop without
+    __shared__ double s_csl[CBRW ? GAL_MAX_NCH : 1];
     __shared__ double s_tie[GAL_MAX_NCH];
     __shared__ int s_rwbad;  // RW: a channel's group has more holds / advances than the pattern masks hold (the host's
                              // gate excludes it; if it happens all the same, every group of the block runs the slow body)
@@ -1785,6 +1798,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         // ---- hold patterns, step A: the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted: thread
         // (channel, u) ranks its own; thread (channel, 16) writes the sentinel and the tie binade of the code step
         if (tid == 0) s_rwbad = 0;
+        if constexpr (CBRW) {
+            if (tid < NCH) s_csl[tid] = rw_step_of(tid);
+        }
         if (tid < NCH * 16) {
             const int j = tid >> 4, u = (tid & 15) + 1;
             const double s = rw_step_of(j);
@@ -2081,7 +2097,10 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                                     else chan_step_fast(ch##j, gr##j, cs##j, ds##j, sg4##j, acc); }
 // CBOC slow groups: the per-sample step that tests the wrap and reads the stream itself (idle positions skipped: a CBOC
 // channel never contributes zero)
-#define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j, CBRW ? 1 : 0>(ch##j, cs##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
+/* the channel's code step: a register, or (CBOC on resampled windows) an LDS read */
+typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
+#define GAL_CS(j) (CBRW ? ((lds_vf64_ptr)s_csl)[(j) < GAL_MAX_NCH ? (j) : 0] : cs##j)
+#define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j, CBRW ? 1 : 0>(ch##j, csl##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
 #define GAL_STEP_S(j) if (j < NCH) chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
 #define GAL_END(j) if (j < NCH) group_end(ch##j, gr##j, Pd, ix##j);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
@@ -2093,10 +2112,14 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // dependency chains give the scheduler enough ILP to cover FP64 and LDS latency, while only four channels'
 // group temporaries are live at once.  sched_barrier keeps the parts apart.  `near` is wave-uniform after the
 // ballot: no lane of the wave has any of the four codes within 16 samples of its wrap -> fast body.
-#define GAL_RW_A(j) if (j < NCH) { rw_phase_a<j, BINS, BPITCH>(ch##j, rt##j, s_bin); if constexpr (CBRW) rw_phase_a6<j>(ch##j, rt##j, s_bin6); }
-#define GAL_RW_B(j) if (j < NCH) { unsafe##j = rw_phase_b<j>(rt##j, str0, s_pat); if constexpr (CBRW) unsafe##j |= rw_phase_b6<j>(rt##j, s_pat6); }
+#define GAL_RW_A(j) if (j < NCH) rw_phase_a<j, BINS, BPITCH>(ch##j, rt##j, s_bin);
+#define GAL_RW_B(j) if (j < NCH) unsafe##j = rw_phase_b<j>(rt##j, str0, s_pat);
+/* CBOC: spread first, then the half-period look-up (few temporaries live across it) */
+#define GAL_RW_C1(j) if (j < NCH) rw_phase_c1_cboc(ch##j, rt##j);
+#define GAL_RW_A6(j) if (j < NCH) rw_phase_a6<j>(ch##j, rt##j, s_bin6);
+#define GAL_RW_B6(j) if (j < NCH) unsafe##j = rw_phase_b6<j>(rt##j, s_pat6);
 /* CBOC: an idle position (all-zero stream row) has B == C everywhere, so its (B + C) word is cleared by hand */
-#define GAL_RW_C(j) if (j < NCH) { if constexpr (CBRW) { rw_phase_c_cboc(ch##j, rt##j, gx##j, gxb##j); gxb##j = j < nact ? gxb##j : 0u; } \
+#define GAL_RW_C(j) if (j < NCH) { if constexpr (CBRW) { rw_phase_d_cboc(rt##j, gx##j, gxb##j); gxb##j = j < nact ? gxb##j : 0u; } \
                                    else gx##j = rw_phase_c<RW>(ch##j, rt##j); }
 #define GAL_STEP_R(j) if (j < NCH) { if constexpr (CBRW) chan_step_rw_cboc(ch##j, gx##j, gxb##j, u, ds##j, sg4##j, acc); \
                                      else chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc); }
@@ -2109,12 +2132,13 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #define GAL_ADV(j)                                                                            \
     if (j < NCH) {                                                                            \
         const double y0 = ch##j.y;                                                            \
-        const double y1 = y0 + cs##j;                                                         \
+        const double cstep_ = GAL_CS(j);                                                      \
+        const double y1 = y0 + cstep_;                                                        \
         const double S = y1 - y0;                                                             \
         double y16 = __builtin_fma(S, 16.0, y0);                                              \
         if (__builtin_amdgcn_ballot_w64((GAL_HI(y16) ^ GAL_HI(y0)) > 0xfffffu) != 0) {       \
             y16 = y0;                                                                         \
-            _Pragma("unroll") for (int q = 0; q < SYN_GROUP; ++q) y16 = y16 + cs##j;         \
+            _Pragma("unroll") for (int q = 0; q < SYN_GROUP; ++q) y16 = y16 + cstep_;        \
         }                                                                                     \
         ch##j.y = y16;                                                                        \
     }
@@ -2135,6 +2159,15 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
                 GAL_RW_B(a) GAL_RW_B(b) GAL_RW_B(c) GAL_RW_B(d)                  \
                 fast = (__builtin_amdgcn_ballot_w64(unsafe##a) | __builtin_amdgcn_ballot_w64(unsafe##b) | \
                         __builtin_amdgcn_ballot_w64(unsafe##c) | __builtin_amdgcn_ballot_w64(unsafe##d)) == 0; \
+                if constexpr (CBRW) {                                            \
+                    if (fast) {                                                  \
+                        GAL_RW_C1(a) GAL_RW_C1(b) GAL_RW_C1(c) GAL_RW_C1(d)      \
+                        GAL_RW_A6(a) GAL_RW_A6(b) GAL_RW_A6(c) GAL_RW_A6(d)      \
+                        GAL_RW_B6(a) GAL_RW_B6(b) GAL_RW_B6(c) GAL_RW_B6(d)      \
+                        fast = (__builtin_amdgcn_ballot_w64(unsafe##a) | __builtin_amdgcn_ballot_w64(unsafe##b) | \
+                                __builtin_amdgcn_ballot_w64(unsafe##c) | __builtin_amdgcn_ballot_w64(unsafe##d)) == 0; \
+                    }                                                            \
+                }                                                                \
             }                                                                    \
             if (fast) {                                                          \
                 sf##a -= 1;                                                      \
@@ -2178,6 +2211,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         if (!fast) {                                                             \
             if constexpr (SIG == 1) {                                            \
                 GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                  \
+                [[maybe_unused]] const double csl##a = GAL_CS(a), csl##b = GAL_CS(b), csl##c = GAL_CS(c), csl##d = GAL_CS(d); \
                 _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
                 {                                                                \
                     int acc = o[u];                                              \
@@ -2262,6 +2296,9 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #undef GAL_RW_A
 #undef GAL_RW_B
 #undef GAL_RW_C
+#undef GAL_RW_B6
+#undef GAL_RW_A6
+#undef GAL_RW_C1
 #undef GAL_STEP_R
 #undef GAL_PIN_R
 #undef GAL_PIN
