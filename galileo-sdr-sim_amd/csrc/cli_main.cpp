@@ -674,13 +674,15 @@ int main(int argc, char *argv[])
     }
     cv.notify_all();
     writer.join();
+    // (the sink is closed inside the reported time: unmapping a 1.2 GB file mapping is not free, and the file is only
+    // the caller's once it is closed)
+    if (!sink.finish()) io_error = true;
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     fprintf(stderr, "\nDone!\nProcess time = %.2f [sec]  (%.1f Msamples/s, %.0fx real time)\n", el,
             emitted * 0.26 / el, emitted * 0.1 / el);
     if (gal_scen_eph_gaps(scen) > 0)
         fprintf(stderr, "NOTE: %d (satellite, refresh) pairs ran on a stale ephemeris record (see the warning above)\n",
                 gal_scen_eph_gaps(scen));
-    if (!sink.finish()) io_error = true;
     gal_synth_destroy(eng);
     gal_scen_close(scen);
     if (io_error) {

@@ -429,8 +429,22 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             // samples at 2.6 MS/s -> R = 1040) all wraps of a wave fall into the same group.  Pick the multiple
             // of 16 near 1024 that minimises (slow groups + idle lanes).
             const double period = (double)GAL_CODE_LEN * h->cfg.sample_rate / 1.023e6;
+            // Small batches: with chunks of ~1024 samples a batch of E epochs is E blocks of four waves -- below 256
+            // epochs some CUs get nothing and the call lasts as long as ONE lane needs for its 1040 samples x all channels
+            // (0.29 ms for a one-epoch call).  Shorter chunks spread the same samples over more lanes: aim at one block
+            // per CU (65536 chunks in the batch), not below 208 samples per chunk (13 groups: the fixed cost per chunk --
+            // checkpoints, table build, self-check -- is ~17 % there, irrelevant when most of the chip would idle).
+            double centre = 1024.0;
+            int lo = 768, hi = 1536;
+            const double want = (double)E * (double)N / 65536.0;
+            if (want < 1024.0) {
+                centre = want < 208.0 ? 208.0 : want;
+                lo = (int)(0.75 * centre) / 16 * 16;
+                hi = ((int)(1.5 * centre) + 15) / 16 * 16;
+                if (lo < 64) lo = 64;
+            }
             double best = 1e30;
-            for (int cand = 768; cand <= 1536; cand += 16) {
+            for (int cand = lo; cand <= hi; cand += 16) {
                 const double q = std::floor(period / cand + 0.5);
                 if (q < 1.0) continue;
                 const double spread = 64.0 / q * std::fabs(period - q * cand);  // samples, over one wave
@@ -438,7 +452,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 if (slow > 1.0) slow = 1.0;
                 const int nck = (N + cand - 1) / cand;
                 const double waste = 1.0 - (double)N / ((double)((nck + 63) / 64 * 64) * cand);
-                const double cost = 0.3 * slow + waste + 0.02 * std::fabs(cand - 1024.0) / 1024.0;
+                const double cost = 0.3 * slow + waste + 0.02 * std::fabs(cand - centre) / centre;
                 if (cost < best) {
                     best = cost;
                     R = cand;
