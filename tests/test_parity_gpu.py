@@ -35,7 +35,30 @@ def test_full_epoch_size_bit_exact(pkg):
     """Reference geometry: 260000 samples per epoch, 12 channels, several epochs."""
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=12, n_slots=16, samples_per_epoch=260000, seed=5)
     iq, st, stats = _compare(pkg, p, 260000)
-    assert stats["chunk_samples"] == 1040 and stats["chunks_per_epoch"] == 250  # chunk divides the code period
+    # a batch this small gets short chunks (one block per CU would need 65536 of them) that still divide the code period
+    assert stats["chunk_samples"] == 208 and stats["chunks_per_epoch"] == 1250 and 10400 % stats["chunk_samples"] == 0
+    iq, st, stats = _compare(pkg, p, 260000, chunk_samples=1040)
+    assert stats["chunk_samples"] == 1040 and stats["chunks_per_epoch"] == 250
+
+
+def test_chunk_length_follows_the_batch_size(pkg):
+    """gal_synth_plan picks the chunk length from the batch size: ~1024 samples (1040 = a tenth of the code period at
+    2.6 MS/s) from 263 epochs on, shorter for batches that would otherwise leave CUs without a block; same bits either way
+    (the full-size tests cover 1040 against 1024 / 520)."""
+    for n_ep, want in ((1, 208), (64, 208), (128, 416), (300, 1040)):
+        p = pkg.workloads.make_synthetic(n_epochs=n_ep, n_chan=3, n_slots=4, samples_per_epoch=260000, seed=40 + n_ep)
+        with pkg.SynthEngine(samples_per_epoch=260000, n_slots=4, device=0) as eng:
+            eng.plan(p)
+            assert eng.output_bytes() == n_ep * 260000 * 4
+            import torch
+
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr())
+            _, stats = eng.finish()
+        assert stats["chunk_samples"] == want and stats["chain_mismatch"] == 0, (n_ep, stats)
+        if n_ep <= 64:
+            ref_iq, _ = oracle_run(p[:2], 260000, 2.6e6)
+            assert np.array_equal(out[: ref_iq.size].cpu().numpy(), ref_iq)
 
 
 def test_page_flip_mid_epoch(pkg):
