@@ -12,11 +12,11 @@
 //
 // Pipeline: a producer thread runs the host front-end (libgalscen: orbits, ranges, I/NAV pages) up to two batches
 // ahead -> the main thread plans and executes each batch on the GPU and, after gal_synth_finish(), enqueues the copy
-// into one of two pinned buffers on two copy streams -> the sink moves full buffers into the output.  The sink of a
-// regular file is the file's own page cache: the file is sized up front and mapped, and a pool of writer threads copies
-// disjoint pieces of the pinned buffer into the mapping (page faults and copies run in parallel; a single write()/fwrite
-// stream is one core's copy speed, and buffered pwrite()s of several threads serialise on the inode lock).  Pipes,
-// stdout and devices get plain sequential write()s.  In steady state the run time is that of the slowest stage.
+// into one of two pinned buffers on two copy streams -> the sink moves full buffers into the output with sequential
+// write()s.  (--writers n > 0: a regular file is sized up front and mapped instead, and n threads copy disjoint pieces of
+// the pinned buffer into the mapping -- built to get past one core's copy speed, measured no faster once the unmap is
+// counted: the kernel's page-cache insertion for ONE file does not scale with threads; kept as an option.)  In steady
+// state the run time is that of the slowest stage: the device->host link for /dev/null, the page cache for a file.
 //
 // --sites <file>: BASELINE config 5 as a product entry point -- one line `lat,lon,hgt[,outfile]` per receiver site, one
 // child process of this executable per site, spread over the GPUs of the node (GAL_DEVICE), every site's ishort file
@@ -72,7 +72,7 @@ void usage(const char *prog)
            "                   keeps the last valid record; the reference indexes out of bounds there)\n"
            "  --sites <file>   One line lat,lon,hgt[,outfile] per receiver site: one process per site over the GPUs of the\n"
            "                   node (--gpus N, default all; --per-gpu K processes per GPU, default 1); -o is the name stem\n"
-           "  --writers <n>    Threads that move finished batches into a regular output file (default: up to 8; 0: sequential write)\n"
+           "  --writers <n>    Threads that move finished batches into a regular output file (default 0: sequential write(); > 0: mapped file, n copy threads)\n"
            "  -v               Verbose\n"
            "  -U/-b/-a/-G/-p/-n/-g/-i     accepted for compatibility (file sink only)\n",
            prog);
@@ -482,11 +482,11 @@ int main(int argc, char *argv[])
     const size_t epoch_bytes = (size_t)cfg.samples_per_epoch * 4;
 
     if (n_writers < 0) {
-        const unsigned hc = std::thread::hardware_concurrency();
-        // (measured on the MI355X host, 256 cores, tmpfs: 4-16 writers 1.5-3.0 G samples/s, 1-2 and 32 slower than the
-        // sequential sink's 1.37 -- the kernel's page-cache insertion for ONE file does not scale with threads,
-        // profiles/r03a_sink_probe.log)
-        n_writers = hc >= 16 ? 8 : hc >= 4 ? (int)hc / 2 : 1;
+        // Default: the sequential sink.  Measured on the MI355X host (256 cores, tmpfs, 1.25 GB): write() stream 0.20 s;
+        // mapped sink with 4 / 8 / 16 copy threads 0.24 / 0.22 / 0.24 s INCLUDING the unmap (0.10-0.21 s without it, which is
+        // what round 3's first measurements showed): the kernel inserts pages into ONE file's page cache at ~6 GB/s whoever
+        // asks -- write(), page faults of many threads, pwrite()s of many threads (inode lock) -- profiles/r03a_sink_probe.log.
+        n_writers = 0;
     }
     Sink sink;
     if (!sink.open(outfile, realtime ? 0 : (size_t)total * epoch_bytes, n_writers)) {  // (paced runs stream: they are slow by design)

@@ -432,13 +432,14 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             // Small batches: with chunks of ~1024 samples a batch of E epochs is E blocks of four waves -- below 256
             // epochs some CUs get nothing and the call lasts as long as ONE lane needs for its 1040 samples x all channels
             // (0.29 ms for a one-epoch call).  Shorter chunks spread the same samples over more lanes: aim at one block
-            // per CU (65536 chunks in the batch), not below 208 samples per chunk (13 groups: the fixed cost per chunk --
-            // checkpoints, table build, self-check -- is ~17 % there, irrelevant when most of the chip would idle).
+            // per CU (65536 chunks in the batch), not below ~416 samples per chunk: every chunk is also a checkpoint the
+            // walkers have to store, and for a one-epoch call 208-sample chunks lose more in the walker chain (0.33 ms)
+            // than they win in the kernel (0.08 ms) -- 416: 0.26 + 0.13 ms (tools/per_epoch_breakdown.py).
             double centre = 1024.0;
             int lo = 768, hi = 1536;
             const double want = (double)E * (double)N / 65536.0;
             if (want < 1024.0) {
-                centre = want < 208.0 ? 208.0 : want;
+                centre = want < 416.0 ? 416.0 : want;
                 lo = (int)(0.75 * centre) / 16 * 16;
                 hi = ((int)(1.5 * centre) + 15) / 16 * 16;
                 if (lo < 64) lo = 64;
