@@ -1,16 +1,26 @@
 #!/bin/bash
+# final measurements of a round: GPU tests, profiles (tools/profile_round.sh), the driver's bench command, latency probes
 set -u
+tag=${1:-r03h}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 ) > gpurun_out/r3i_pytest.log 2>&1
-tail -3 gpurun_out/r3i_pytest.log
-timeout 300 python tools/per_epoch_breakdown.py > gpurun_out/r3i_breakdown.log 2>&1
-NAV=tests/golden/20feb2022.rnx
-: > gpurun_out/r3i_cli.log
-for sink in /dev/null /dev/shm/cli.ishort; do for rep in 1 2 3; do
-  t0=$(date +%s.%N)
-  galileo-sdr-sim_amd/galileo-sdr-sim -e $NAV -l -6,51,100 -t 2022/02/20,12:00:00 -d 120 -P 0 -o $sink 2>&1 | grep -E "Process time" | tr '\n' ' ' >> gpurun_out/r3i_cli.log
-  t1=$(date +%s.%N); echo " wall $(echo "$t1 - $t0" | bc) s -> $sink" >> gpurun_out/r3i_cli.log; rm -f /dev/shm/cli.ishort
-done; done
-for w in 0 4 8 16; do echo -n "writers $w: " >> gpurun_out/r3i_cli.log; galileo-sdr-sim_amd/galileo-sdr-sim -e $NAV -l -6,51,100 -t 2022/02/20,12:00:00 -d 120 -P 0 --writers $w -o /dev/shm/cli.ishort 2>&1 | grep "Process time" >> gpurun_out/r3i_cli.log; rm -f /dev/shm/cli.ishort; done
-cat gpurun_out/r3i_breakdown.log gpurun_out/r3i_cli.log
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > gpurun_out/${tag}_pytest.log 2>&1
+tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench.err
+timeout 600 python bench.py --no-extras --no-cpu-baseline > gpurun_out/${tag}_bench_100.json 2>> gpurun_out/${tag}_bench.err
+timeout 600 python bench.py --no-extras --no-cpu-baseline --pipeline 1 > gpurun_out/${tag}_bench_p1.json 2>> gpurun_out/${tag}_bench.err
+timeout 600 python bench.py --no-extras --no-cpu-baseline --channels 9 > gpurun_out/${tag}_bench_ch9.json 2>> gpurun_out/${tag}_bench.err
+timeout 300 python tools/per_epoch_latency.py > gpurun_out/${tag}_latency.log 2>&1
+timeout 300 python tools/per_epoch_breakdown.py >> gpurun_out/${tag}_latency.log 2>&1
+timeout 300 tools/trace_step.sh $tag > gpurun_out/${tag}_trace.log 2>&1
+tail -3 gpurun_out/${tag}_pytest.log; tail -8 gpurun_out/${tag}_profile.log | cut -c1-300; cat gpurun_out/${tag}_latency.log; tail -9 gpurun_out/${tag}_trace.log
+python - $tag <<'PY'
+import json,sys
+tag=sys.argv[1]
+for f in ("default","100","p1","ch9"):
+    try:
+        d=json.loads(open("gpurun_out/%s_bench_%s.json"%(tag,f)).read().strip().splitlines()[-1]); r=d["roofline"]
+        print(f, d["value"], d["ms_per_step"], "frac", r["frac"], "kernel", r["avg_kernel_ms"], "sustained", r["sustained"]["frac"], "overlapped", r["overlapped"]["avg_kernel_ms"], "rocprof1", r["rocprof_avg_kernel_ms"], r["frac_rocprof_standalone"])
+        if f=="default": print(json.dumps(d.get("configs")), json.dumps(d.get("e2e")), json.dumps(d.get("cpu_baseline")))
+    except Exception as e: print(f,"ERR",e)
+PY
