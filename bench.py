@@ -186,7 +186,7 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank):
                 engines[j].execute(outs[j].data_ptr())
         return stats
 
-    run(2)
+    run(2 if workload == "syn24_full" else 8)  # (the legs in front of this one leave the device idle: CLI sink, allocations)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stats = run(steps)
@@ -270,6 +270,10 @@ def main():
                     "NCO chain and synthesises its own range (strong scaling, no exchange)")
     ap.add_argument("--signal", default="boc11", choices=["boc11", "cboc"], help="boc11 = the reference's signal (headline); "
                     "cboc = the opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC)")
+    ap.add_argument("--preroll-ms", type=float, default=300.0,
+                    help="device wake-up in front of the W warm-up steps: un-timed passes of the same step for this long "
+                    "(reported as preroll_steps).  A device that comes out of idle runs its first ~100 ms below its "
+                    "sustained clocks, and W = 5 steps are 6 ms of work; 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-headline legs (kernel + D2H, CLI file "
                     "sink, M-DYN, M-SYN24) that the default 1-GPU run reports under e2e / configs")
@@ -290,7 +294,10 @@ def main():
     backend = os.environ.get("GAL_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # GAL_BENCH_FORCE_DIST=1: initialise the process group for world size 1 as well (launched by torch.distributed.run
+    # --nproc-per-node 1): the RCCL calls of the N > 1 path -- init with device_id, barrier, the two all_reduce of the
+    # report, all_gather_object -- on a box with one GPU (tools/rccl_one_rank.sh)
+    if world > 1 or os.environ.get("GAL_BENCH_FORCE_DIST"):
         import torch.distributed as dist_mod
 
         dist = dist_mod
@@ -356,6 +363,11 @@ def main():
                 inflight[j] = False
         return all_stats
 
+    preroll_steps = 0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        run(2 * depth)
+        preroll_steps += 2 * depth
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -417,6 +429,7 @@ def main():
             **({"ranks": per_rank} if per_rank else {}),
             "steps": args.steps,
             "warmup": args.warmup,
+            "preroll_steps": preroll_steps,  # un-timed device wake-up in front of the warm-up steps (--preroll-ms)
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
@@ -489,13 +502,13 @@ def main():
             del outs[:], out
             torch.cuda.empty_cache()
             line["e2e"]["file_sink"] = leg_file_sink()
-            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 16, local_rank),
+            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 24, local_rank),
                                "syn24": leg_config(torch, pkg, "syn24", 600, 8, local_rank),
                                # BASELINE config 4 at its FULL size: 600 s x 25 MS/s x 24 SVs = 15.0 G samples, 60 GB of IQ
                                # per handle kept in HBM (sample indices beyond 2^32)
                                "syn24_full": leg_config(torch, pkg, "syn24_full", 5999, 3, local_rank),
                                # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
-                               "cboc": leg_config(torch, pkg, "cboc", 1199, 10, local_rank)}
+                               "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
         line["x_realtime"] = round(value * 1e6 / rate, 2)

@@ -21,6 +21,7 @@ def test_bench_json_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["preroll_steps"] > 0  # the device wake-up in front of the warm-up steps is reported, never timed
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["chain_mismatch"] == 0
     rf = d["roofline"]

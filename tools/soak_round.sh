@@ -1,0 +1,22 @@
+#!/bin/bash
+# Randomised parity soak of the current tree (run on the GPU box): product build, long-batch stitcher forced (hooks build),
+# CBOC mode, end-to-end scenarios.   tools/soak_round.sh <tag> [scale]   -> gpurun_out/<tag>_fuzz_soak.log
+set -u
+tag=${1:-rXX}
+k=${2:-1}
+out=gpurun_out/${tag}_fuzz_soak.log
+mkdir -p gpurun_out
+{
+echo "### product build: fuzz_parity.py $((20000*k)) 301 / $((600*k)) 302 big"
+timeout 1500 python tools/fuzz_parity.py $((20000*k)) 301 2>&1 | tail -1
+timeout 1500 python tools/fuzz_parity.py $((600*k)) 302 big 2>&1 | tail -1
+echo "### hooks build, long-batch stitcher forced: fuzz_parity.py $((3000*k)) 303 / $((150*k)) 304 big"
+GAL_FUZZ_HOOKS=1 GAL_SCAN_SINGLE_LEGS=0 timeout 900 python tools/fuzz_parity.py $((3000*k)) 303 2>&1 | tail -1
+GAL_FUZZ_HOOKS=1 GAL_SCAN_SINGLE_LEGS=0 timeout 900 python tools/fuzz_parity.py $((150*k)) 304 big 2>&1 | tail -1
+echo "### CBOC: fuzz_parity.py $((4000*k)) 305 / $((150*k)) 306 big"
+GAL_FUZZ_CBOC=1 timeout 900 python tools/fuzz_parity.py $((4000*k)) 305 2>&1 | tail -1
+GAL_FUZZ_CBOC=1 timeout 900 python tools/fuzz_parity.py $((150*k)) 306 big 2>&1 | tail -1
+echo "### end to end (streamed in 1-3 calls per scenario): fuzz_scenarios.py $((40*k)) cases seed 31"
+timeout 900 python tools/fuzz_scenarios.py $((40*k)) 31 2>&1 | tail -1
+} > $out 2>&1
+cat $out
