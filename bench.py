@@ -294,19 +294,44 @@ def main():
     backend = os.environ.get("GAL_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
-    # GAL_BENCH_FORCE_DIST=1: initialise the process group for world size 1 as well (launched by torch.distributed.run
-    # --nproc-per-node 1): the RCCL calls of the N > 1 path -- init with device_id, barrier, the two all_reduce of the
-    # report, all_gather_object -- on a box with one GPU (tools/rccl_one_rank.sh)
-    if world > 1 or os.environ.get("GAL_BENCH_FORCE_DIST"):
+
+    ctl = {"group": None}  # the CPU-side (gloo) group that carries the barriers, see below
+
+    def init_process_group():
+        # GAL_BENCH_FORCE_DIST=1: initialise the process group for world size 1 as well (launched by torch.distributed.run
+        # --nproc-per-node 1): the RCCL calls of the N > 1 path -- init, barrier, the two all_reduce of the report,
+        # all_gather_object -- on a box with one GPU (tools/rccl_one_rank.sh)
+        if not (world > 1 or os.environ.get("GAL_BENCH_FORCE_DIST")):
+            return None
         import torch.distributed as dist_mod
 
-        dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL carries what the path has to exchange -- the report reductions behind the timed region.  The BARRIERS
+            # around the timed region go through a gloo group of the same ranks (process barrier on the CPU, then
+            # torch.cuda.synchronize()): an RCCL barrier is a device kernel on one more hardware queue, and the first half
+            # dozen steps behind it run 20-30 % slow (profiles/r03k_rccl_slowdown6.log).  GAL_BENCH_RCCL=eager creates the
+            # communicator here instead of at its first collective, GAL_BENCH_BARRIER=rccl sends the barriers through it.
+            if os.environ.get("GAL_BENCH_RCCL", "lazy") == "eager":
+                dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist_mod.init_process_group(backend="nccl")
+            if os.environ.get("GAL_BENCH_BARRIER", "gloo") == "gloo":
+                ctl["group"] = dist_mod.new_group(backend="gloo")
         else:
-            dist.init_process_group(backend=backend)
+            dist_mod.init_process_group(backend=backend)
+        return dist_mod
+
+    # When the process group is initialised matters on this runtime: HIP creates the hardware queue of a stream at the
+    # stream's first use, and which queues end up next to each other decides how well the walker chain of one handle runs
+    # beside the synthesis kernel of the other (profiles/r03k_rccl_slowdown*.log, r03k_queue_map.log: the same bench reads
+    # 1.25 ms per step in a plain process and 1.42 with the RCCL communicator created first).  "late" (default) = after
+    # the engines exist and a first step has used every one of their streams; "early" = first thing, "mid" = after the
+    # engines are planned but before their first step.
+    pg_order = os.environ.get("GAL_BENCH_PG_ORDER", "late")
+    if pg_order == "early":
+        dist = init_process_group()
 
     from __graft_entry__ import load_pkg
 
@@ -340,10 +365,12 @@ def main():
         streams.append(st)
         outs.append(torch.empty(e_count * n_samp * 2, dtype=torch.int16, device="cuda"))
     out = outs[0]
+    if pg_order == "mid":
+        dist = init_process_group()
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl["group"])  # (None = the default group)
         torch.cuda.synchronize()
 
     def run(n_steps):
@@ -354,16 +381,29 @@ def main():
             j = k % depth
             if inflight[j]:
                 all_stats.append(engines[j].finish()[1])
+                if step_clock is not None:
+                    step_clock.append(time.perf_counter())
             engines[j].execute(outs[j].data_ptr(), e_first, e_count)
             inflight[j] = True
         for k in range(n_steps, n_steps + depth):
             j = k % depth
             if inflight[j]:
                 all_stats.append(engines[j].finish()[1])
+                if step_clock is not None:
+                    step_clock.append(time.perf_counter())
                 inflight[j] = False
         return all_stats
 
+    # GAL_BENCH_STEP_TIMES=1: host time at which every finish() of the timed region returned, summarised on stderr
+    step_clock = None
+
     preroll_steps = 0
+    if pg_order not in ("early", "mid"):
+        # first use of every stream of every handle: their hardware queues exist from here on; then the process group; the
+        # device wake-up comes after it (RCCL's set-up takes a second or two, in which the device would go idle again)
+        run(depth)
+        preroll_steps += depth
+        dist = init_process_group()
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
         run(2 * depth)
@@ -371,9 +411,19 @@ def main():
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
+    if os.environ.get("GAL_BENCH_STEP_TIMES"):
+        step_clock = [t0]
     step_stats = run(args.steps)
+    t_run = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if step_clock is not None:
+        gaps = [(b - a) * 1e3 for a, b in zip(step_clock[:-1], step_clock[1:])]
+        order = sorted(range(len(gaps)), key=lambda i: -gaps[i])[:6]
+        sys.stderr.write("step times [ms]: first finish after %.3f, median gap %.3f, largest %s, end barrier %.3f, region %.3f\n" % (
+            gaps[0], sorted(gaps)[len(gaps) // 2], ", ".join("#%d %.3f" % (i, gaps[i]) for i in order),
+            (time.perf_counter() - t_run) * 1e3, elapsed * 1e3))
+        step_clock = None
     assert len(step_stats) == args.steps
     stats = step_stats[-1]
     ms_synth = sum(s["ms_synth"] for s in step_stats)

@@ -49,6 +49,7 @@ void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
+void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state, uint32_t *h_flag, uint32_t seq, hipStream_t st);
 int galk_scanm_blocks(int legs);
 size_t galk_scanm_bytes(int S, int legs);
 int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
@@ -143,7 +144,9 @@ struct gal_synth {
     int range_e0 = 0, range_ne = 0;  // epoch range of the last execute
     void *own_iq = nullptr;
     size_t own_iq_bytes = 0;
-    int *h_ctr = nullptr;  // pinned
+    int *h_ctr = nullptr;  // pinned: [CTR_COUNT] counters, [CTR_COUNT] spare, then the completion flag (k_publish)
+    uint32_t *h_flag = nullptr;  // = (uint32_t *)(h_ctr + 2 * CTR_COUNT): sequence number of the last batch whose record is complete
+    uint32_t seq = 0;            // sequence number of the batch in flight
     int64_t legs_walked = 0, legs_translated = 0, n_fallbacks = 0;  // last finish(): carrier legs walked / translated
     gal_chan_state_t *h_state = nullptr;  // pinned [S]
     bool state_fetched = false;           // h_state holds the state of the batch in flight
@@ -245,10 +248,13 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
-    if (hipHostMalloc((void **)&h->h_ctr, 2 * CTR_COUNT * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+    // (coherent = fine-grained: k_publish writes both from the device while the host polls the flag behind h_ctr)
+    if (hipHostMalloc((void **)&h->h_ctr, (2 * CTR_COUNT + 16) * sizeof(int), hipHostMallocCoherent) != hipSuccess ||
         hipHostMalloc((void **)&h->h_state, sizeof(gal_chan_state_t) * GAL_ENGINE_MAX_CHAN,
-                      hipHostMallocDefault) != hipSuccess)
+                      hipHostMallocCoherent) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "pinned host allocation failed"));
+    h->h_flag = (uint32_t *)(h->h_ctr + 2 * CTR_COUNT);
+    *h->h_flag = 0;
 
     if (hipMalloc((void **)&h->d_lut, 2 * 512 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_str, 50 * 512 * sizeof(uint32_t)) != hipSuccess)
@@ -760,8 +766,9 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     HIP_TRY(hipEventRecord(h->ev[2], st));
     // counters (walker passes + replay check) and the end-of-batch state, behind the synthesis: nothing in front of
     // k_synth that it does not need (finish()'s repair paths fetch both again)
-    HIP_TRY(hipMemcpyAsync(h->h_ctr, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h->h_state, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost, st));
+    h->seq += 1;
+    if (h->seq == 0) h->seq = 1;
+    galk_launch_publish(P, h->h_ctr, h->h_state, h->h_flag, h->seq, st);
     h->state_fetched = true;
     h->last_iq = (uint32_t *)iq_dev;
     h->stats.synth_runs = 1;
@@ -778,7 +785,28 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = h->stream;
     const DevPlan *P = &h->Pw;
-    HIP_TRY(hipStreamSynchronize(st));
+    // The batch is complete when its record has arrived in pinned memory (k_publish runs behind k_synth on the handle's
+    // stream): poll the sequence number; the stream itself is looked at now and then, so that a failed launch or a
+    // device fault ends the wait with its error instead of hanging it.
+    {
+        const uint32_t want = h->seq;
+        unsigned spins = 0;
+        while (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != want) {
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipErrorNotReady) continue;
+                HIP_TRY(q);
+                // the stream has drained: the record must be there (same memory, read once more), or the kernel never ran
+                if (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != want) {
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != want)
+                        return fail(GAL_E_DEVICE, "the batch's completion record never arrived");
+                }
+                break;
+            }
+        }
+    }
     float ms_walk = 0, ms_synth = 0;
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
     hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[2]);

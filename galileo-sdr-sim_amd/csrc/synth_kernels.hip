@@ -2420,6 +2420,27 @@ extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)
     hipLaunchKernelGGL(k_pages, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
 }
 
+// The batch's completion record, written by the DEVICE straight into pinned host memory behind the synthesis kernel: the
+// counters (walker passes, replay check), the end-of-batch channel state and -- last, behind a system-scope fence -- the
+// batch's sequence number, which gal_synth_finish polls.  (Two hipMemcpyAsync + hipStreamSynchronize before: two blit
+// kernels and the runtime's wait path between the end of k_synth and the host seeing it.)
+__global__ void k_publish(const int *__restrict__ ctr, const uint32_t *__restrict__ state, const int state_words,
+                          int *h_ctr, uint32_t *h_state, uint32_t *h_flag, const uint32_t seq)
+{
+    const int t = threadIdx.x;
+    if (t < CTR_COUNT) h_ctr[t] = ctr[t];
+    for (int i = t; i < state_words; i += blockDim.x) h_state[i] = state[i];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state, uint32_t *h_flag, uint32_t seq, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, P->ctr, (const uint32_t *)P->state_out,
+                       (int)(sizeof(gal_chan_state_t) / 4) * P->S, h_ctr, (uint32_t *)h_state, h_flag, seq);
+}
+
 #endif  // GAL_TU_WALK
 
 #if GAL_TU_SYNTH
