@@ -116,7 +116,7 @@ struct gal_synth {
     // so walker workgroups of the next batch only get on when a synthesis wave retires -- with priority they
     // are first in line then, instead of queueing behind the pending synthesis workgroups of other handles
     hipStream_t walk_stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_walk = nullptr;
+    hipEvent_t ev_walk = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
@@ -231,7 +231,6 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
                 hipStreamCreateWithPriority(&ws, hipStreamNonBlocking, greatest) == hipSuccess &&
                 hipStreamCreateWithPriority(&as, hipStreamNonBlocking, greatest) == hipSuccess &&
-                hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming) == hipSuccess) {
                 h->walk_stream = ws;
                 hipStreamDestroy(h->aux_stream);
@@ -316,7 +315,6 @@ int gal_synth_destroy(gal_synth_t *h)
         if (e) hipEventDestroy(e);
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
-    if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_walk) hipEventDestroy(h->ev_walk);
     if (h->walk_stream) hipStreamDestroy(h->walk_stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
@@ -724,13 +722,11 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->Pw.cp_e0 = first_epoch;
     hipStream_t st = h->stream;
     const DevPlan *P = &h->Pw;
-    // ws: the walker chain (the handle's high-priority stream, ordered after the caller's stream by an event)
-    hipStream_t ws = st;
-    if (h->walk_stream) {
-        ws = h->walk_stream;
-        HIP_TRY(hipEventRecord(h->ev_in, st));
-        HIP_TRY(hipStreamWaitEvent(ws, h->ev_in, 0));
-    }
+    // ws: the walker chain (the handle's high-priority stream).  It does not wait for the caller's stream: everything the
+    // walkers read was uploaded by gal_synth_plan, which returns after its copies have completed, and everything they
+    // write is scratch of this handle, whose last reader (k_synth of the previous batch) has completed because
+    // gal_synth_finish has been called (in_flight above).  k_synth itself stays in order on the caller's stream.
+    hipStream_t ws = h->walk_stream ? h->walk_stream : st;
     HIP_TRY(hipEventRecord(h->ev[0], ws));
     HIP_TRY(hipEventRecord(h->ev_prep, ws));
     // Speculative carrier walk, the chain k_synth waits for: first guesses (which also reset the batch's counters), then

@@ -144,8 +144,9 @@ size_t gal_synth_output_bytes(const gal_synth_t *h);
 /*
  * Run the hot path for the planned batch: NCO walk + per-sample synthesis, writing
  * interleaved int16 I,Q (little endian) to iq_dev (DEVICE memory, 16-byte aligned).  Asynchronous: the
- * walker chain runs on the handle's own high-priority streams (ordered after the work already on the handle's
- * stream), the synthesis kernel on the handle's stream; may be called repeatedly for the same plan.  Several
+ * walker chain runs on the handle's own high-priority streams and starts at once (its inputs were uploaded by
+ * gal_synth_plan, which is synchronous; it does not wait for other work on the handle's stream), the synthesis kernel
+ * runs in order on the handle's stream; may be called repeatedly for the same plan.  Several
  * handles may be in flight on different streams: the latency-bound walk of one batch then runs beside the
  * synthesis kernel of another (bench.py --pipeline).
  */
@@ -162,7 +163,9 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev);
  */
 int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch, int32_t n_epochs);
 
-/* Wait for the stream, check the chain self-check, return the end-of-batch channel state (host,
+/* Wait for the batch (its completion record -- counters, end state, a sequence number -- is written by the device into
+ * pinned host memory behind the synthesis kernel and polled here; work the caller has enqueued on the stream BEHIND
+ * gal_synth_execute is not waited for), check the chain self-check, return the end-of-batch channel state (host,
  * n_slots entries, may be NULL) and statistics (may be NULL).  The IQ in iq_dev is FINAL ONLY AFTER THIS CALL HAS
  * RETURNED GAL_OK: the carrier chain is evaluated speculatively, and if the speculation was not verified in time
  * (or the replay check disagreed) finish() repeats the synthesis into iq_dev.  Do not enqueue copies out of
