@@ -44,6 +44,7 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 
 extern "C" {
 void galk_warm(hipStream_t st);
+void galk_touch(hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
@@ -291,6 +292,18 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     galk_warm(nullptr);  // code-object load now, not inside the first batch
+    // First use of the handle's own streams: HIP creates a stream's hardware queue at its first use, and which queues
+    // the walker streams get -- their own, or one shared with streams other libraries created in the meantime -- decides
+    // how well the chain runs beside another handle's synthesis ("Hardware queues").  From here on they are
+    // fixed: a caller who creates its handles before it initialises RCCL & co. keeps them to itself.
+    if (h->walk_stream) {
+        galk_touch(h->walk_stream);
+        galk_touch(h->aux_stream);
+        if (hipStreamSynchronize(h->walk_stream) != hipSuccess || hipStreamSynchronize(h->aux_stream) != hipSuccess) {
+            gal_synth_destroy(h);
+            return fail(GAL_E_DEVICE, "kernel launch failed on device %d: %s", dev, hipGetErrorString(hipGetLastError()));
+        }
+    }
     if (hipStreamSynchronize(nullptr) != hipSuccess) {
         gal_synth_destroy(h);
         return fail(GAL_E_DEVICE, "kernel launch failed on device %d: %s", dev, hipGetErrorString(hipGetLastError()));

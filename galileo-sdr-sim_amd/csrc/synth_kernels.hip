@@ -2518,6 +2518,7 @@ GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_
 #undef GAL_FAMILY_DECL
 
 __global__ void k_warm() {}
+extern "C" void galk_touch(hipStream_t st) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st); }
 extern "C" void galk_warm(hipStream_t st)
 {
     hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st);
