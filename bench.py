@@ -446,17 +446,41 @@ def main():
     v32 = out.view(torch.int32)
     for a in range(0, v32.numel(), 1 << 28):  # in pieces: the int64 widening of a 60 GB output is 120 GB
         chk = (chk + int(v32[a:a + (1 << 28)].to(torch.int64).sum().item())) & 0xFFFFFFFF
-    elapsed, total_samples, chk = pkg.shard.reduce_report(dist, "cuda" if backend == "nccl" else "cpu", elapsed,
-                                                          samples_per_step * args.steps, chk)
-    value = total_samples / elapsed / 1e6
-    # per-rank detail (N > 1): the epoch range, the walker and kernel time of this rank's steps and the carrier legs it walked --
-    # in the strong split (--shard scenario) a rank walks the prefix [0, end of its range) of the scenario, not the whole of it
+    # The report: MAX of the time, SUM of samples and checksums, per-rank detail.  Over RCCL (the default group); should the
+    # communicator fail to come up on this node the measurement is not lost with it -- the same reductions go through the
+    # gloo group that carried the barriers, and the line says so ("report_backend").
+    report_backend = None
     per_rank = None
-    if dist is not None:
-        mine = {"rank": rank, "epochs": [int(e_first), int(e_first + e_count)], "avg_walk_ms": round(ms_walk / args.steps, 4),
-                "avg_kernel_ms": round(ms_synth / args.steps, 4), "legs_walked": int(engines[0].walk_counts()[0])}
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+    local_elapsed, local_samples, local_chk = elapsed, samples_per_step * args.steps, chk
+
+    def report(group, device):
+        el, tot, ck = pkg.shard.reduce_report(dist, device, local_elapsed, local_samples, local_chk, group=group)
+        pr = None
+        if dist is not None:
+            # per-rank detail (N > 1): the epoch range, the walker and kernel time of this rank's steps and the carrier legs it
+            # walked -- in the strong split (--shard scenario) a rank walks the prefix [0, end of its range), not the whole plan
+            mine = {"rank": rank, "epochs": [int(e_first), int(e_first + e_count)], "avg_walk_ms": round(ms_walk / args.steps, 4),
+                    "avg_kernel_ms": round(ms_synth / args.steps, 4), "legs_walked": int(engines[0].walk_counts()[0])}
+            pr = [None] * world
+            dist.all_gather_object(pr, mine, group=group)
+        return el, tot, ck, pr
+
+    if dist is None:
+        elapsed, total_samples, chk, per_rank = report(None, "cpu")
+    elif backend != "nccl":
+        elapsed, total_samples, chk, per_rank = report(None, "cpu")
+        report_backend = backend
+    else:
+        try:
+            elapsed, total_samples, chk, per_rank = report(None, "cuda")
+            report_backend = "rccl"
+        except Exception as exc:  # noqa: BLE001 -- whatever RCCL raises, the gloo group is the way out
+            if ctl["group"] is None:
+                raise
+            sys.stderr.write("bench: report over RCCL failed (%s: %s); falling back to the gloo group\n" % (type(exc).__name__, exc))
+            elapsed, total_samples, chk, per_rank = report(ctl["group"], "cpu")
+            report_backend = "gloo (RCCL failed: %s)" % type(exc).__name__
+    value = total_samples / elapsed / 1e6
 
     if rank == 0:
         avg_synth_ms = ms_synth / args.steps
@@ -476,7 +500,7 @@ def main():
             "n_gpus": world,
             **({"rehearsal": "all %d ranks on GPU %d, backend %s: launch-path check, NOT a scaling measurement" % (
                 world, local_rank, backend)} if os.environ.get("GAL_BENCH_DEVICE") and world > 1 else {}),
-            **({"ranks": per_rank} if per_rank else {}),
+            **({"ranks": per_rank, "report_backend": report_backend} if per_rank else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "preroll_steps": preroll_steps,  # un-timed device wake-up in front of the warm-up steps (--preroll-ms)

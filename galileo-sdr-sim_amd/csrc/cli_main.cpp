@@ -339,8 +339,22 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
 
 }  // namespace
 
+// GAL_CLI_TIMING=1: where the start-up goes (stage times on stderr)
+static void stage(const char *what)
+{
+    static const bool on = getenv("GAL_CLI_TIMING") != nullptr;
+    static auto t0 = std::chrono::steady_clock::now();
+    static auto tl = t0;
+    if (!on) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[timing] %-28s +%7.1f ms  (%7.1f ms since start)\n", what, std::chrono::duration<double, std::milli>(t - tl).count(),
+            std::chrono::duration<double, std::milli>(t - t0).count());
+    tl = t;
+}
+
 int main(int argc, char *argv[])
 {
+    stage("process start");
     if (argc < 3) {
         usage(argv[0]);
         exit(1);
@@ -465,6 +479,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "%s\n", gal_scen_last_error());
         exit(1);
     }
+    stage("scenario opened (RINEX)");
     const int total = gal_scen_total_epochs(scen);
     int32_t wk;
     double ws;
@@ -494,11 +509,13 @@ int main(int argc, char *argv[])
         exit(1);
     }
 
+    stage("sink opened");
     gal_synth_t *eng = nullptr;
     if (gal_synth_create(&cfg, &eng) != GAL_OK) {
         fprintf(stderr, "ERROR: %s\n", gal_synth_last_error());
         exit(1);
     }
+    stage("gal_synth_create");
     hipStream_t stream;
     hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     gal_synth_set_stream(eng, stream);
@@ -516,6 +533,7 @@ int main(int argc, char *argv[])
         hipEventCreate(&slot[i].copied[0]);
         hipEventCreate(&slot[i].copied[1]);
     }
+    stage("device + pinned buffers");
     // device -> host on two streams of their own: two DMA engines share the link, and the copy of batch k runs
     // beside the front-end and the synthesis of batch k+1
     hipStream_t copy_stream[2];
@@ -677,6 +695,7 @@ int main(int argc, char *argv[])
     // (the sink is closed inside the reported time: unmapping a 1.2 GB file mapping is not free, and the file is only
     // the caller's once it is closed)
     if (!sink.finish()) io_error = true;
+    stage("run (= Process time)");
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     fprintf(stderr, "\nDone!\nProcess time = %.2f [sec]  (%.1f Msamples/s, %.0fx real time)\n", el,
             emitted * 0.26 / el, emitted * 0.1 / el);
@@ -685,6 +704,7 @@ int main(int argc, char *argv[])
                 gal_scen_eph_gaps(scen));
     gal_synth_destroy(eng);
     gal_scen_close(scen);
+    stage("teardown");
     if (io_error) {
         fprintf(stderr, "ERROR: short write on the output sink\n");
         rc = 1;

@@ -48,14 +48,15 @@ def epoch_range(rank, world, n_epochs):
     return first, base + (1 if rank < extra else 0)
 
 
-def reduce_report(dist, device, elapsed_s, n_samples, checksum):
-    """MAX of the elapsed time, SUM of samples, XOR-free SUM of 32-bit checksums over ranks."""
+def reduce_report(dist, device, elapsed_s, n_samples, checksum, group=None):
+    """MAX of the elapsed time, SUM of samples, XOR-free SUM of 32-bit checksums over ranks (`group`: None = the default
+    process group; tensors live on `device`, which must suit the group's backend)."""
     import torch
 
     if dist is None:
         return elapsed_s, n_samples, checksum & 0xFFFFFFFF
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     c = torch.tensor([n_samples, checksum & 0xFFFFFFFF], dtype=torch.int64, device=device)
-    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), int(c[0].item()), int(c[1].item()) & 0xFFFFFFFF

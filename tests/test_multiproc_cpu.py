@@ -29,6 +29,14 @@ def _worker(rank, world, port, q):
     chk = int(iq.astype(np.int64).sum()) & 0xFFFFFFFF
     dist.barrier()
     el, total, chk_all = pkg.shard.reduce_report(dist, "cpu", 0.5 + rank, iq.size // 2, chk)
+    # the same through a second group of the same ranks: bench.py's barriers (and, should RCCL fail, its report) go through
+    # a gloo group beside the default one
+    ctl = dist.new_group(backend="gloo")
+    dist.barrier(group=ctl)
+    assert pkg.shard.reduce_report(dist, "cpu", 0.5 + rank, iq.size // 2, chk, group=ctl) == (el, total, chk_all)
+    got = [None] * world
+    dist.all_gather_object(got, {"rank": rank}, group=ctl)
+    assert [g["rank"] for g in got] == list(range(world))
     q.put((rank, el, total, chk_all, chk))
     dist.destroy_process_group()
 
