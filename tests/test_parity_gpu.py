@@ -614,6 +614,40 @@ def test_call_sequence_is_checked(pkg):
         assert np.array_equal(out.cpu().numpy(), ref_iq)
 
 
+def test_completion_record_belongs_to_the_batch(pkg):
+    """gal_synth_finish polls the record the device writes into pinned host memory behind k_synth (counters, end state,
+    sequence number).  Different plans one after the other on ONE handle: every finish must return the state and the
+    statistics of ITS batch (a stale record would hand out the previous batch's), also when the caller has queued work of
+    its own behind execute() on the same stream -- finish waits for the batch, not for the stream -- and when execute is
+    repeated for an unchanged plan."""
+    import torch
+
+    n = 26000
+    st = torch.cuda.Stream()
+    filler = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=8, device=0) as eng:
+        eng.set_stream(st.cuda_stream)
+        for k in range(6):
+            n_ep = 2 + (k % 3)
+            p = pkg.workloads.make_synthetic(n_epochs=n_ep, n_chan=2 + k, n_slots=8, samples_per_epoch=n, seed=900 + k)
+            eng.plan(p)
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            ref_iq, ref_st = oracle_run(p, n, 2.6e6)
+            act = ref_st["prn"] > 0
+            for rep in range(2):
+                eng.execute(out.data_ptr())
+                with torch.cuda.stream(st):  # the caller's own work behind the batch, same stream
+                    for _ in range(4):
+                        filler.mul_(1.0001)
+                state, stats = eng.finish()
+                assert stats["n_epochs"] == n_ep and stats["chain_mismatch"] == 0 and stats["n_active_max"] == 2 + k
+                assert np.array_equal(state["prn"], ref_st["prn"])
+                assert np.array_equal(state["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+                assert np.array_equal(state["page"][act], ref_st["page"][act])
+                assert np.array_equal(out.cpu().numpy(), ref_iq)
+            torch.cuda.synchronize()
+
+
 def test_single_stream_mode(pkg):
     """GAL_CFG_SINGLE_STREAM: walkers and synthesis on the caller's stream (no internal high-priority stream)."""
     p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=7, n_slots=16, samples_per_epoch=52000, seed=606)

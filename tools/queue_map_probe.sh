@@ -28,7 +28,7 @@ for k in sorted(m):
 PY
 }
 run plain rocprofv3 --kernel-trace --output-format csv -d /tmp/qm_plain -- python bench.py $args
-GAL_BENCH_FORCE_DIST=1 run rccl_early rocprofv3 --kernel-trace --output-format csv -d /tmp/qm_rccl_early -- $tr bench.py $args
-GAL_BENCH_FORCE_DIST=1 GAL_BENCH_PG_ORDER=late run rccl_late rocprofv3 --kernel-trace --output-format csv -d /tmp/qm_rccl_late -- $tr bench.py $args
+GAL_BENCH_FORCE_DIST=1 GAL_BENCH_PG_ORDER=early GAL_BENCH_RCCL=eager run rccl_early rocprofv3 --kernel-trace --output-format csv -d /tmp/qm_rccl_early -- $tr bench.py $args
+GAL_BENCH_FORCE_DIST=1 run rccl_late rocprofv3 --kernel-trace --output-format csv -d /tmp/qm_rccl_late -- $tr bench.py $args
 GPU_MAX_HW_QUEUES=8 run plain_q8 rocprofv3 --kernel-trace --output-format csv -d /tmp/qm_plain_q8 -- python bench.py $args
 cat $log
