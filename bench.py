@@ -245,6 +245,24 @@ def measured_traffic():
 HOOKS_BUILD = bool(os.environ.get("GAL_BENCH_HOOKS"))
 
 
+def exchange_report(dist, backend, ctl, report):
+    """The report of a run -- MAX of the time, SUM of samples and checksums, per-rank detail -- over RCCL (the default group)
+    when the backend is nccl.  Should the communicator fail to come up on this node the measurement is not lost with it:
+    the same reductions then go through the gloo group that carried the barriers, and the line says so
+    ("report_backend").  report(group, device) does the exchange; returns its four values + the backend used."""
+    if dist is None:
+        return report(None, "cpu") + (None,)
+    if backend != "nccl":
+        return report(None, "cpu") + (backend,)
+    try:
+        return report(None, "cuda") + ("rccl",)
+    except Exception as exc:  # noqa: BLE001 -- whatever RCCL raises, the gloo group is the way out
+        if ctl["group"] is None:
+            raise
+        sys.stderr.write("bench: report over RCCL failed (%s: %s); falling back to the gloo group\n" % (type(exc).__name__, exc))
+        return report(ctl["group"], "cpu") + ("gloo (RCCL failed: %s)" % type(exc).__name__,)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,11 +464,7 @@ def main():
     v32 = out.view(torch.int32)
     for a in range(0, v32.numel(), 1 << 28):  # in pieces: the int64 widening of a 60 GB output is 120 GB
         chk = (chk + int(v32[a:a + (1 << 28)].to(torch.int64).sum().item())) & 0xFFFFFFFF
-    # The report: MAX of the time, SUM of samples and checksums, per-rank detail.  Over RCCL (the default group); should the
-    # communicator fail to come up on this node the measurement is not lost with it -- the same reductions go through the
-    # gloo group that carried the barriers, and the line says so ("report_backend").
-    report_backend = None
-    per_rank = None
+    # The report: MAX of the time, SUM of samples and checksums, per-rank detail (exchange_report)
     local_elapsed, local_samples, local_chk = elapsed, samples_per_step * args.steps, chk
 
     def report(group, device):
@@ -465,21 +479,17 @@ def main():
             dist.all_gather_object(pr, mine, group=group)
         return el, tot, ck, pr
 
-    if dist is None:
-        elapsed, total_samples, chk, per_rank = report(None, "cpu")
-    elif backend != "nccl":
-        elapsed, total_samples, chk, per_rank = report(None, "cpu")
-        report_backend = backend
-    else:
-        try:
-            elapsed, total_samples, chk, per_rank = report(None, "cuda")
-            report_backend = "rccl"
-        except Exception as exc:  # noqa: BLE001 -- whatever RCCL raises, the gloo group is the way out
-            if ctl["group"] is None:
-                raise
-            sys.stderr.write("bench: report over RCCL failed (%s: %s); falling back to the gloo group\n" % (type(exc).__name__, exc))
-            elapsed, total_samples, chk, per_rank = report(ctl["group"], "cpu")
-            report_backend = "gloo (RCCL failed: %s)" % type(exc).__name__
+    # (RCCL prints a version banner when a communicator comes up -- on stdout, which belongs to the ONE JSON line: file
+    # descriptor 1 points at stderr while the report is exchanged)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        elapsed, total_samples, chk, per_rank, report_backend = exchange_report(dist, backend, ctl, report)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     value = total_samples / elapsed / 1e6
 
     if rank == 0:

@@ -33,3 +33,32 @@ def test_bench_json_line():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert d["value"] > 1000.0  # far above the 260 Msamples/s target even on a 24-epoch batch
+
+
+def test_report_exchange_falls_back_to_the_control_group():
+    """bench.exchange_report: over RCCL when the backend is nccl; if that raises (communicator did not come up), the same
+    exchange through the gloo group that carried the barriers, and the line names the backend it used."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    calls = []
+
+    def report_ok(group, device):
+        calls.append((group, device))
+        return 1.5, 100, 7, [{"rank": 0}]
+
+    def report_rccl_down(group, device):
+        calls.append((group, device))
+        if device == "cuda":
+            raise RuntimeError("NCCL error")
+        return 1.5, 100, 7, [{"rank": 0}]
+
+    dist = object()
+    assert bench.exchange_report(None, "nccl", {"group": None}, report_ok) == (1.5, 100, 7, [{"rank": 0}], None)
+    assert bench.exchange_report(dist, "gloo", {"group": None}, report_ok)[4] == "gloo" and calls[-1] == (None, "cpu")
+    assert bench.exchange_report(dist, "nccl", {"group": "ctl"}, report_ok)[4] == "rccl" and calls[-1] == (None, "cuda")
+    out = bench.exchange_report(dist, "nccl", {"group": "ctl"}, report_rccl_down)
+    assert out[:4] == (1.5, 100, 7, [{"rank": 0}]) and out[4].startswith("gloo (RCCL failed: RuntimeError")
+    assert calls[-2:] == [(None, "cuda"), ("ctl", "cpu")]
+    with pytest.raises(RuntimeError):  # no control group to fall back to: the error is the caller's
+        bench.exchange_report(dist, "nccl", {"group": None}, report_rccl_down)
