@@ -43,7 +43,7 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 #endif
 
 extern "C" {
-void galk_warm(hipStream_t st);
+void galk_warm(hipStream_t st, int signal, double ratio);
 void galk_touch(hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
@@ -291,7 +291,8 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     }
     if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
-    galk_warm(nullptr);  // code-object load now, not inside the first batch
+    // code-object load now, not inside the first batch (the families this configuration can launch)
+    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
     // First use of the handle's own streams: HIP creates a stream's hardware queue at its first use, and which queues
     // the walker streams get -- their own, or one shared with streams other libraries created in the meantime -- decides
     // how well the chain runs beside another handle's synthesis ("Hardware queues").  From here on they are

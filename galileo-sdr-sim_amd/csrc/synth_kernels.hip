@@ -2519,15 +2519,23 @@ GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_
 
 __global__ void k_warm() {}
 extern "C" void galk_touch(hipStream_t st) { hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st); }
-extern "C" void galk_warm(hipStream_t st)
+// signal: 0 = BOC(1,1), 1 = CBOC; ratio = 2 * 1.023e6 / sample rate = the nominal code step in half chips per sample.  Only the
+// families a handle of this configuration can launch are loaded now (the walkers, the classic body, and the resampled-window
+// form whose gate the rate can pass: synth_api.cpp, gal_synth_plan); should a batch need another one after all, HIP loads it
+// at that launch.
+extern "C" void galk_warm(hipStream_t st, int signal, double ratio)
 {
     hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st);
+    const bool rw1 = ratio >= 0.70 && ratio <= 1.02;
+    if (signal == 1) {
+        galk_warm_f4(st);
+        if (rw1) galk_warm_f6(st);
+        return;
+    }
     galk_warm_f1(st);
-    galk_warm_f2(st);
-    galk_warm_f3(st);
-    galk_warm_f4(st);
-    galk_warm_f5(st);
-    galk_warm_f6(st);
+    if (rw1) galk_warm_f2(st);
+    if (ratio <= 0.14) galk_warm_f3(st);
+    else if (ratio <= 0.28) galk_warm_f5(st);
 }
 
 extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act,
