@@ -510,37 +510,29 @@ int main(int argc, char *argv[])
     }
 
     stage("sink opened");
-    // Start-up in two threads: the engine (HIP start-up, code objects, tables) beside the batch buffers (pinning two host
-    // buffers of 133 MB takes 50 ms on its own) -- the run itself is 30 ms for 120 s of signal, start-up is what a user waits for
+    // (Engine creation and buffer allocation one after the other: running them in two threads was measured -- 6 alternations
+    // on one box, 157-318 ms against 250-328 ms for this stage, no difference beyond the run-to-run spread of the HIP
+    // start-up itself; the runtime serialises code-object loading and page pinning.)
     gal_synth_t *eng = nullptr;
-    const int dev_ordinal = cfg.device >= 0 ? cfg.device : 0;
-    cfg.device = dev_ordinal;
-    int create_rc = GAL_OK;
-    char create_err[512] = "";
-    std::thread creator([&]() {
-        create_rc = gal_synth_create(&cfg, &eng);
-        if (create_rc != GAL_OK) snprintf(create_err, sizeof(create_err), "%s", gal_synth_last_error());  // (thread-local text)
-    });
+    if (gal_synth_create(&cfg, &eng) != GAL_OK) {
+        fprintf(stderr, "ERROR: %s\n", gal_synth_last_error());
+        exit(1);
+    }
+    stage("gal_synth_create");
     if (batch_epochs > total) batch_epochs = total > 0 ? total : 1;
     const size_t batch_bytes = epoch_bytes * batch_epochs;
     int16_t *d_iq[2] = {nullptr, nullptr};
     Slot slot[2];
-    bool alloc_ok = hipSetDevice(dev_ordinal) == hipSuccess;
-    for (int i = 0; i < 2 && alloc_ok; ++i) {
-        alloc_ok = hipMalloc((void **)&d_iq[i], batch_bytes) == hipSuccess &&
-                   hipHostMalloc((void **)&slot[i].host, batch_bytes, hipHostMallocDefault) == hipSuccess &&
-                   hipEventCreate(&slot[i].copied[0]) == hipSuccess && hipEventCreate(&slot[i].copied[1]) == hipSuccess;
+    for (int i = 0; i < 2; ++i) {
+        if (hipMalloc((void **)&d_iq[i], batch_bytes) != hipSuccess ||
+            hipHostMalloc((void **)&slot[i].host, batch_bytes, hipHostMallocDefault) != hipSuccess) {
+            fprintf(stderr, "ERROR: buffer allocation failed\n");
+            exit(1);
+        }
+        hipEventCreate(&slot[i].copied[0]);
+        hipEventCreate(&slot[i].copied[1]);
     }
-    creator.join();
-    if (create_rc != GAL_OK) {  // (first: "no gfx950 device" is the message a user without one has to see)
-        fprintf(stderr, "ERROR: %s\n", create_err);
-        exit(1);
-    }
-    if (!alloc_ok) {
-        fprintf(stderr, "ERROR: buffer allocation failed\n");
-        exit(1);
-    }
-    stage("gal_synth_create | buffers");
+    stage("device + pinned buffers");
     hipStream_t stream;
     hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     gal_synth_set_stream(eng, stream);
