@@ -541,6 +541,18 @@ int main(int argc, char *argv[])
     hipStream_t copy_stream[2];
     hipStreamCreateWithFlags(&copy_stream[0], hipStreamNonBlocking);
     hipStreamCreateWithFlags(&copy_stream[1], hipStreamNonBlocking);
+    // First use of the copy path belongs to the start-up, not to the run: the first device -> host copy of a process
+    // took 8 ms on its own (profiles/r03p_cli_batches.log: batch 2 started 10.4 ms into a run whose batches take 2.35 ms)
+    if (!getenv("GAL_CLI_COLD_COPY")) {
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 2; ++k) {
+                const size_t off = k ? batch_bytes / 2 : 0, nb = batch_bytes / 2 < ((size_t)1 << 20) ? batch_bytes / 2 : ((size_t)1 << 20);
+                if (nb) hipMemcpyAsync((char *)slot[i].host + off, (const char *)d_iq[i] + off, nb, hipMemcpyDeviceToHost, copy_stream[k]);
+            }
+        hipStreamSynchronize(copy_stream[0]);
+        hipStreamSynchronize(copy_stream[1]);
+    }
+    stage("copy path warmed");
 
     // writer thread: drains full slots in order
     std::mutex mu;
@@ -612,11 +624,17 @@ int main(int argc, char *argv[])
     bool have_state = false;
     int emitted = 0, cur = 0, rc = 0, r = 0;
     // (SIGINT: the batch in flight is finished and written, batches the producer has queued behind it are dropped)
+    const bool batch_timing = getenv("GAL_CLI_TIMING") != nullptr;
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     while (emitted < total && !io_error && !g_stop) {
+        const auto tb0 = std::chrono::steady_clock::now();
         {
             std::unique_lock<std::mutex> lk(rmu);
             rcv.wait(lk, [&] { return rb[r].ready; });
         }
+        const double tb_rows = ms_since(tb0);
         const int n = rb[r].n;
         const gal_chan_epoch_t *rows_ptr = rb[r].rows.data();
         if (n < 0) {
@@ -629,6 +647,7 @@ int main(int argc, char *argv[])
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !slot[cur].full; });
         }
+        const double tb_slot = ms_since(tb0);
         if (gal_synth_plan(eng, rows_ptr, n, have_state ? state.data() : nullptr) != GAL_OK ||
             gal_synth_execute(eng, d_iq[cur]) != GAL_OK) {
             fprintf(stderr, "\nERROR: %s\n", gal_synth_last_error());
@@ -649,6 +668,10 @@ int main(int argc, char *argv[])
             rc = 1;
             break;
         }
+        const double tb_synth = ms_since(tb0);
+        if (batch_timing)
+            fprintf(stderr, "[timing] batch at %7.2f ms: %3d epochs, waited %.2f ms for rows, %.2f for a free slot, plan + execute + finish %.2f\n",
+                    std::chrono::duration<double, std::milli>(tb0 - t_start).count(), n, tb_rows, tb_slot - tb_rows, tb_synth - tb_slot);
         slot[cur].bytes = epoch_bytes * n;
         {
             const size_t half = epoch_bytes * (size_t)((n + 1) / 2);
