@@ -86,7 +86,8 @@ def leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp,
     the copy of step k runs beside the synthesis of step k+1."""
     depth = len(engines)
     host = [torch.empty(outs[0].numel(), dtype=torch.int16, pin_memory=True) for _ in range(depth)]
-    copy_stream = torch.cuda.Stream()
+    copy_streams = [torch.cuda.Stream(), torch.cuda.Stream()]  # two halves on two streams, as the CLI copies its batches
+    half = outs[0].numel() // 2
     copied = [None] * depth
 
     def run(n):
@@ -95,18 +96,22 @@ def leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp,
             j = k % depth
             if inflight[j]:
                 engines[j].finish()  # IQ final only after finish()
-                copy_stream.wait_stream(streams[j])
-                with torch.cuda.stream(copy_stream):
-                    host[j].copy_(outs[j], non_blocking=True)
-                    copied[j] = torch.cuda.Event()
-                    copied[j].record(copy_stream)
+                copied[j] = []
+                for cs, lo, hi in ((copy_streams[0], 0, half), (copy_streams[1], half, outs[j].numel())):
+                    cs.wait_stream(streams[j])
+                    with torch.cuda.stream(cs):
+                        host[j][lo:hi].copy_(outs[j][lo:hi], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(cs)
+                        copied[j].append(ev)
                 inflight[j] = False
             if k < n:
-                if copied[j] is not None:
-                    copied[j].synchronize()  # the device buffer is free again
+                for ev in copied[j] or ():
+                    ev.synchronize()  # the device buffer is free again
                 engines[j].execute(outs[j].data_ptr(), e_first, e_count)
                 inflight[j] = True
-        copy_stream.synchronize()
+        for cs in copy_streams:
+            cs.synchronize()
 
     run(2)
     torch.cuda.synchronize()
