@@ -135,6 +135,37 @@ def test_cli_sigint_finishes_the_current_epoch(tmp_path):
     assert size % (260000 * 4) == 0 and 5 * 260000 * 4 <= size < 79 * 260000 * 4
 
 
+@pytest.mark.gpu
+def test_cli_sigint_gives_back_the_preallocated_pages():
+    """Un-paced run into a regular file: the sink allocates the file's pages ahead of the writes (fallocate, size kept)
+    while the device starts up.  SIGINT in mid-run: exit status 0, the file ends on an epoch boundary short of the full
+    length, and nothing stays allocated beyond what was written."""
+    import signal
+    import time
+
+    if not os.path.isdir("/dev/shm"):
+        pytest.skip("needs a tmpfs")
+    out = "/dev/shm/galsim_sigint_%d.ishort" % os.getpid()
+    epoch = 260000 * 4
+    try:
+        p = subprocess.Popen([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "300", "-P", "0", "-o", out],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        t0 = time.time()
+        while time.time() - t0 < 60 and not (os.path.exists(out) and os.path.getsize(out) > 0) and p.poll() is None:
+            time.sleep(0.005)
+        p.send_signal(signal.SIGINT)
+        p.wait(timeout=60)
+        assert p.returncode == 0, p.stderr.read()
+        st = os.stat(out)
+        assert st.st_size % epoch == 0 and 0 < st.st_size
+        if st.st_size == 2999 * epoch:
+            pytest.skip("the run was over before the signal arrived")
+        assert st.st_blocks * 512 <= st.st_size + (8 << 20), (st.st_blocks * 512, st.st_size)
+    finally:
+        if os.path.exists(out):
+            os.unlink(out)
+
+
 def test_cli_sites_errors(tmp_path):
     """--sites: a missing or empty site list is an error before anything is started."""
     r = subprocess.run([CLI, "-e", NAV, "--sites", str(tmp_path / "missing.txt"), "-d", "2"], capture_output=True, text=True)
