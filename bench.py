@@ -86,8 +86,7 @@ def leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp,
     the copy of step k runs beside the synthesis of step k+1."""
     depth = len(engines)
     host = [torch.empty(outs[0].numel(), dtype=torch.int16, pin_memory=True) for _ in range(depth)]
-    copy_streams = [torch.cuda.Stream(), torch.cuda.Stream()]  # two halves on two streams, as the CLI copies its batches
-    half = outs[0].numel() // 2
+    copy_stream = torch.cuda.Stream()
     copied = [None] * depth
 
     def run(n):
@@ -96,22 +95,18 @@ def leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp,
             j = k % depth
             if inflight[j]:
                 engines[j].finish()  # IQ final only after finish()
-                copied[j] = []
-                for cs, lo, hi in ((copy_streams[0], 0, half), (copy_streams[1], half, outs[j].numel())):
-                    cs.wait_stream(streams[j])
-                    with torch.cuda.stream(cs):
-                        host[j][lo:hi].copy_(outs[j][lo:hi], non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(cs)
-                        copied[j].append(ev)
+                copy_stream.wait_stream(streams[j])
+                with torch.cuda.stream(copy_stream):
+                    host[j].copy_(outs[j], non_blocking=True)
+                    copied[j] = torch.cuda.Event()
+                    copied[j].record(copy_stream)
                 inflight[j] = False
             if k < n:
-                for ev in copied[j] or ():
-                    ev.synchronize()  # the device buffer is free again
+                if copied[j] is not None:
+                    copied[j].synchronize()  # the device buffer is free again
                 engines[j].execute(outs[j].data_ptr(), e_first, e_count)
                 inflight[j] = True
-        for cs in copy_streams:
-            cs.synchronize()
+        copy_stream.synchronize()
 
     run(2)
     torch.cuda.synchronize()
@@ -163,20 +158,22 @@ def leg_file_sink(seconds=120):
     return out
 
 
-def leg_config(torch, pkg, workload, epochs, steps, local_rank):
+def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams):
     """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
-    bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode), pipelined like the headline."""
+    bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode), pipelined like the headline, on the
+    headline's two streams (new streams would get whatever hardware queues are left: DESIGN.md section 6)."""
     n_samp, rate, n_slots, n_chan = 260000, 2.6e6, 16, 12
     if workload in ("syn24", "syn24_full"):
         n_samp, rate, n_slots, n_chan = 2500000, 25e6, 24, 24
     params = pkg.shard.rank_workload(0, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate,
                                      dyn_track=(workload == "dyn"))
     engines, outs = [], []
+    while len(streams) < 2:  # (--pipeline 1)
+        streams.append(torch.cuda.Stream())
     for _ in range(2):
         eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
                               flags=pkg.synth.GAL_CFG_CBOC if workload == "cboc" else 0)
-        st = torch.cuda.Stream()
-        eng.set_stream(st.cuda_stream)
+        eng.set_stream(streams[len(engines)].cuda_stream)
         eng.plan(params)
         engines.append(eng)
         outs.append(torch.empty(epochs * n_samp * 2, dtype=torch.int16, device="cuda"))
@@ -591,13 +588,13 @@ def main():
             del outs[:], out
             torch.cuda.empty_cache()
             line["e2e"]["file_sink"] = leg_file_sink()
-            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 24, local_rank),
-                               "syn24": leg_config(torch, pkg, "syn24", 600, 8, local_rank),
+            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 24, local_rank, streams),
+                               "syn24": leg_config(torch, pkg, "syn24", 600, 8, local_rank, streams),
                                # BASELINE config 4 at its FULL size: 600 s x 25 MS/s x 24 SVs = 15.0 G samples, 60 GB of IQ
                                # per handle kept in HBM (sample indices beyond 2^32)
-                               "syn24_full": leg_config(torch, pkg, "syn24_full", 5999, 3, local_rank),
+                               "syn24_full": leg_config(torch, pkg, "syn24_full", 5999, 3, local_rank, streams),
                                # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
-                               "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank)}
+                               "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank, streams)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
         line["x_realtime"] = round(value * 1e6 / rate, 2)
