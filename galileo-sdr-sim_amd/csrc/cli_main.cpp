@@ -563,6 +563,8 @@ int main(int argc, char *argv[])
         hipEventCreate(&slot[i].copied[1]);
     }
     stage("device + pinned buffers");
+    // (a stream for the engine, made here: left to the engine it would be made inside the first gal_synth_plan -- 7-17 ms
+    // of the run instead of the start-up)
     hipStream_t stream;
     hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     gal_synth_set_stream(eng, stream);

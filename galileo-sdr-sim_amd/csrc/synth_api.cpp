@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <chrono>
 #include <vector>
 
 #include "synth_dev.h"
@@ -158,6 +159,16 @@ struct gal_synth {
     std::vector<double> rw_s0, rw_g0;
 };
 
+// The stream the handle works on: the caller's (gal_synth_set_stream), or one of its own, made at first need.
+static hipStream_t handle_stream(gal_synth *h)
+{
+    if (!h->stream) {
+        if (!h->own_stream && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        h->stream = h->own_stream;
+    }
+    return h->stream;
+}
+
 extern "C" {
 
 #ifdef GAL_TEST_HOOKS
@@ -187,8 +198,20 @@ const int16_t *gal_tables_cos512(void) { init_tables(); return g_cos; }
 const int16_t *gal_tables_sin512(void) { init_tables(); return g_sin; }
 uint32_t gal_tables_cs25(void) { return kCS25; }
 
+// GAL_CREATE_TIMING=1: where gal_synth_create spends its time (stderr)
+static void create_stage(const char *what)
+{
+    static const bool on = getenv("GAL_CREATE_TIMING") != nullptr;
+    if (!on) return;
+    static thread_local auto tl = std::chrono::steady_clock::now();
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[create] %-34s +%7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tl).count());
+    tl = t;
+}
+
 int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
 {
+    create_stage("enter");
     if (!cfg || !out) return fail(GAL_E_INVAL, "gal_synth_create: null argument");
     *out = nullptr;
     if (!(cfg->sample_rate > 0.0) || cfg->samples_per_epoch < 4 || cfg->n_slots < 1 ||
@@ -202,6 +225,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(GAL_E_DEVICE, "no HIP device: the synthesis engine has no CPU fallback");
+    create_stage("hipGetDeviceCount (HIP start-up)");
     int dev = cfg->device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     if (dev >= ndev) return fail(GAL_E_INVAL, "device %d out of range (%d devices)", dev, ndev);
@@ -212,6 +236,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return fail(GAL_E_DEVICE, "device %d is %s; this library carries gfx950 code only", dev,
                     prop.gcnArchName);
 
+    create_stage("set device + properties");
     gal_synth *h = new (std::nothrow) gal_synth();
     if (!h) return fail(GAL_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
@@ -220,12 +245,11 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         gal_synth_destroy(h);
         return code;
     };
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
-    h->stream = h->own_stream;
-    if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
+    // Streams cost 7-17 ms each to create (a hardware queue apiece): the handle's own stream is made when a batch is planned
+    // without the caller having set one (handle_stream), the walker streams here -- two high-priority ones; a plain second
+    // stream only where priorities are not to be had or not wanted (GAL_CFG_SINGLE_STREAM)
     {
+        bool have = false;
         if (!(cfg->flags & GAL_CFG_SINGLE_STREAM)) {
             int least = 0, greatest = 0;
             hipStream_t ws = nullptr, as = nullptr;
@@ -234,15 +258,18 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
                 hipStreamCreateWithPriority(&as, hipStreamNonBlocking, greatest) == hipSuccess &&
                 hipEventCreateWithFlags(&h->ev_walk, hipEventDisableTiming) == hipSuccess) {
                 h->walk_stream = ws;
-                hipStreamDestroy(h->aux_stream);
                 h->aux_stream = as;
+                have = true;
             } else {  // no stream priorities here: everything stays on the caller's stream (still correct)
                 (void)hipGetLastError();
                 if (ws) hipStreamDestroy(ws);
                 if (as) hipStreamDestroy(as);
             }
         }
+        if (!have && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess)
+            return bail(fail(GAL_E_DEVICE, "hipStreamCreate failed"));
     }
+    create_stage("streams");
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
@@ -256,6 +283,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     h->h_flag = (uint32_t *)(h->h_ctr + 2 * CTR_COUNT);
     *h->h_flag = 0;
 
+    create_stage("events + pinned record");
     if (hipMalloc((void **)&h->d_lut, 2 * 512 * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_str, 50 * 512 * sizeof(uint32_t)) != hipSuccess)
         return bail(fail(GAL_E_NOMEM, "table allocation failed"));
@@ -291,8 +319,10 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     }
     if (hipMemcpy(h->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
+    create_stage("tables (hipMalloc + uploads)");
     // code-object load now, not inside the first batch (the families this configuration can launch)
     galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
+    create_stage("warm launches enqueued");
     // First use of the handle's own streams: HIP creates a stream's hardware queue at its first use, and which queues
     // the walker streams get -- their own, or one shared with streams other libraries created in the meantime -- decides
     // how well the chain runs beside another handle's synthesis ("Hardware queues").  From here on they are
@@ -309,6 +339,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         gal_synth_destroy(h);
         return fail(GAL_E_DEVICE, "kernel launch failed on device %d: %s", dev, hipGetErrorString(hipGetLastError()));
     }
+    create_stage("code objects loaded, streams used");
     *out = h;
     return GAL_OK;
 }
@@ -340,7 +371,7 @@ int gal_synth_destroy(gal_synth_t *h)
 int gal_synth_set_stream(gal_synth_t *h, void *hip_stream)
 {
     if (!h) return fail(GAL_E_INVAL, "null handle");
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;  // (null: handle_stream makes one at first need)
     return GAL_OK;
 }
 
@@ -667,7 +698,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             if (st[i].carr_phase == 0.0) st[i].carr_phase = 0.0;
         memcpy(up + o_act, act_g.data(), act_g.size());
         memcpy(up + o_nact, nact_g.data(), nact_g.size() * sizeof(int));
-        hipStream_t st_up = h->stream;
+        hipStream_t st_up = handle_stream(h);
+        if (!st_up) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
         HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
         HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
         HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
@@ -734,7 +766,8 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->Pw.tr_e0 = first_epoch;
     h->Pw.tr_e1 = first_epoch + n_epochs;
     h->Pw.cp_e0 = first_epoch;
-    hipStream_t st = h->stream;
+    hipStream_t st = handle_stream(h);
+    if (!st) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
     const DevPlan *P = &h->Pw;
     // ws: the walker chain (the handle's high-priority stream).  It does not wait for the caller's stream: everything the
     // walkers read was uploaded by gal_synth_plan, which returns after its copies have completed, and everything they
@@ -793,7 +826,8 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     if (!h->executed) return fail(GAL_E_STATE, "gal_synth_finish before gal_synth_execute");
     h->in_flight = false;
     HIP_TRY(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = handle_stream(h);
+    if (!st) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
     const DevPlan *P = &h->Pw;
     // The batch is complete when its record has arrived in pinned memory (k_publish runs behind k_synth on the handle's
     // stream): poll the sequence number; the stream itself is looked at now and then, so that a failed launch or a
