@@ -541,8 +541,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_synth<%d,false,%d,%d>%s" % (min(args.channels, 12), 1 if args.signal == "cboc" else 0,
-                                                         stats.get("window_mode") or 0,
+                "kernel": "k_synth<%d,false,%d,%d%s>%s" % (min(args.channels, 12), 1 if args.signal == "cboc" else 0,
+                                                         (stats.get("window_mode") or 0) & 15,
+                                                         ",1" if (stats.get("window_mode") or 0) & 16 else "",
                                                          " (+ accumulate launch)" if args.channels > 12 else ""),
                 # achieved / frac: algorithmic bytes per launch / the kernel's launch duration with the kernel running ALONE
                 # (HIP events on its stream, one handle, measured live right behind the timed region).  Inside the timed

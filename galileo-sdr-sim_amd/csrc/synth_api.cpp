@@ -20,6 +20,15 @@
 // rw_phase_a): the kernel's bin table (128 bins of the group-start fraction) decides a lane only if its bin holds ONE
 // threshold, so every pair must be more than a bin (plus the registration margin) apart -- true for 2.6 MS/s (0.017),
 // false where 2.046 MHz / fs is close to a fraction with a denominator below 16 (2.5 MS/s: 9/11, 2.728 MS/s: 3/4).
+// k_synth's carrier index from a fixed-point DDA (synth_kernels.hip, chan_step_rw_cd): opt-in, GAL_CARRIER_DDA=1 (read at
+// create for the code object to load and at every plan).  Bit-exact like the default body -- the waves that meet an uncertain
+// index are synthesised again by the exact-phase kernel -- but not faster yet: DESIGN.md 5 / 9 has the measurements.
+static int carrier_dda_enabled()
+{
+    const char *env = getenv("GAL_CARRIER_DDA");
+    return env && atoi(env) != 0 ? 1 : 0;
+}
+
 static double rw_threshold_gap(double s)
 {
     double T[15];
@@ -44,7 +53,7 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 #endif
 
 extern "C" {
-void galk_warm(hipStream_t st, int signal, double ratio);
+void galk_warm(hipStream_t st, int signal, double ratio, int cd);
 void galk_touch(hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
@@ -321,7 +330,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     create_stage("tables (hipMalloc + uploads)");
     // code-object load now, not inside the first batch (the families this configuration can launch)
-    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
+    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate, carrier_dda_enabled());
     create_stage("warm launches enqueued");
     // First use of the handle's own streams: HIP creates a stream's hardware queue at its first use, and which queues
     // the walker streams get -- their own, or one shared with streams other libraries created in the meantime -- decides
@@ -402,6 +411,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
     // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel, thresholds a bin apart
     bool rw_ok = true;
+    bool cd_ok = true;  // every carrier step small enough for the DDA table's extension behind a wrap (CD_LUT_N)
     int rw_mode = 0;  // 1: holds (code step 0.74 .. 1 half chips per sample), 2: <= 2 advances (<= 0.133), 3: <= 4 advances
                       // (<= 0.266); one form per batch
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); }
@@ -437,6 +447,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
+            cd_ok = cd_ok && std::fabs(r.f_carr * delt) * (16.0 * 511.0) <= 120.0;
             if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
                 const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
@@ -579,6 +590,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
+    const size_t o_wflag = take((size_t)E * ((tiles + 3) / 4) * 4 * 4 + 16);
     // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
     size_t single_legs = (size_t)kScanSingleBlockLegs;
 #ifdef GAL_TEST_HOOKS
@@ -648,10 +660,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 #endif
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
+    P.wflag = (uint32_t *)(base + o_wflag);
 
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
     P.rw = rw_ok ? rw_mode : 0;  // (CBOC: form 1 only -- the gate above leaves rw_ok false for the others)
+    const bool cd_want = cd_ok && carrier_dda_enabled();
 #ifdef GAL_TEST_HOOKS
     // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)
@@ -660,6 +674,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         P.rw = v == 0 ? 0 : (v >= 11 && v <= 13) ? (P.signal == 0 || v == 11 ? v - 10 : 0) : P.rw;
     }
 #endif
+    P.cd = (P.rw == 1 && P.signal == 0 && cd_want) ? 1 : 0;
 
     // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
     // goes over in one copy; one memset clears what must start at zero; one sync at the end: after plan() the batch
@@ -925,7 +940,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;
-    h->stats.window_mode = h->P.rw;
+    h->stats.window_mode = h->P.rw | (h->P.cd ? 16 : 0);
     h->legs_walked = ctr_end[CTR_WALKS];
     h->legs_translated = ctr_end[CTR_SHIFTS];
     if (stats) *stats = h->stats;

@@ -77,6 +77,9 @@ struct DevPlan {
     int signal;           // 0 BOC(1,1) (the reference), 1 CBOC(6,1,1/11) (GAL_CFG_CBOC)
     int rw;               // resampled-window body of k_synth: 1 every code step has 0.74 <= 2 f_code / fs < 1 (holds),
                           // 2 / 3 every code step has 2 f_code / fs <= 0.133 / 0.266 (<= 2 / 4 advances), 0 classic per-sample window index
+    uint32_t *wflag;      // [E * blocks_per_epoch * 4] cd: one word per wave of the k_synth launch, 1 = synthesise it again exactly
+    int cd;               // 1: k_synth takes the carrier table index from a fixed-point DDA (rw == 1, BOC(1,1), every carrier step of
+                          // the batch below 120 / (16 x 511) cycles per sample: synth_kernels.hip, chan_step_rw_cd)
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 

@@ -109,7 +109,10 @@ typedef struct gal_synth_stats {
     int32_t window_mode;        /* fast body of the synthesis kernel: 1 / 2 / 3 resampled windows (one chip-pattern look-up per
                                    16 samples; 1: 0.74 <= 2 f_code / fs < 1, as at the reference's 2.6 MS/s; 2: 2 f_code / fs
                                    <= 0.133, sample rates from 15.4 MS/s; 3: <= 0.266, from 7.7 MS/s; all need well
-                                   separated pattern thresholds), 0 per-sample window index (any rate).  Same bits either way */
+                                   separated pattern thresholds), 0 per-sample window index (any rate).  Same bits either way.
+                                   + 16: form 1 with the carrier table index from a fixed-point DDA (opt-in: environment
+                                   GAL_CARRIER_DDA=1; the waves that meet an uncertain index are synthesised again with the
+                                   exact phase -- same bits again)                                                          */
     int32_t synth_runs;         /* synthesis launches the last batch took: 1, or 2 when gal_synth_finish() had to repeat
                                    it (carrier chain not complete when the kernel was started, or the replay check failed) */
 } gal_synth_stats_t;
