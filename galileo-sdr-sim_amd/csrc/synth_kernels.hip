@@ -1727,6 +1727,10 @@ __device__ __forceinline__ void chan_step_cboc_fast(ChanState &c, const ChanGrou
 // The carrier checkpoints are then verified by an exact closed-form walk of the chunk (nco_walk.h) at the chunk's end
 // instead of by the replay itself.
 // (timing experiments only: tools/build_variant.sh x -DGAL_CD_DOCHECK=0 takes the chunk-end walk out)
+#ifndef GAL_CD_PIN
+#define GAL_CD_PIN 0  // scheduling unit of the DDA body: 2^k - 1 -> 2^k samples.  One sample: 1.214 ms (kernel without the chunk-end
+                      // walk, same box), two: 1.262, four: 1.54, eight: 1.84, none: 1.69 -- wider units spill (profiles/r03u_dda.md)
+#endif
 #ifndef GAL_CD_DOCHECK
 #define GAL_CD_DOCHECK 1
 #endif
@@ -2354,7 +2358,7 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
                         int acc = o[u];                                          \
                         GAL_STEP_D(a) GAL_STEP_D(b) GAL_STEP_D(c) GAL_STEP_D(d)  \
                         GAL_AMB_D(a, b, c, d)                                    \
-                        if (u & 1) { GAL_PIN_D(a, b, c, d) }                     \
+                        if ((u & GAL_CD_PIN) == GAL_CD_PIN) { GAL_PIN_D(a, b, c, d) } \
                         o[u] = acc;                                              \
                     }                                                            \
                     GAL_CD_YADV(a) GAL_CD_YADV(b) GAL_CD_YADV(c) GAL_CD_YADV(d)  \
