@@ -447,7 +447,13 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
-            cd_ok = cd_ok && std::fabs(r.f_carr * delt) * (16.0 * 511.0) <= 120.0;
+            if (cd_ok) {
+                // (c exactly as the kernel forms it; a c half way between two points of the DDA's 2^-32 grid would round with
+                // the parity of t instead of always the same way: chan_step_rw_cd)
+                const double c = 511.0 * std::fabs(r.f_carr * delt);
+                const double cg = (c + 1048576.0) - 1048576.0;
+                cd_ok = c * 16.0 <= 120.0 && std::fabs(c - cg) != 1.1641532182693481e-10;
+            }
             if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
                 const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;

@@ -1703,29 +1703,35 @@ __device__ __forceinline__ void chan_step_cboc_fast(ChanState &c, const ChanGrou
 }
 
 
-// ---- Carrier table index from a fixed-point DDA (k_synth<.., CD = 1>; BOC(1,1) on resampled windows).
+// ---- Carrier table index from a fixed-point DDA (k_synth<.., CD = 1>; BOC(1,1) on resampled windows; opt-in).
 // The reference's index k = (int)(511 p) needs the EXACT phase p of the sequential recurrence only where 511 p is within
 // the recurrence's rounding drift of an integer.  Everywhere else any approximation of 511 p with a known error bound has
-// the same floor.  Per channel the kernel therefore keeps Y ~ 511 * (mirrored phase) instead of the phase itself:
-//   * once per group:  Y += GSZ c (one fma; c = 511 |d| as a double), Y -= 511 once it is >= 511 (the wrap: exact);
-//   * per sample:      t = Y + CD_BIAS at the group start, t += c.  CD_BIAS = 2^20 + 512 + 2^-27 puts t into the binade
-//     [2^20, 2^21), where a double is a fixed-point number with 32 fraction bits: the low word of t IS the fraction of
-//     511 p + 2^-27, the low 20 bits of the high word ARE floor(511 p + 512 + 2^-27), and the address of the table entry is
-//     ONE v_lshl_add_u32 of the high word (the exponent bits are folded into the base).  Five VALU instructions less per
-//     channel-sample than v_add_f64 / v_fract_f64 / v_mul_f64 / v_cvt_i32_f64 / v_lshl_add_u32: add, shift-add.
-//   * error: t differs from 511 p_exact + CD_BIAS by < 17 * 2^-33 (the adds of the group, each rounded to the 2^-32 grid)
-//     + 65 * 2^-44 (Y's own adds) + 1040 * 511 * 2^-53 (drift of the exact recurrence from the real line) < 2.1e-9 < 2^-27.
-//     So the index can differ from the reference's only if the fraction of 511 p lies within 2^-27 of an integer, i.e. the
-//     low word of t is below CD_AMB = 2^6 (probability 2^-26 per channel-sample).  Every lane keeps the minimum of the low
-//     words of its chunk (v_min3_u32, one per two channel-samples); a wave in which any lane ends below CD_AMB -- about one
-//     in a hundred -- raises its flag in DevPlan::wflag, and a second launch of the EXACT-phase kernel (k_synth<.., CD = 0>
-//     with the flags as its filter: blocks and waves without a flag leave at once) synthesises those waves' chunks again,
-//     after this kernel in stream order.  Nothing of that handling sits inside this kernel's sample loop.
-//   * table (per Doppler sign): entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps at 1, so Y
-//     wraps at 511 -- entries 1023.. repeat 512.. and serve the samples of a group that follow a wrap); i < 512 (mirrored
-//     phase still negative after a Doppler sign change): (int) truncates towards zero, so entry i holds k = i - 511.
-// The carrier checkpoints are then verified by an exact closed-form walk of the chunk (nco_walk.h) at the chunk's end
-// instead of by the replay itself.
+// the same floor.  Per channel the kernel therefore keeps, instead of the phase itself,
+//     t = CD_BIAS + 511 * (mirrored phase),   CD_BIAS = 2^20 + 512 + 2^-26,
+// a double in the binade [2^20, 2^21), where a double is a fixed-point number with 32 fraction bits: the low word of t IS
+// the fraction of 511 p + 2^-26, the low 20 bits of the high word ARE floor(511 p + 512 + 2^-26), and the address of the
+// table entry is ONE v_lshl_add_u32 of the high word (the exponent bits are folded into the base, cd_addr).
+//   * per sample:  t += c, c = 511 |d|.  t is on the 2^-32 grid, so the rounded sum is t + RN(c) EXACTLY (the host keeps
+//     batches away in which c lies half way between two grid points, where the direction would depend on t's parity):
+//     one v_add_f64 that is a 52-bit integer addition.  With the shift-add that is 2 VALU instructions where the
+//     exact-phase step has 5 (add, fract, mul, cvt, shift-add).
+//   * per full group:  t += kappa, kappa = 16 (c - RN(c)) (from LDS: s_ka), which takes the systematic part of the grid
+//     error out, and t -= 511 once t >= CD_BIAS + 511: the wrap of the phase, exact on the grid.
+//   * error: t differs from CD_BIAS + 511 p_exact by < 16 * 2^-33 (the group's systematic part before its correction)
+//     + 65 * 2^-33 (the roundings of the corrections) + 2^-33 (chunk start) + 1040 * 511 * 2^-53 (drift of the exact
+//     recurrence from the real line) < 9.7e-9 < 2^-26.  So the index can differ from the reference's only if the fraction
+//     of 511 p lies within 2^-26 of an integer, i.e. the low word of t is below CD_AMB = 2^7 (probability 2^-25 per
+//     channel-sample).  Every lane keeps the minimum of the low words of its chunk (v_min3_u32, one per two
+//     channel-samples); a wave in which any lane ends below CD_AMB -- about one in fifty -- raises its flag in
+//     DevPlan::wflag, and a second launch of the EXACT-phase kernel (k_synth<.., CD = 0> with the flags as its filter:
+//     blocks and waves without a flag leave at once) synthesises those waves' chunks again, after this kernel in stream
+//     order.  Nothing of that handling sits inside this kernel's sample loop (an in-loop repair was measured: its live
+//     ranges push the channel states into scratch).
+//   * table (per Doppler sign): entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps at 1, so
+//     511 p wraps at 511 -- entries 1023.. repeat 512.. and serve the samples of a group that follow a wrap); i < 512
+//     (mirrored phase still negative after a Doppler sign change): (int) truncates towards zero, so entry i holds k = i - 511.
+// The carrier checkpoints, which the exact replay verifies on its way, are verified here by an exact closed-form walk of
+// the chunk (nco_walk.h) at the chunk's end.
 // (timing experiments only: tools/build_variant.sh x -DGAL_CD_DOCHECK=0 takes the chunk-end walk out)
 #ifndef GAL_CD_PIN
 #define GAL_CD_PIN 0  // scheduling unit of the DDA body: 2^k - 1 -> 2^k samples.  One sample: 1.214 ms (kernel without the chunk-end
