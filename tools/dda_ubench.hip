@@ -7,6 +7,8 @@
 //      address = v_lshl_add_u32(hi(t), 2, base') -- floor(t - 2^20) sits in the low bits of the high word --, ds_read_b32,
 //      v_bfe_i32, v_pk_mad_u16, and one v_min3_u32 per TWO samples over the low words (the fraction of 511 p: a sample
 //      whose fraction is within the error bound of 0 makes the group ambiguous -> exact replay, rare)  = 4.5 VALU + 1 LDS
+//   C  B with conflict-free gathers (every lane of a wave reads its own bank: the table index is replaced by the lane id
+//      in the low five bits)   D  B without the LDS read: the VALU floor of the step
 // Prints ns per channel-sample and SIMD at 1..3 waves per SIMD.
 //   hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -o tools/dda_ubench tools/dda_ubench.hip && tools/dda_ubench
 #include <hip/hip_runtime.h>
@@ -59,8 +61,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
                 } else {
                     const uint32_t hi = (uint32_t)(__builtin_bit_cast(uint64_t, t[j]) >> 32);
                     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(hi), "s"(based));
+                    if (MODE == 2) a = (a & ~0x7cu) | ((threadIdx.x & 31u) << 2);  // (one extra v_bfi per sample)
                 }
-                const int tt = *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
+                const int tt = MODE == 3 ? (int)a : *(const __attribute__((address_space(3))) int *)(uintptr_t)a;
                 acc_mad(acc, tt, v);
                 if (MODE == 0) {
                     p[j] = __builtin_amdgcn_fract(p[j] + ds);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
             o[u] = acc;
         }
         // group end: keep the DDA inside the table (what the renormalisation at a group start does)
-        if (MODE == 1) {
+        if (MODE >= 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[j] = t[j] >= 1048576.0 + 511.0 ? t[j] - 511.0 : t[j];
         }
@@ -111,7 +114,8 @@ static void run(int *d, int waves)
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double chs = (double)iters * 16 * 4 * waves;  // channel-samples per SIMD (wave-level)
-    printf("%s, %d waves/SIMD: %.3f ms, %.2f ns per channel-sample and SIMD\n", MODE ? "B dda  " : "A exact", waves, ms,
+    static const char *names[4] = {"A exact", "B dda  ", "C dda, conflict-free", "D dda, no LDS"};
+    printf("%s, %d waves/SIMD: %.3f ms, %.2f ns per channel-sample and SIMD\n", names[MODE], waves, ms,
            ms * 1e6 / chs);
 }
 
@@ -121,5 +125,7 @@ int main()
     hipMalloc(&d, 256 * 4 * 256 * sizeof(int));
     for (int w = 1; w <= 3; ++w) run<0>(d, w);
     for (int w = 1; w <= 3; ++w) run<1>(d, w);
+    for (int w = 1; w <= 3; ++w) run<2>(d, w);
+    for (int w = 1; w <= 3; ++w) run<3>(d, w);
     return 0;
 }
