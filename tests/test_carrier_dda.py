@@ -133,3 +133,26 @@ def test_dda_full_size_equals_the_exact_body(pkg, monkeypatch):
     assert torch.equal(outs[0], outs[1])
     ref_iq, _ = oracle_run(p[:2], 260000, 2.6e6)
     assert np.array_equal(outs[0][: ref_iq.size].cpu().numpy(), ref_iq)
+
+
+def test_dda_epoch_ranges_of_one_plan(pkg, dda):
+    """gal_synth_execute_range with the DDA form: the wave flags are those of the LAUNCH (a range of the plan's epochs), and the
+    exact-phase pass over the flagged waves writes into the range's own buffer."""
+    import torch
+
+    n = 52000
+    p = pkg.workloads.make_synthetic(n_epochs=9, n_chan=12, n_slots=16, samples_per_epoch=n, seed=4322)
+    p["carr_phase0"][0, :3] = 0.0  # fraction word = the bias: these waves are flagged for certain
+    ref_iq, _ = oracle_run(p, n, 2.6e6)
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
+        eng.plan(p)
+        for world in (1, 2, 3):
+            parts = []
+            for r in range(world):
+                e0, ne = pkg.shard.epoch_range(r, world, p.shape[0])
+                out = torch.empty(ne * n * 2, dtype=torch.int16, device="cuda")
+                eng.execute(out.data_ptr(), e0, ne)
+                _, stats = eng.finish()
+                assert stats["chain_mismatch"] == 0 and stats["window_mode"] == 17
+                parts.append(out.cpu().numpy())
+            assert np.array_equal(np.concatenate(parts), ref_iq), world
