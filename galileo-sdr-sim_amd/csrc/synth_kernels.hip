@@ -34,10 +34,11 @@
 
 using namespace galnco;
 
-// The file is compiled as seven translation units, side by side (Makefile: -DGAL_TU=0..6), because the instantiations of
+// The file is compiled as eight translation units, side by side (Makefile: -DGAL_TU=0..7), because the instantiations of
 // k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
 // GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
-// by both libraries; TU 5 the family (0, 3), TU 6 (1, 1): CBOC on resampled windows.  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
+// by both libraries; TU 5 the family (0, 3), TU 6 (1, 1): CBOC on resampled windows, TU 7 (0, 1) with the carrier index from a
+// fixed-point DDA (CD = 1, opt-in).  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
 #if !defined(GAL_TU)
 #define GAL_TU_WALK 1
 #define GAL_TU_SYNTH 1

@@ -2,7 +2,7 @@
 # kasm.sh <mangled-name-fragment> : disassemble csrc/synth_kernels.hip for gfx950 and cut one kernel out into /tmp/kasm.s;
 # prints its register / spill counts and where scratch traffic sits relative to the main loop
 cd "$(dirname "$0")/../galileo-sdr-sim_amd" || exit 1
-frag=${1:-k_synthILi12ELb0ELi0ELi1}
+frag=${1:-k_synthILi12ELb0ELi0ELi1ELi0}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value $KASM_FLAGS -S --cuda-device-only -o /tmp/sk.s csrc/synth_kernels.hip || exit 1
 a=$(grep -n "^_Z7${frag}" /tmp/sk.s | head -1 | cut -d: -f1)
 b=$(grep -n "amdhsa_kernel _Z7${frag}" /tmp/sk.s | cut -d: -f1)
