@@ -59,6 +59,7 @@ void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
+void galk_launch_verify_carr(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state, uint32_t *h_flag, uint32_t seq, hipStream_t st);
 int galk_scanm_blocks(int legs);
@@ -128,6 +129,7 @@ struct gal_synth {
     // are first in line then, instead of queueing behind the pending synthesis workgroups of other handles
     hipStream_t walk_stream = nullptr;
     hipEvent_t ev_walk = nullptr;
+    hipEvent_t ev_ver = nullptr;  // k_verify_carr done (carrier-DDA batches)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
@@ -282,6 +284,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ver, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     // (coherent = fine-grained: k_publish writes both from the device while the host polls the flag behind h_ctr)
@@ -370,6 +373,7 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_walk) hipEventDestroy(h->ev_walk);
+    if (h->ev_ver) hipEventDestroy(h->ev_ver);
     if (h->walk_stream) hipStreamDestroy(h->walk_stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -736,8 +740,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     return GAL_OK;
 }
 
-static int enqueue_synth(gal_synth *h, uint32_t *iq)
+// verify_here: the carrier-DDA form of k_synth does not verify the carrier checkpoints itself; k_verify_carr does, in front of
+// it on the same stream (repair paths, handles without a walker stream) -- the first launch of a batch runs it on the walker
+// stream instead, beside the synthesis (gal_synth_execute_range)
+static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
 {
+    if (verify_here && h->P.cd && h->nact_max != 0) galk_launch_verify_carr(&h->Pw, h->stream);
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
         HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
         return GAL_OK;
@@ -819,15 +827,23 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     galk_launch_walk_code(P, h->aux_stream);
     galk_launch_pages(P, h->aux_stream);
     HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
+    // carrier-DDA batches: the checkpoints are verified by a kernel of their own (k_verify_carr), on the walker stream behind
+    // the chain and beside the synthesis; the completion record waits for both
+    const bool verify_beside = h->P.cd && ws != st && h->nact_max != 0;
     if (ws != st) {
         HIP_TRY(hipEventRecord(h->ev_walk, ws));
         HIP_TRY(hipStreamWaitEvent(st, h->ev_walk, 0));
+        if (verify_beside) {
+            galk_launch_verify_carr(P, ws);
+            HIP_TRY(hipEventRecord(h->ev_ver, ws));
+        }
     }
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
     HIP_TRY(hipEventRecord(h->ev[1], st));
-    int rc = enqueue_synth(h, (uint32_t *)iq_dev);
+    int rc = enqueue_synth(h, (uint32_t *)iq_dev, !verify_beside);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], st));
+    if (verify_beside) HIP_TRY(hipStreamWaitEvent(st, h->ev_ver, 0));
     // counters (walker passes + replay check) and the end-of-batch state, behind the synthesis: nothing in front of
     // k_synth that it does not need (finish()'s repair paths fetch both again)
     h->seq += 1;
@@ -895,7 +911,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         h->state_fetched = false;
         HIP_TRY(hipEventRecord(h->ev[1], st));
         h->stats.synth_runs += 1;
-        int rc = enqueue_synth(h, h->last_iq);
+        int rc = enqueue_synth(h, h->last_iq, true);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev[2], st));
         HIP_TRY(hipMemcpyAsync(ctr_end, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -929,7 +945,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         h->state_fetched = false;
         HIP_TRY(hipEventRecord(h->ev[1], st));
         h->stats.synth_runs += 1;
-        int rc = enqueue_synth(h, h->last_iq);
+        int rc = enqueue_synth(h, h->last_iq, true);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(h->ev[2], st));
         HIP_TRY(hipMemcpyAsync(ctr_end, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -385,6 +385,34 @@ __global__ void k_walk_carr(DevPlan P, int first)
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
 }
 
+// k_verify_carr: every leg of the executed epochs walked once more, genuinely and in closed form, from its own first
+// checkpoint: each checkpoint of the leg and the state it hands to the next leg must come out bit for bit (CTR_MISMATCH
+// otherwise, which sends gal_synth_finish into the all-walked fallback).  This is what k_synth's exact replay establishes on
+// its way; the carrier-DDA form of k_synth (CD = 1) never forms the exact phase, so batches that run it get this kernel on
+// the walker stream, beside the synthesis.  Same lane order as k_walk_carr (a wave = 64 legs of one slot).
+__global__ void k_verify_carr(DevPlan P)
+{
+    if (P.ctr[CTR_UNVERIFIED] != 0) return;  // chain not complete: gal_synth_finish iterates and launches this again
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.LEGS * P.S) return;
+    const int s = t / P.LEGS;
+    const int i = t - s * P.LEGS;
+    const int e = i / P.W, w = i - e * P.W;
+    if (e < P.cp_e0) return;  // walked silently: no checkpoints
+    const int idx = e * P.S + s;
+    if (P.prn[idx] <= 0) return;
+    const int L = P.Lc * P.R;
+    int n = P.N - w * L;
+    n = n > L ? L : n;
+    if (n <= 0) return;
+    const double d = P.dstep[idx];
+    const double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
+    int bad = 0;
+    const WalkOut o = carr_walk_track(cpp[0], d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { bad += cpp[c] != v; });
+    bad += cpp[(n + P.R - 1) / P.R] != o.p;  // the next leg's first checkpoint, or the end-of-epoch state
+    if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
+}
+
 // k_carr_scan: one 1024-thread block per slot stitches the legs.  Sequential statement (what the three
 // block-wide sweeps below compute; walk_host.cpp::galwalk_spec_wrap runs the same statement on the host):
 //     chain state: last claim (lc_w, lc_r), its pending correction D, allok
@@ -1731,15 +1759,15 @@ __device__ __forceinline__ void chan_step_cboc_fast(ChanState &c, const ChanGrou
 //   * table (per Doppler sign): entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps at 1, so
 //     511 p wraps at 511 -- entries 1023.. repeat 512.. and serve the samples of a group that follow a wrap); i < 512
 //     (mirrored phase still negative after a Doppler sign change): (int) truncates towards zero, so entry i holds k = i - 511.
-// The carrier checkpoints, which the exact replay verifies on its way, are verified here by an exact closed-form walk of
-// the chunk (nco_walk.h) at the chunk's end.
+// The carrier checkpoints, which the exact replay verifies on its way, are verified by k_verify_carr: a genuine closed-form
+// walk of every leg (nco_walk.h) on the walker stream, beside this kernel.
 // (timing experiments only: tools/build_variant.sh x -DGAL_CD_DOCHECK=0 takes the chunk-end walk out)
 #ifndef GAL_CD_PIN
 #define GAL_CD_PIN 0  // scheduling unit of the DDA body: 2^k - 1 -> 2^k samples.  One sample: 1.214 ms (kernel without the chunk-end
                       // walk, same box), two: 1.262, four: 1.54, eight: 1.84, none: 1.69 -- wider units spill (profiles/r03u_dda.md)
 #endif
 #ifndef GAL_CD_DOCHECK
-#define GAL_CD_DOCHECK 1
+#define GAL_CD_DOCHECK 0  // 1: the chunk's carrier walk inside k_synth (the first form of the verification: 0.15 ms per launch)
 #endif
 #define CD_LUT_N 1152
 #define CD_AMB 128u
@@ -2600,6 +2628,12 @@ extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 extern "C" void galk_launch_carr_guess(const DevPlan *P, hipStream_t st)
 {
     hipLaunchKernelGGL(k_carr_guess, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
+}
+
+extern "C" void galk_launch_verify_carr(const DevPlan *P, hipStream_t st)
+{
+    const int n = P->LEGS * P->S;
+    hipLaunchKernelGGL(k_verify_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P);
 }
 
 extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st)
