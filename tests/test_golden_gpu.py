@@ -101,6 +101,25 @@ def test_g6_g7_judge_run_scenarios_hip_md5_equal_reference_output(pkg):
     assert hashlib.md5(iq.tobytes()).hexdigest() == REF["G7"]["md5"]
 
 
+def test_g8_g9_judge_r3_scenarios_hip_md5_equal_reference_output(pkg):
+    """G8 / G9 (run through the reference by the round-3 judge with the reference's own flags): RINEX -> front-end -> HIP
+    hashes to the reference's files; G8 streamed in two calls across its 06:42:30 refresh."""
+    rows = pkg.Scenario(NAV, llh=(35.274, 137.014, 100), start="2022/02/20,06:42:10", duration_s=35, iono_enable=False).all()
+    h = hashlib.md5()
+    st = None
+    with pkg.SynthEngine(device=0) as eng:
+        for a, b in ((0, 120), (120, 349)):
+            iq, st, stats = eng.run_host(rows[a:b], st)
+            assert stats["chain_mismatch"] == 0 and stats["n_active_max"] == REF["G8"]["n_sv"]
+            h.update(iq.tobytes())
+    assert h.hexdigest() == REF["G8"]["md5"]
+    rows = pkg.Scenario(NAV, llh=(-33.9, 18.4, 50), start="2022/02/20,16:20:00", duration_s=15, iono_enable=True).all()
+    with pkg.SynthEngine(device=0) as eng:
+        iq, _, stats = eng.run_host(rows)
+    assert iq.nbytes == REF["G9"]["bytes"] and stats["n_active_max"] == REF["G9"]["n_sv"]
+    assert hashlib.md5(iq.tobytes()).hexdigest() == REF["G9"]["md5"]
+
+
 def test_ephemeris_gap_scenario_hip_equals_oracle(pkg, tmp_path):
     """The window in which the reference runs into eph_vector[sv][-1] (tests/test_golden_scenarios.py::
     test_ephemeris_gap_policy): the default policy completes all 399 epochs; HIP == oracle on those rows, through the
