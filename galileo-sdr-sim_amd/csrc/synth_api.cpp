@@ -20,15 +20,6 @@
 // rw_phase_a): the kernel's bin table (128 bins of the group-start fraction) decides a lane only if its bin holds ONE
 // threshold, so every pair must be more than a bin (plus the registration margin) apart -- true for 2.6 MS/s (0.017),
 // false where 2.046 MHz / fs is close to a fraction with a denominator below 16 (2.5 MS/s: 9/11, 2.728 MS/s: 3/4).
-// k_synth's carrier index from a fixed-point DDA (synth_kernels.hip, chan_step_rw_cd): opt-in, GAL_CARRIER_DDA=1 (read at
-// create for the code object to load and at every plan).  Bit-exact like the default body -- the waves that meet an uncertain
-// index are synthesised again by the exact-phase kernel -- but not faster yet: DESIGN.md 5 / 9 has the measurements.
-static int carrier_dda_enabled()
-{
-    const char *env = getenv("GAL_CARRIER_DDA");
-    return env && atoi(env) != 0 ? 1 : 0;
-}
-
 static double rw_threshold_gap(double s)
 {
     double T[15];
@@ -54,6 +45,10 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 
 extern "C" {
 void galk_warm(hipStream_t st, int signal, double ratio, int cd);
+void galk_warm_g(hipStream_t st);
+int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act, const int *nact,
+                        uint32_t *iq, int e0, int ne, hipStream_t st);
+void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hipStream_t st);
 void galk_touch(hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
@@ -111,6 +106,9 @@ void init_tables()
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
 constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block per slot stitches the carrier legs
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
+constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = chunk length of its batches (synth_group.hip: SG_CHUNK)
+constexpr int kGroupSyms = 64;      // ... symbol masks per channel and epoch (SG_SYMS)
+constexpr int kGroupListCap = 1 << 16;  // ... capacity of the undecided-group list (a 120 s batch lists ~2000)
 constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + stitch (which translates on the spot), one spare --
                                     // no-op launches in front of k_synth when the chain is complete after one, as it normally
                                     // is; a handle whose last batch got by with one enqueues one (gal_synth_finish iterates and
@@ -185,9 +183,9 @@ extern "C" {
 #ifdef GAL_TEST_HOOKS
 // libgalsynth_hooks.so: the same sources with the fault-injection hooks of the repair-path tests compiled in
 // (GAL_WALK_LEGS / GAL_WALK_TRANSLATE / GAL_WALK_PASSES environment variables).  Never shipped, never benchmarked.
-const char *gal_synth_version(void) { return "galsynth 0.2 (gfx950, HIP) +testhooks"; }
+const char *gal_synth_version(void) { return "galsynth 0.3 (gfx950, HIP) +testhooks"; }
 #else
-const char *gal_synth_version(void) { return "galsynth 0.2 (gfx950, HIP)"; }
+const char *gal_synth_version(void) { return "galsynth 0.3 (gfx950, HIP)"; }
 #endif
 const char *gal_synth_last_error(void) { return g_err; }
 
@@ -333,7 +331,12 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     create_stage("tables (hipMalloc + uploads)");
     // code-object load now, not inside the first batch (the families this configuration can launch)
-    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate, carrier_dda_enabled());
+    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate, 0);
+    {
+        const double ratio = 2.0 * 1.023e6 / cfg->sample_rate;
+        if (!(cfg->flags & (GAL_CFG_CBOC | GAL_CFG_EXACT_REPLAY)) && ratio >= 0.70 && ratio <= 1.02 && cfg->chunk_samples <= 0)
+            galk_warm_g(nullptr);
+    }
     create_stage("warm launches enqueued");
     // First use of the handle's own streams: HIP creates a stream's hardware queue at its first use, and which queues
     // the walker streams get -- their own, or one shared with streams other libraries created in the meantime -- decides
@@ -415,7 +418,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
     // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel, thresholds a bin apart
     bool rw_ok = true;
-    bool cd_ok = true;  // every carrier step small enough for the DDA table's extension behind a wrap (CD_LUT_N)
+    bool g_ok = true;   // k_synth_g: every carrier step in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries
+                        // per group (the table's extension behind a wrap), and a phase that moves: a carrier that stands still
+                        // ON an index boundary would have every one of its groups listed for the exact replay
     int rw_mode = 0;  // 1: holds (code step 0.74 .. 1 half chips per sample), 2: <= 2 advances (<= 0.133), 3: <= 4 advances
                       // (<= 0.266); one form per batch
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); }
@@ -451,12 +456,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
-            if (cd_ok) {
-                // (c exactly as the kernel forms it; a c half way between two points of the DDA's 2^-32 grid would round with
-                // the parity of t instead of always the same way: chan_step_rw_cd)
-                const double c = 511.0 * std::fabs(r.f_carr * delt);
-                const double cg = (c + 1048576.0) - 1048576.0;
-                cd_ok = c * 16.0 <= 120.0 && std::fabs(c - cg) != 1.1641532182693481e-10;
+            if (g_ok) {
+                const double ad = std::fabs(r.f_carr * delt);
+                g_ok = ad >= 9.094947017729282e-13 && 511.0 * ad * 16.0 <= 120.0;
             }
             if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
@@ -487,7 +489,17 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 
     // ---- chunking
     int R = h->cfg.chunk_samples;
-    if (R <= 0) {
+    // k_synth_g (synth_group.hip) where it applies: BOC(1,1) on resampled windows of the hold form, automatic chunking, an epoch
+    // that spans fewer symbols than the kernel's mask table holds, list entries that fit 32 bits
+    bool fam_g = !cboc && rw_ok && rw_mode == 1 && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) && nact_max > 0 &&
+                 (double)N / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
+                 (double)E * (double)((N + kGroupChunk - 1) / kGroupChunk) * 64.0 < 4294967296.0;
+#ifdef GAL_TEST_HOOKS
+    if (getenv("GAL_SYNTH_RW")) fam_g = false;  // the forced window forms are k_synth's
+    if (const char *env = getenv("GAL_SYNTH_FAMILY")) fam_g = fam_g && atoi(env) != 0;
+#endif
+    if (fam_g) R = kGroupChunk;
+    else if (R <= 0) {
         int target = (int)((N + 512) / 1024);
         target = (target + 63) / 64 * 64;
         if (target < 64) target = 64;
@@ -601,6 +613,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
     const size_t o_wflag = take((size_t)E * ((tiles + 3) / 4) * 4 * 4 + 16);
+    const size_t o_gflist = take(fam_g ? (size_t)kGroupListCap * 4 : 16);
     // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
     size_t single_legs = (size_t)kScanSingleBlockLegs;
 #ifdef GAL_TEST_HOOKS
@@ -671,11 +684,19 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
     P.wflag = (uint32_t *)(base + o_wflag);
+    P.fam = fam_g ? 1 : 0;
+    P.gflist = (uint32_t *)(base + o_gflist);
+    P.gflist_cap = kGroupListCap;
+    {
+        // k_synth_g: a block of 8 waves takes an epoch's chunks; short batches are cut finer so that every CU gets one
+        int bpe = 1;
+        while (E * bpe < 512 && bpe * 8 < nchunks) bpe *= 2;
+        P.gbpe = bpe;
+    }
 
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
     P.rw = rw_ok ? rw_mode : 0;  // (CBOC: form 1 only -- the gate above leaves rw_ok false for the others)
-    const bool cd_want = cd_ok && carrier_dda_enabled();
 #ifdef GAL_TEST_HOOKS
     // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)
@@ -684,7 +705,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         P.rw = v == 0 ? 0 : (v >= 11 && v <= 13) ? (P.signal == 0 || v == 11 ? v - 10 : 0) : P.rw;
     }
 #endif
-    P.cd = (P.rw == 1 && P.signal == 0 && cd_want) ? 1 : 0;
+    P.cd = 0;
 
     // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
     // goes over in one copy; one memset clears what must start at zero; one sync at the end: after plan() the batch
@@ -745,16 +766,21 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 // stream instead, beside the synthesis (gal_synth_execute_range)
 static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
 {
-    if (verify_here && h->P.cd && h->nact_max != 0) galk_launch_verify_carr(&h->Pw, h->stream);
+    if (verify_here && (h->P.cd || h->P.fam == 1) && h->nact_max != 0) galk_launch_verify_carr(&h->Pw, h->stream);
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
         HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
         return GAL_OK;
     }
     for (int g = 0; g < h->n_groups; ++g) {
-        const int rc = galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, h->d_act + (size_t)g * h->P.E * kActRow,
-                                         h->d_nact + (size_t)g * h->P.E, iq, h->range_e0, h->range_ne, h->stream);
+        const uint8_t *act = h->d_act + (size_t)g * h->P.E * kActRow;
+        const int *nact = h->d_nact + (size_t)g * h->P.E;
+        const int rc = h->P.fam == 1
+                           ? galk_launch_synth_g(&h->P, h->d_plan, h->group_nch[g], g > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream)
+                           : galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream);
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
     }
+    // the groups k_synth_g could not decide (chip pattern or table index within the rounding drift of a boundary), exactly
+    if (h->P.fam == 1) galk_launch_repair_g(&h->P, iq, h->range_e0, h->stream);
     HIP_TRY(hipGetLastError());
     return GAL_OK;
 }
@@ -829,7 +855,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     // carrier-DDA batches: the checkpoints are verified by a kernel of their own (k_verify_carr), on the walker stream behind
     // the chain and beside the synthesis; the completion record waits for both
-    const bool verify_beside = h->P.cd && ws != st && h->nact_max != 0;
+    const bool verify_beside = (h->P.cd || h->P.fam == 1) && ws != st && h->nact_max != 0;
     if (ws != st) {
         HIP_TRY(hipEventRecord(h->ev_walk, ws));
         HIP_TRY(hipStreamWaitEvent(st, h->ev_walk, 0));
@@ -908,6 +934,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
             HIP_TRY(hipStreamSynchronize(st));
         }
         HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(P->ctr + CTR_GFLAGS, 0, 2 * sizeof(int), st));
         h->state_fetched = false;
         HIP_TRY(hipEventRecord(h->ev[1], st));
         h->stats.synth_runs += 1;
@@ -956,13 +983,33 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
         ms_synth = extra;
         h->n_fallbacks += 1;
     }
+    if (h->P.fam == 1 && ctr_end[CTR_GOVER] != 0) {
+        // more undecided groups than the list holds (a batch the gate should have kept away, e.g. hold patterns that overflow
+        // the masks): the batch once more with the exact-replay kernel, which takes any input
+        h->P.fam = 0;
+        h->Pw.fam = 0;
+        HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
+        HIP_TRY(hipEventRecord(h->ev[1], st));
+        h->stats.synth_runs += 1;
+        int rc = enqueue_synth(h, h->last_iq, false);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(h->ev[2], st));
+        HIP_TRY(hipMemcpyAsync(ctr_end, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float extra = 0;
+        hipEventElapsedTime(&extra, h->ev[1], h->ev[2]);
+        ms_walk += ms_synth;
+        ms_synth = extra;
+    }
+    h->stats.kernel_family = h->P.fam;
+    h->stats.repaired_groups = h->P.fam == 1 ? ctr_end[CTR_GFLAGS] : 0;
     h->stats.walk_passes = ctr_end[CTR_PASSES];
     h->enq_passes = ctr_end[CTR_PASSES] > 1 ? kDefaultPasses : 1;
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;
-    h->stats.window_mode = h->P.rw | (h->P.cd ? 16 : 0);
+    h->stats.window_mode = h->P.rw;
     h->legs_walked = ctr_end[CTR_WALKS];
     h->legs_translated = ctr_end[CTR_SHIFTS];
     if (stats) *stats = h->stats;

@@ -9,7 +9,10 @@
 #include "../../include/galsynth.h"
 
 enum { CTR_UNVERIFIED = 0, CTR_PASSES = 1, CTR_MISMATCH = 2, CTR_UNVER_NEXT = 3, CTR_WALKS = 4, CTR_SHIFTS = 5, CTR_REWALK_NEXT = 6,
-       CTR_TICKET = 7, CTR_COUNT = 8 };
+       CTR_TICKET = 7,
+       CTR_GFLAGS = 8,  // k_synth_g: groups listed for k_repair_g (the list's fill count)
+       CTR_GOVER = 9,   // ... the list overflowed: gal_synth_finish repeats the batch with the exact-replay kernel
+       CTR_COUNT = 10 };
 
 // Everything lives in HBM; [E][S] arrays are indexed e * S + s.
 struct DevPlan {
@@ -80,6 +83,11 @@ struct DevPlan {
     uint32_t *wflag;      // [E * blocks_per_epoch * 4] cd: one word per wave of the k_synth launch, 1 = synthesise it again exactly
     int cd;               // 1: k_synth takes the carrier table index from a fixed-point DDA (rw == 1, BOC(1,1), every carrier step of
                           // the batch below 120 / (16 x 511) cycles per sample: synth_kernels.hip, chan_step_rw_cd)
+    int fam;              // synthesis kernel family: 0 k_synth (one chunk per lane, exact replay), 1 k_synth_g (one 16-sample group per
+                          // lane from the chunk's checkpoint in closed form + k_repair_g for the undecided groups; synth_group.hip)
+    int gbpe;             // k_synth_g: blocks per epoch
+    uint32_t *gflist;     // k_synth_g -> k_repair_g: the undecided groups, (epoch in range * nchunks + chunk) * 64 + group
+    int gflist_cap;
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
 };
 

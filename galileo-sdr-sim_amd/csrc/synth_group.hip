@@ -1,0 +1,600 @@
+// synth_group.hip -- k_synth_g: the hot kernel of the reference geometry (BOC(1,1), 0.74 <= 2 f_code / fs < 1, i.e. 2.6 MS/s),
+// ONE 16-SAMPLE GROUP PER LANE, and k_repair_g, which replays the few groups it could not decide with the reference's exact
+// operation sequence.  Replaces the per-sample loop of the reference, src/galileo-sdr.cpp:481-539.
+//
+// k_synth (synth_kernels.hip) lets a lane replay 1040 consecutive samples because the two NCO recurrences (:528-532) are
+// chains of ROUNDED additions: the exact phase of sample n is only available by stepping.  But the loop does not use the
+// phases, it uses two INTEGERS derived from them -- the half-chip index (int)(2 x) (:512) and the table index
+// (int)(511 p) (:509-510) -- and those depend on the rounding history only where the real-valued phase lies within the
+// accumulated rounding drift of an integer boundary.  Everywhere else any approximation with a known error bound has the
+// same floor.  The walkers leave an EXACT checkpoint of both chains every R = 1024 samples (k_walk_code / k_walk_carr); from
+// it every 16-sample group of the chunk gets its start state in closed form,
+//     y_g = fma(16 g, s, y_c)                      |y_g - sequential y| <= 1041 ulp(8192)/2 = 2^-31
+//     p_g = frac(fma(16 g, |d|, p_c))              |p_g - sequential p| <= 1040 x 2^-53
+// and the group is synthesised from those: the chips through the resampled-window pattern look-up of k_synth<.., RW = 1>
+// (rw_phase_a/b/c: a group whose fraction lies within 2^-22 of a pattern threshold is UNDECIDED), the carrier index through
+// the fixed-point DDA t = 2^20 + 512 + 2^-26 + 511 p advanced by t += 511 |d| (a double in [2^20, 2^21) is a fixed-point
+// number with 32 fraction bits: the high word is the table address, the low word the fraction of 511 p; a sample whose
+// fraction word is below 2^7, i.e. 511 p within 2^-26 of an integer, is UNDECIDED; the error of t against the sequential
+// phase is below 18 x 2^-33 + 2^-34 < 2^-28).  A lane that met an undecided sample appends its group to a list; k_repair_g
+// walks each listed group's exact start state out of the same checkpoint (nco_walk.h: code_walk / carr_walk_track) and
+// replays its 16 samples x all channels with the reference's statements.  About 2000 of the 19.5 million groups of a 120 s
+// batch are listed (1.7e-4 of them for a chip threshold, 6e-6 for a carrier index).
+//
+// What the layout buys over one chunk per lane: no per-lane state survives a group, so nothing is loop-carried but the
+// accumulators (k_synth: 60 VGPRs of channel state; this kernel runs four waves per SIMD instead of three); a wave's 64
+// lanes write 4 KB of CONTIGUOUS output per iteration (k_synth: 64 bursts of 64 B in 64 different places); the code wrap is
+// a matter of the window's contents, not of the sample loop (k_synth: slow groups); the chunk's checkpoints are wave-uniform
+// scalar loads (k_synth: 36 gathers per lane); neighbouring lanes read neighbouring carrier-table entries (4.7 instead of
+// 6.7 LDS cycles per gather at +-3.5 kHz).
+// The carrier checkpoints, which k_synth's exact replay verifies on its way, are verified by k_verify_carr (synth_kernels.hip)
+// on the walker stream, beside this kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nco_walk.h"
+#include "synth_dev.h"
+#include "synth_common.h"
+
+using namespace galnco;
+using namespace galdev;
+
+#ifndef SG_THREADS
+#define SG_THREADS 512  // 8 waves share one epoch's tables (54 KB of LDS): two blocks per CU, four waves per SIMD
+#endif
+#ifndef SG_WAVES_PER_EU
+#define SG_WAVES_PER_EU 4
+#endif
+#ifndef SG_AHEAD
+#define SG_AHEAD 1      // samples by which the carrier-table reads run ahead of their multiply-adds (1 or 2)
+#endif
+#define SG_CHUNK 1024   // samples per wave iteration: 64 lanes x 16
+#define SG_SYMS 64      // symbol sign masks per channel and epoch (host gate: an epoch spans fewer symbols)
+#define SG_LUT_N 1152   // entries per carrier table: 512 (mirrored phase still negative) + 511 + 129 (behind a wrap inside a group)
+#define SG_AMB 128u
+#define SG_BIAS (1049088.0 + 1.4901161193847656250e-08)  // 2^20 + 512 + 2^-26
+#define SG_MAXCH 12
+
+// What a group start needs of its channel and chunk, wave-uniform: written once per wave iteration by a LOADER lane (lane j < NCH
+// fetches channel j's checkpoint of the NEXT chunk while the wave works on the current one) into the wave's own LDS slots, read
+// back by every lane as one-address reads.  No scalar registers, nothing loop-invariant for the compiler to hoist into them.
+struct SgRec {
+    double yc;   // code phase of the chunk's first sample (pre-check, :491), in half chips: 2 x
+    double pm;   // carrier phase there, MIRRORED: times the sign of the epoch's step (k_synth: ChanState::p)
+    double s;    // code step in half chips per sample, 2 f_code delt
+    double dabs; // |f_carr delt|
+};
+typedef uint32_t sg_u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) sg_u4 *sg_lds_u4;
+typedef const __attribute__((address_space(3))) int *sg_lds_int;
+typedef const __attribute__((address_space(3))) uint32_t *sg_lds_u32;
+
+__device__ __forceinline__ uint32_t sg_min3(const uint32_t a, const uint32_t b, const uint32_t c)
+{
+    uint32_t d;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ double sg_f64(const uint32_t lo, const uint32_t hi) { return u2d(((uint64_t)hi << 32) | lo); }
+
+// One part: CNT channel positions J0 .. J0+CNT-1 of one 16-sample group, in phases, each run for all positions of the part
+// before the next one starts, so that the part waits ONCE for each round of LDS reads.  o[]: the group's int16 pairs (I, Q) as
+// they go to memory; amb: the smallest fraction word the lane has seen; undec: lanes with an undecided chip pattern.
+template <int J0, int CNT>
+__device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &undec, const double g16, const SgRec *rec, const uint32_t *sya,
+                                        const double *s_c511, const uint32_t *s_lutd,
+                                        const uint32_t *s_str, const uint2 *s_bin, const uint4 *s_pat)
+{
+    uint32_t X[CNT];
+    double t[CNT];
+    // the DDA's step 511 |d| and the table base of the part's positions: wave-uniform and constant over the epoch, but read
+    // from LDS for every group -- kept in registers for all twelve positions they would cost 36 of them
+    double c511[CNT];
+    uint32_t lutd[CNT];
+#pragma unroll
+    for (int q = 0; q < CNT; ++q) {
+        c511[q] = ((const volatile __attribute__((address_space(3))) double *)(uintptr_t)s_c511)[J0 + q];
+        lutd[q] = ((const volatile __attribute__((address_space(3))) uint32_t *)(uintptr_t)s_lutd)[J0 + q];
+    }
+    {
+        // ---- phase A: the wave's records; approximate pre-check code phase at the group start; bin entry, stream words and
+        // sign masks in flight
+        int ic0[CNT];
+        float f[CNT];
+        uint2 be[CNT];
+        uint32_t lo[CNT], hi[CNT], mcur[CNT], mnext[CNT];
+        double praw[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            const int j = J0 + q;
+            const sg_u4 r0 = ((sg_lds_u4)(uintptr_t)(rec + j))[0], r1 = ((sg_lds_u4)(uintptr_t)(rec + j))[1];
+            const uint32_t sa0 = *(sg_lds_u32)(uintptr_t)(sya + j);
+            const double A = __builtin_fma(g16, sg_f64(r1.x, r1.y), sg_f64(r0.x, r0.y));
+            const int H0 = (int)A;
+            f[q] = (float)__builtin_amdgcn_fract(A);
+            const bool wrapped = H0 >= 8184;  // the chunk's one code wrap (:491-507) lies in front of this group
+            ic0[q] = wrapped ? H0 - 8184 : H0;
+            const int bi = (int)(f[q] * (float)RW_BINS);
+            be[q] = s_bin[j * RW_BIN_PITCH + bi];
+            const uint32_t *wp = s_str + j * STR_PITCH + (ic0[q] >> 4);
+            lo[q] = wp[0];
+            hi[q] = wp[1];
+            // sign masks of the symbol in force at the group start and of its successor
+            const uint32_t sa = sa0 + (wrapped ? 4u : 0u);
+            mcur[q] = ((sg_lds_u32)(uintptr_t)sa)[0];
+            mnext[q] = ((sg_lds_u32)(uintptr_t)sa)[1];
+            praw[q] = __builtin_fma(g16, sg_f64(r1.z, r1.w), sg_f64(r0.z, r0.w));
+        }
+        // ---- phase B: threshold compare, pattern masks in flight; the carrier's DDA word meanwhile
+        uint4 M[CNT];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            const int j = J0 + q;
+            const float thr = __uint_as_float(be[q].x);
+            const uint32_t po = be[q].y + (f[q] >= thr ? 16u : 0u);
+            M[q] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_pat + j * 16) + po);
+            // undecided: the fraction too close to its bin's threshold (a NaN threshold = a bin near two of them), or to 0 / 1,
+            // where sample 0's own half chip hangs on the rounding history
+            undec |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(f[q] - thr) >= RW_DELTA) | !(__builtin_fabsf(f[q] - 0.5f) <= 0.5f - RW_DELTA));
+            const double pg = praw[q] - __builtin_trunc(praw[q]);  // (a mirrored phase that is still negative stays negative)
+            t[q] = __builtin_fma(511.0, pg, SG_BIAS);
+        }
+        // ---- phase C: window (signs applied), spread
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            uint32_t W = __builtin_amdgcn_alignbit(hi[q], lo[q], (uint32_t)ic0[q] << 1) ^ mcur[q];
+            // a window that runs over the end of the code period: the half chips behind it (the stream row continues with the
+            // period's start) carry the next symbol's signs
+            const uint32_t ms = ic0[q] > 8184 - 16 ? (~0u << (2 * (8184 - ic0[q]))) : 0u;
+            W ^= (mcur[q] ^ mnext[q]) & ms;
+            X[q] = rw_spread(window_signed(W), M[q]);
+        }
+    }
+    // ---- the 16 samples: chip value from field u of X, table address from the high word of t.  The table reads are issued
+    // SG_AHEAD samples ahead of the multiply-adds that consume them and waited for with explicit counts: written as volatile
+    // asm, because the compiler's own schedule issues two reads, waits, uses them, issues two more -- two exposed LDS latencies
+    // per sample.  (Its own wait counts stay valid: more reads in flight than it knows of only make them conservative.  No
+    // scalar-memory load is in flight here, so the LDS reads return in order.)
+    __builtin_amdgcn_sched_barrier(0);
+    int e[16][CNT];
+    uint32_t lw[16][CNT];
+#define SG_ISSUE(u)                                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < CNT; ++q) {                                                                     \
+        asm volatile("v_lshl_add_u32 %0, %1, 2, %2\n\tds_read_b32 %0, %0"                                                 \
+                     : "=&v"(e[u][q]) : "v"((uint32_t)(d2u(t[q]) >> 32)), "v"(lutd[q]) : "memory");                       \
+        lw[u][q] = (uint32_t)d2u(t[q]);                                                                                   \
+        t[q] = t[q] + c511[q];                                                                                            \
+    }
+#pragma unroll
+    for (int u = 0; u < SG_AHEAD; ++u) { SG_ISSUE(u) }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (u + SG_AHEAD < 16) { SG_ISSUE(u + SG_AHEAD) }
+        // reads of sample u have landed once no more than the ones issued behind them are outstanding
+        constexpr int kAhead = SG_AHEAD;
+        const int behind = (16 - 1 - u < kAhead ? 16 - 1 - u : kAhead) * CNT;
+        if constexpr (CNT == 1) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(amb) :: "memory");
+                                  else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e[u][0]), "+v"(amb) :: "memory");
+                                  else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[u][0]), "+v"(amb) :: "memory"); }
+        if constexpr (CNT == 2) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory");
+                                  else if (behind == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory");
+                                  else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory"); }
+        if constexpr (CNT == 3) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory");
+                                  else if (behind == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory");
+                                  else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory"); }
+        if constexpr (CNT == 4) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory");
+                                  else if (behind == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory");
+                                  else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory"); }
+        int acc = o[u];
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) gal_acc(acc, e[u][q], __builtin_amdgcn_sbfe((int)X[q], (uint32_t)(2 * u), 2));
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) amb = amb < lw[u][q] ? amb : lw[u][q];
+        o[u] = acc;
+    }
+#undef SG_ISSUE
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ACC: add onto samples already in `iq` (second and later channel groups when more than 12 channels are active)
+template <int NCH, bool ACC>
+__global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(SG_WAVES_PER_EU)))
+void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restrict__ act_all, const int *__restrict__ nact_all,
+               uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
+{
+    static_assert(NCH >= 1 && NCH <= SG_MAXCH, "1..12 channel positions per launch");
+    __shared__ uint32_t s_str[NCH * STR_PITCH];
+    __shared__ int s_lut[2 * SG_LUT_N];
+    __shared__ uint2 s_bin[NCH * RW_BIN_PITCH];
+    __shared__ uint4 s_pat[NCH * 16];
+    __shared__ float s_thr[NCH * 16];
+    __shared__ uint32_t s_sym[NCH * SG_SYMS];
+    __shared__ __attribute__((aligned(16))) SgRec s_rec[(SG_THREADS / 64) * 2 * SG_MAXCH];  // [wave][buffer][position]
+    __shared__ double s_c511[SG_MAXCH];
+    __shared__ uint32_t s_lutd[SG_MAXCH];
+    __shared__ uint32_t s_sya[(SG_THREADS / 64) * 2 * SG_MAXCH];  // ... LDS byte address of the sign mask of the chunk's first symbol
+    __shared__ int s_rwbad;
+
+    const int bpe = G.blocks_per_epoch;
+    const int er = blockIdx.x / bpe;  // epoch relative to the executed range
+    const int tg = blockIdx.x - er * bpe;
+    const int e = G.e0 + er;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+
+    // ---- phase 0 (scalar): plan pointers, the epoch's active list, slot indices
+    const int *const p_lut = Pd->lut;
+    const int *const p_prn = Pd->prn;
+    const int *const p_ib0 = Pd->ib0;
+    const uint32_t *const p_str = Pd->str;
+    const double *const p_cpx = Pd->cp_x, *const p_cpp = Pd->cp_p;
+    const uint32_t *const p_cpi = Pd->cp_ib;
+    const double *const p_cstep = Pd->cstep, *const p_dstep = Pd->dstep;
+    const uint32_t *const p_pcur = Pd->page_cur, *const p_pnext = Pd->page_next;
+    const uint32_t cs25 = Pd->cs25;
+    int *const p_ctr = Pd->ctr;
+    const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
+    const uint4 aw = *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW);
+    const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};
+    int ixs[SG_MAXCH];
+#pragma unroll
+    for (int j = 0; j < SG_MAXCH; ++j) {
+        // slot index e * S + act[j] of position j (idle positions alias slot act[0]: loads stay in bounds, results unused)
+        ixs[j] = __builtin_amdgcn_readfirstlane(e * G.S + (int)((awv[j >> 2] >> (8 * (j & 3))) & 0xffu));
+    }
+
+    // ---- phase 1: the epoch's tables in LDS
+    if (tid == 0) s_rwbad = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int prn = p_prn[ixs[j]];
+        prn = prn < 1 ? 1 : prn;  // idle position: any valid row, zeroed below
+        const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
+        const bool on = j < nact;
+        const uint32_t w0 = src[0], w1 = src[1];
+        // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window
+        // across the code wrap is one contiguous read
+        for (int t = tid; t < STR_WORDS; t += nthr) {
+            uint32_t w = src[t];
+            if (t == STR_WORDS - 1) w = (w & 0xffffu) | (w0 << 16);
+            s_str[j * STR_PITCH + t] = on ? w : 0u;
+        }
+        if (tid == 0) s_str[j * STR_PITCH + STR_WORDS] = on ? ((w0 >> 16) | (w1 << 16)) : 0u;
+    }
+    for (int i = tid; i < 2 * SG_LUT_N; i += nthr) {
+        // table (plain / conjugate) x SG_LUT_N + entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps
+        // at 1, so 511 p wraps at 511); i < 512 (mirrored phase still negative after a Doppler sign change): (int) truncates
+        // towards zero (:509), so entry i holds k = i - 511
+        const int tab = i >= SG_LUT_N, ii = i - tab * SG_LUT_N;
+        int k = ii < 512 ? ii - 511 : ii - 512;
+        k = k >= 511 ? k - 511 : k;
+        k = k >= 511 ? k - 511 : k;
+        s_lut[i] = p_lut[(tab ? -k : k) & 511];
+    }
+    // symbol sign masks: entry k = the XOR mask (sg x 0x55555555, sg = (data ^ secondary) | secondary << 1) of the k-th symbol
+    // after the one in force at the epoch start; data symbol = page bit, secondary = CS25[ibit % 25] (:517-518); the page
+    // changes when the symbol counter wraps inside the epoch (:497-506)
+    for (int i = tid; i < NCH * SG_SYMS; i += nthr) {
+        const int j = i / SG_SYMS, k = i - j * SG_SYMS;
+        int ix = 0;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) ix = j == q ? ixs[q] : ix;
+        int ibit = p_ib0[ix] + k;
+        const bool nx = ibit >= GAL_N_SYM_PAGE;
+        ibit = nx ? ibit - GAL_N_SYM_PAGE : ibit;
+        const uint32_t *pg = (nx ? p_pnext : p_pcur) + (size_t)ix * GAL_PAGE_WORDS;
+        const uint32_t dbit = (pg[ibit >> 5] >> (ibit & 31)) & 1u;
+        const uint32_t sbit = (cs25 >> (ibit % 25)) & 1u;
+        const uint32_t sg = (dbit ^ sbit) | (sbit << 1);
+        s_sym[i] = j < nact ? sg * 0x55555555u : 0u;
+    }
+    double rw_s[NCH];  // the channels' code steps in half chips (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) rw_s[j] = j < nact ? uniform_f64(2.0 * p_cstep[ixs[j]]) : 0.0;
+    auto rw_step_of = [&](const int jj) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) v = jj == j ? rw_s[j] : v;
+        return v;
+    };
+    // the DDA's step 511 |d| and the table base (plain / conjugate table minus the exponent field of [2^20, 2^21) << 2, so that
+    // the address is ONE shift-add of t's high word) of every position
+    if (tid < SG_MAXCH) {
+        int ix = 0;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) ix = tid == q ? ixs[q] : ix;
+        const double d = (tid < NCH && tid < nact) ? p_dstep[ix] : 0.0;
+        s_c511[tid] = 511.0 * __builtin_fabs(d);
+        s_lutd[tid] = (uint32_t)(uintptr_t)(sg_lds_int)s_lut + (((uint32_t)(d2u(d) >> 32) >> 31) ? SG_LUT_N * 4u : 0u) - (0x41300000u << 2);
+    }
+    // ---- hold patterns (k_synth<.., RW = 1>, rw_phase_a): step A, the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted
+    for (int t = tid; t < NCH * 16; t += nthr) {
+        const int j = t >> 4, u = (t & 15) + 1;
+        const double s = rw_step_of(j);
+        if (u <= 15) {
+            const double us = (double)u * s;
+            const double T = 1.0 - (us - __builtin_floor(us));
+            int rank = 0;
+            for (int v = 1; v <= 15; ++v) {
+                const double vs = (double)v * s;
+                const double Tv = 1.0 - (vs - __builtin_floor(vs));
+                rank += (Tv < T) || (Tv == T && v < u);
+            }
+            s_thr[j * 16 + rank] = (float)T;
+        } else {
+            s_thr[j * 16 + 15] = 2.0f;
+        }
+    }
+    __syncthreads();
+    // ---- step B: the bin tables (NCH x 129 entries) and the 16 patterns of each channel
+    for (int t = tid; t < NCH * (RW_BINS + 1); t += nthr) {
+        const int j = t / (RW_BINS + 1), b = t - j * (RW_BINS + 1);
+        const float lo = (float)b * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / RW_BINS) + RW_EDGE;
+        int cnt = 0, idb = 0;
+        float thr = 4.0f;  // "no threshold near this bin": never reached, never close
+        for (int i = 0; i < 15; ++i) {
+            const float th = s_thr[j * 16 + i];
+            idb += th < lo;
+            const bool in = th >= lo && th < hi;
+            cnt += in;
+            thr = in ? th : thr;
+        }
+        if (cnt >= 2 || b == RW_BINS) thr = __builtin_nanf("");  // undecidable here
+        if (j >= nact) { thr = 4.0f; idb = 0; }
+        s_bin[j * RW_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
+    }
+    for (int t = tid; t < NCH * 16; t += nthr) {
+        const int j = t >> 4, id = t & 15;  // id = number of thresholds <= f
+        const double s = rw_step_of(j);
+        const double Tlo = id ? (double)s_thr[j * 16 + id - 1] : 0.0;
+        double Thi = (double)s_thr[j * 16 + id];
+        Thi = Thi > 1.0 ? 1.0 : Thi;
+        const double f = 0.5 * (Tlo + Thi);
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+        int d = 0;
+        double gp = 0.0;  // floor(f), f < 1
+        for (int u = 1; u <= 15; ++u) {
+            const double g = __builtin_floor(f + (double)u * s);
+            if (g == gp) {  // sample u HOLDS the half chip of sample u - 1
+                const uint32_t m = ~0u << (2 * u);
+                m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
+                ++d;
+            }
+            gp = g;
+        }
+        if (j >= nact) m0 = m1 = m2 = m3 = 0u;
+        else if (d > 4) s_rwbad = 1;  // more holds than the masks carry (the host's gate excludes it): every group is listed
+        s_pat[t] = make_uint4(m0, m1, m2, m3);
+    }
+    __syncthreads();
+    const bool rw_off = __builtin_amdgcn_readfirstlane(s_rwbad) != 0;
+
+    // ---- the block's chunks: wave w of the block takes chunks tg * nw + w, + bpe * nw, ...
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int nw = nthr >> 6;
+    const double g16 = (double)(16 * lane);
+    // loader lanes: lane j < NCH fetches position j's checkpoint (idle positions alias slot act[0], see ixs)
+    const int jl = lane < NCH ? lane : NCH - 1;
+    int ixl = 0;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) ixl = jl == q ? ixs[q] : ixl;
+    const bool onl = jl < nact;
+    const size_t cpl = (size_t)ixl * G.CP1;
+    const double dl = onl ? p_dstep[ixl] : 0.0;
+    const double sl = onl ? 2.0 * p_cstep[ixl] : 0.0, dabsl = __builtin_fabs(dl);
+    const uint32_t dsgnl = (uint32_t)(d2u(dl) >> 32) & 0x80000000u;
+    // LDS byte address of the position's symbol masks, minus 4 x the symbol counter at the epoch start (idle: an all-zero row)
+    const uint32_t symbl = (uint32_t)(uintptr_t)(sg_lds_u32)s_sym + (uint32_t)jl * (SG_SYMS * 4u) - (onl ? (uint32_t)p_ib0[ixl] * 4u : 0u);
+    SgRec *const recw = s_rec + wv * 2 * SG_MAXCH;
+    uint32_t *const syaw = s_sya + wv * 2 * SG_MAXCH;
+    const int cstep_w = bpe * nw;
+    int c = __builtin_amdgcn_readfirstlane(tg * nw + wv);
+    // checkpoint of chunk cc: x (pre-check code phase, chips), p (carrier phase), ibit | flipped << 16
+    double lx = 0.0, lp = 0.0;
+    uint32_t lib = 0u;
+    auto fetch = [&](const int cc) {
+        const int ce = cc < G.nchunks ? cc : G.nchunks - 1;
+        lx = p_cpx[cpl + ce];
+        lp = p_cpp[cpl + ce];
+        lib = p_cpi[cpl + ce];
+    };
+    auto stage = [&](const int buf) {
+        SgRec r;
+        r.yc = lx + lx;
+        r.pm = u2d(d2u(lp) ^ ((uint64_t)dsgnl << 32));
+        r.s = sl;
+        r.dabs = dabsl;
+        if (lane < NCH) {
+            recw[buf * SG_MAXCH + lane] = r;
+            // (idle positions: steps zero, stream row zero, sign masks zero -- no contribution whatever the aliased checkpoint
+            // holds; an undecided group listed on their account costs a replay, nothing else)
+            syaw[buf * SG_MAXCH + lane] = symbl + (onl ? ((lib & 0xffffu) + 500u * (lib >> 16)) * 4u : 0u);
+        }
+    };
+    fetch(c);
+    int buf = 0;
+    for (; c < G.nchunks; c += cstep_w, buf ^= 1) {
+        stage(buf);
+        fetch(c + cstep_w);  // in flight while this chunk is synthesised
+        const int n0 = c * SG_CHUNK;
+        const int nsteps = G.N - n0 - 16 * lane;  // samples of this lane's group inside the epoch
+        if (nsteps > 0) {
+        uint32_t *out = iq + (size_t)er * G.N + n0 + 16 * lane;  // iq holds the executed range only
+        const bool vec_ok = ((((size_t)er * G.N + n0) & 3) == 0) && nsteps >= 16;
+        int o[16];
+        if (ACC) {
+            if (vec_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(out + 4 * q);
+                    o[4 * q] = (int)v.x; o[4 * q + 1] = (int)v.y; o[4 * q + 2] = (int)v.z; o[4 * q + 3] = (int)v.w;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) o[u] = u < nsteps ? (int)out[u] : 0;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) o[u] = 0;
+        }
+        uint32_t amb = ~0u;
+        uint64_t undec = rw_off ? ~0ull : 0ull;
+        const SgRec *rec = recw + buf * SG_MAXCH;
+        const uint32_t *sya = syaw + buf * SG_MAXCH;
+        // balanced parts: 5, 6, 7, 9, 10, 11 positions are cut 3+2, 3+3, 4+3, 3+3+3, 4+3+3, 4+4+3
+#define SG_PART(J0, CNT) sg_part<J0, CNT>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat); \
+                         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NCH <= 4) { SG_PART(0, NCH) }
+        else if constexpr (NCH == 5) { SG_PART(0, 3) SG_PART(3, 2) }
+        else if constexpr (NCH == 6) { SG_PART(0, 3) SG_PART(3, 3) }
+        else if constexpr (NCH == 7) { SG_PART(0, 4) SG_PART(4, 3) }
+        else if constexpr (NCH == 8) { SG_PART(0, 4) SG_PART(4, 4) }
+        else if constexpr (NCH == 9) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 3) }
+        else if constexpr (NCH == 10) { SG_PART(0, 4) SG_PART(4, 3) SG_PART(7, 3) }
+        else if constexpr (NCH == 11) { SG_PART(0, 4) SG_PART(4, 4) SG_PART(8, 3) }
+        else { SG_PART(0, 4) SG_PART(4, 4) SG_PART(8, 4) }
+#undef SG_PART
+        if (vec_ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4 *>(out + 4 * q) = make_uint4((uint32_t)o[4 * q], (uint32_t)o[4 * q + 1], (uint32_t)o[4 * q + 2], (uint32_t)o[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < nsteps) out[u] = (uint32_t)o[u];
+        }
+        if (((undec >> lane) & 1ull) | (amb < SG_AMB)) {  // undecided: k_repair_g replays the group exactly
+            const int slot = atomicAdd(p_ctr + CTR_GFLAGS, 1);
+            if (slot < flist_cap) flist[slot] = ((uint32_t)er * (uint32_t)G.nchunks + (uint32_t)c) * 64u + (uint32_t)lane;
+        }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_repair_g: the listed groups once more, with the reference's statements (:489-533) from their EXACT start state -- the
+// chunk's checkpoint advanced by 16 g samples in closed form (nco_walk.h) -- for ALL active channels of the epoch (every
+// channel group of a > 12-channel batch), written over what the synthesis launches left.  A row of 16 lanes takes one
+// group: lane r the slots r, r + 16, ..; the row then sums its 16 x (I, Q) and lane u stores sample u (:536-537).
+__global__ void k_repair_g(DevPlan P, SynGeom G, uint32_t *__restrict__ iq, const uint32_t *__restrict__ flist, const int flist_cap)
+{
+    const int n_raw = P.ctr[CTR_GFLAGS];
+    const int n = n_raw < flist_cap ? n_raw : flist_cap;
+    if (n_raw > flist_cap && blockIdx.x == 0 && threadIdx.x == 0) P.ctr[CTR_GOVER] = 1;  // gal_synth_finish repeats the batch exactly
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = threadIdx.x & 15;
+    const int nrows = (gridDim.x * blockDim.x) >> 4;
+    for (int i = gt >> 4; i < n; i += nrows) {
+        const uint32_t ent = flist[i];
+        const int g = (int)(ent & 63u);
+        const uint32_t ec = ent >> 6;
+        const int er = (int)(ec / (uint32_t)G.nchunks), c = (int)(ec - (uint32_t)er * (uint32_t)G.nchunks);
+        const int e = G.e0 + er;
+        const int n0 = c * G.R + 16 * g;
+        int cnt = G.N - n0;
+        cnt = cnt > 16 ? 16 : cnt;
+        int aI[16], aQ[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) aI[u] = aQ[u] = 0;
+        for (int s = r; s < G.S; s += 16) {
+            const int idx = e * G.S + s;
+            const int prn = P.prn[idx];
+            if (prn <= 0) continue;
+            const size_t cp = (size_t)idx * G.CP1 + c;
+            const double cst = P.cstep[idx], d = P.dstep[idx];
+            const uint32_t cib = P.cp_ib[cp];
+            const CodeEnd ce = code_walk(P.cp_x[cp], (int)(cib & 0xffffu), cst, 1.0 / cst, 16 * g, 1 << 30, [](int, double, int, int) {});
+            double x = ce.x;
+            int ibit = ce.ibit;
+            int flipped = (int)(cib >> 16) | ce.flipped;
+            double p = carr_walk_track(P.cp_p[cp], d, 1.0 / __builtin_fabs(d), 16 * g, 16 * g + 1, 16 * g + 1, [](int, double) {}).p;
+            const uint32_t *str = P.str + (size_t)(prn - 1) * STR_WORDS;
+            for (int u = 0; u < cnt; ++u) {
+                if (x >= 4092.0) {  // :491-507
+                    x -= 4092.0;
+                    ibit++;
+                    if (ibit >= GAL_N_SYM_PAGE) {
+                        ibit = 0;
+                        flipped = 1;
+                    }
+                }
+                const int k = ((int)(511.0 * p)) & 511;  // :509-510
+                const int icode = (int)(x * 2.0);        // :512
+                // stream field of half chip h: bit 0 = E1B ^ E1C chip, bit 1 = E1C chip ^ (h & 1); a chip bit 1 is the
+                // value -1, and the BOC(1,1) sub-carrier makes the even half chip -chip, the odd one +chip
+                // (src/gal-sig.cpp:9-233)
+                const uint32_t fld = (str[icode >> 4] >> (2 * (icode & 15))) & 3u;
+                const uint32_t cbit = (fld >> 1) ^ ((uint32_t)icode & 1u), bbit = (fld & 1u) ^ cbit;
+                const int sub = (icode & 1) ? 1 : -1;
+                const int E1B_chip = sub * (bbit ? -1 : 1), E1C_chip = sub * (cbit ? -1 : 1);
+                const uint32_t *pg = (flipped ? P.page_next : P.page_cur) + (size_t)idx * GAL_PAGE_WORDS;
+                const int databit = ((pg[ibit >> 5] >> (ibit & 31)) & 1u) ? -1 : 1;   // :517
+                const int secCode = ((P.cs25 >> (ibit % 25)) & 1u) ? -1 : 1;          // :518
+                const int v = E1B_chip * databit - E1C_chip * secCode;               // :520-521, in {-2, 0, 2}
+                const int ent2 = P.lut[k];  // int16 pair (2 cos, 2 sin)
+                aI[u] += (v / 2) * (int)(short)(ent2 & 0xffff);
+                aQ[u] += (v / 2) * (int)(short)((uint32_t)ent2 >> 16);
+                x = x + cst;           // :528
+                p = carr_step(p, d);   // :531-532
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int I = aI[u], Q = aQ[u];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) {
+                I += __shfl_xor(I, m, 16);
+                Q += __shfl_xor(Q, m, 16);
+            }
+            if (r == u && u < cnt) iq[(size_t)er * G.N + n0 + u] = ((uint32_t)(uint16_t)(short)I) | ((uint32_t)(uint16_t)(short)Q << 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool ACC>
+static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
+                            int ne, hipStream_t st, const SynGeom &G)
+{
+    const dim3 grid(ne * G.blocks_per_epoch), block(SG_THREADS);
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
+    switch (nch) {
+        GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
+        GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
+    default: return -1;
+    }
+#undef GAL_CASE
+    return 0;
+}
+
+static SynGeom sg_geom(const DevPlan *P, int e0)
+{
+    SynGeom G;
+    G.e0 = e0;
+    G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1;
+    G.blocks_per_epoch = P->gbpe > 0 ? P->gbpe : 1;
+    G.cls = 1;
+    G.per = P->nchunks;
+    return G;
+}
+
+__global__ void k_warm_g() {}
+extern "C" void galk_warm_g(hipStream_t st) { hipLaunchKernelGGL(k_warm_g, dim3(1), dim3(64), 0, st); }
+
+extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act, const int *nact,
+                                   uint32_t *iq, int e0, int ne, hipStream_t st)
+{
+    if (P->R != SG_CHUNK) return -2;
+    const SynGeom G = sg_geom(P, e0);
+    return accumulate ? launch_synth_g_t<true>(P, Pd, nch, act, nact, iq, e0, ne, st, G)
+                      : launch_synth_g_t<false>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+}
+
+// behind the last synthesis launch of the batch, same stream
+extern "C" void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hipStream_t st)
+{
+    const SynGeom G = sg_geom(P, e0);
+    hipLaunchKernelGGL(k_repair_g, dim3(128), dim3(256), 0, st, *P, G, iq, P->gflist, P->gflist_cap);
+}

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libgalsynth.so")
 # the same sources built with -DGAL_TEST_HOOKS (fault injection for the repair-path tests; tests only)
 HOOKS_LIB_PATH = os.path.join(PKG_DIR, "libgalsynth_hooks.so")
 GAL_CFG_SINGLE_STREAM = 1
+GAL_CFG_EXACT_REPLAY = 4  # always the exact-replay kernel (k_synth), also where k_synth_g could run
 GAL_CFG_CBOC = 2  # opt-in CBOC(6,1,1/11) sub-carrier (not in the reference; defined by the oracle's CBOC mode)
 
 GAL_CH_RESTART = 1
@@ -71,6 +72,8 @@ class _Stats(ctypes.Structure):
         ("ms_synth", ctypes.c_float),
         ("window_mode", ctypes.c_int32),
         ("synth_runs", ctypes.c_int32),
+        ("kernel_family", ctypes.c_int32),
+        ("repaired_groups", ctypes.c_int32),
     ]
 
 

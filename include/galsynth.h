@@ -94,6 +94,11 @@ typedef struct gal_synth_cfg {
                                         I += sc_A (B - C) TAcos[k] + sc_B (B + C) TBcos[k]      (Q with the sin tables)
                                     TA = lround(sqrt(10/11) x cosTable512 / sinTable512), TB = lround(sqrt(1/11) x ...);
                                     everything else (wrap, symbol, page, NCO updates, int16 store) as src/galileo-sdr.cpp:481-539 */
+#define GAL_CFG_EXACT_REPLAY 4u  /* always synthesise with the exact-replay kernel (every lane steps the reference's two NCO
+                                    recurrences sample by sample and checks its end state against the next checkpoint), also where
+                                    the default kernel of the reference geometry -- 16-sample groups from closed-form start
+                                    states, undecided groups replayed exactly -- could run.  Same bits either way; this one is
+                                    slower and carries the replay self-check (gal_synth_stats_t.kernel_family says which ran) */
 #define GAL_CFG_SINGLE_STREAM 1u /* enqueue every kernel on the handle's stream (no internal high-priority walker
                                     streams): for callers that capture or serialise the stream themselves       */
 
@@ -110,11 +115,14 @@ typedef struct gal_synth_stats {
                                    16 samples; 1: 0.74 <= 2 f_code / fs < 1, as at the reference's 2.6 MS/s; 2: 2 f_code / fs
                                    <= 0.133, sample rates from 15.4 MS/s; 3: <= 0.266, from 7.7 MS/s; all need well
                                    separated pattern thresholds), 0 per-sample window index (any rate).  Same bits either way.
-                                   + 16: form 1 with the carrier table index from a fixed-point DDA (opt-in: environment
-                                   GAL_CARRIER_DDA=1; the waves that meet an uncertain index are synthesised again with the
-                                   exact phase -- same bits again)                                                          */
+                                                                                                                            */
     int32_t synth_runs;         /* synthesis launches the last batch took: 1, or 2 when gal_synth_finish() had to repeat
                                    it (carrier chain not complete when the kernel was started, or the replay check failed) */
+    int32_t kernel_family;      /* 0: exact replay, one chunk of ~1000 samples per lane (any rate, any signal); 1: one 16-sample
+                                   group per lane, start states in closed form from the chunk's exact checkpoint, groups whose
+                                   chip pattern or table index hangs on the rounding history replayed exactly afterwards
+                                   (BOC(1,1), 0.74 <= 2 f_code / fs < 1 -- the reference's 2.6 MS/s; the default there)      */
+    int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
 } gal_synth_stats_t;
 
 typedef struct gal_synth gal_synth_t;
