@@ -20,6 +20,19 @@
 // rw_phase_a): the kernel's bin table (128 bins of the group-start fraction) decides a lane only if its bin holds ONE
 // threshold, so every pair must be more than a bin (plus the registration margin) apart -- true for 2.6 MS/s (0.017),
 // false where 2.046 MHz / fs is close to a fraction with a denominator below 16 (2.5 MS/s: 9/11, 2.728 MS/s: 3/4).
+// ... and, for k_synth_g (whose group-start phase is approximate: 0 and 1 are thresholds of sample 0's own half chip there), the
+// smallest distance of a pattern threshold to 0 or 1
+static double rw_threshold_edge(double s)
+{
+    double g = 1.0;
+    for (int u = 1; u <= 15; ++u) {
+        const double us = (double)u * s;
+        const double t = 1.0 - (us - std::floor(us));
+        g = std::min(g, std::min(t, 1.0 - t));
+    }
+    return g;
+}
+
 static double rw_threshold_gap(double s)
 {
     double T[15];
@@ -165,7 +178,7 @@ struct gal_synth {
     int enq_passes = kDefaultPasses;  // carrier passes the next execute enqueues (see kDefaultPasses)
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
     // their smallest distance (rw_threshold_gap) -- reused only for the identical step
-    std::vector<double> rw_s0, rw_g0;
+    std::vector<double> rw_s0, rw_g0, rw_e0;
 };
 
 // The stream the handle works on: the caller's (gal_synth_set_stream), or one of its own, made at first need.
@@ -423,7 +436,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                         // ON an index boundary would have every one of its groups listed for the exact replay
     int rw_mode = 0;  // 1: holds (code step 0.74 .. 1 half chips per sample), 2: <= 2 advances (<= 0.133), 3: <= 4 advances
                       // (<= 0.266); one form per batch
-    if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); }
+    if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); h->rw_e0.assign(S, 0.0); }
     const double delt = 1.0 / h->cfg.sample_rate;
     const bool cboc = (h->cfg.flags & GAL_CFG_CBOC) != 0;
     for (int e = 0; e < E; ++e) {
@@ -470,10 +483,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 if (rw_ok && cs2 != h->rw_s0[s]) {
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
+                    h->rw_e0[s] = mode == 1 ? rw_threshold_edge(cs2) : 0.0;
                     // CBOC: the half-period parity pattern steps by 6 s per sample; only the hold form (1) exists there
                     if (cboc) h->rw_g0[s] = mode == 1 ? std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2)) : 0.0;
                 }
                 if (rw_ok) rw_ok = h->rw_g0[s] > (cboc ? kRwMinGapCboc : kRwMinGap);
+                if (rw_ok && g_ok) g_ok = h->rw_e0[s] > kRwMinGap;
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;
@@ -687,11 +702,29 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.fam = fam_g ? 1 : 0;
     P.gflist = (uint32_t *)(base + o_gflist);
     P.gflist_cap = kGroupListCap;
+#ifdef GAL_TEST_HOOKS
+    if (const char *env = getenv("GAL_G_LIST_CAP")) P.gflist_cap = std::max(1, std::min(kGroupListCap, atoi(env)));  // overflow path
+#endif
     {
-        // k_synth_g: a block of 8 waves takes an epoch's chunks; short batches are cut finer so that every CU gets one
-        int bpe = 1;
-        while (E * bpe < 512 && bpe * 8 < nchunks) bpe *= 2;
-        P.gbpe = bpe;
+        // k_synth_g: a block takes an epoch's chunks (or 1 / bpe of them), its waves one chunk at a time.  Block size and cut
+        // are chosen for the shortest tail: `slots` blocks run at a time, a batch of B blocks takes ceil(B / slots) rounds of
+        // (1 + 0.06 bpe) / bpe epoch times (the block's tables cost about 6 % of an epoch's samples to build)
+        int best_thr = 512, best_bpe = 1;
+        double best = 1e30;
+        for (int thr = 512; thr <= 1024; thr *= 2) {
+            const int slots = 256 * (1024 / thr), waves = thr / 64;
+            for (int bpe = 1; bpe <= 64 && (bpe == 1 || bpe * waves <= nchunks); bpe *= 2) {
+                const double rounds = std::ceil((double)E * bpe / slots);
+                const double cost = rounds * (1.0 / bpe + 0.06 * (thr == 1024 ? 0.7 : 1.0));
+                if (cost < best - 1e-9) { best = cost; best_thr = thr; best_bpe = bpe; }
+            }
+        }
+        P.gthreads = best_thr;
+        P.gbpe = best_bpe;
+#ifdef GAL_TEST_HOOKS
+        if (const char *env = getenv("GAL_G_THREADS")) P.gthreads = atoi(env) == 1024 ? 1024 : 512;
+        if (const char *env = getenv("GAL_G_BPE")) P.gbpe = atoi(env) > 0 ? atoi(env) : P.gbpe;
+#endif
     }
 
     P.lut = h->d_lut; P.str = h->d_str;

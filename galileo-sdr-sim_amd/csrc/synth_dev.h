@@ -86,6 +86,7 @@ struct DevPlan {
     int fam;              // synthesis kernel family: 0 k_synth (one chunk per lane, exact replay), 1 k_synth_g (one 16-sample group per
                           // lane from the chunk's checkpoint in closed form + k_repair_g for the undecided groups; synth_group.hip)
     int gbpe;             // k_synth_g: blocks per epoch
+    int gthreads;         // k_synth_g: threads per block (512 or 1024)
     uint32_t *gflist;     // k_synth_g -> k_repair_g: the undecided groups, (epoch in range * nchunks + chunk) * 64 + group
     int gflist_cap;
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)

@@ -40,7 +40,8 @@ using namespace galnco;
 using namespace galdev;
 
 #ifndef SG_THREADS
-#define SG_THREADS 512  // 8 waves share one epoch's tables (54 KB of LDS): two blocks per CU, four waves per SIMD
+#define SG_THREADS 1024  // largest block: 16 waves share one epoch's tables (58 KB of LDS).  The launch picks 512 (two blocks per CU)
+                         // or 1024 (one): four waves per SIMD either way
 #endif
 #ifndef SG_WAVES_PER_EU
 #define SG_WAVES_PER_EU 4
@@ -49,7 +50,10 @@ using namespace galdev;
 #define SG_AHEAD 1      // samples by which the carrier-table reads run ahead of their multiply-adds (1 or 2)
 #endif
 #define SG_CHUNK 1024   // samples per wave iteration: 64 lanes x 16
-#define SG_SYMS 64      // symbol sign masks per channel and epoch (host gate: an epoch spans fewer symbols)
+#define SG_SYMS 64      // symbol sign pairs per channel and epoch (host gate: an epoch spans fewer symbols)
+#define SG_STR_PITCH 580  // LDS words per stream row: the 8184 half chips of the period, then its first 1088 once more -- a chunk
+                          // starts below the code wrap and advances by < 1008 half chips, so no window index ever wraps
+#define SG_MPOS 17      // sign-mask table: positions of the code wrap relative to a window (0: behind it .. 16: in front of it)
 #define SG_LUT_N 1152   // entries per carrier table: 512 (mirrored phase still negative) + 511 + 129 (behind a wrap inside a group)
 #define SG_AMB 128u
 #define SG_BIAS (1049088.0 + 1.4901161193847656250e-08)  // 2^20 + 512 + 2^-26
@@ -103,7 +107,7 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         int ic0[CNT];
         float f[CNT];
         uint2 be[CNT];
-        uint32_t lo[CNT], hi[CNT], mcur[CNT], mnext[CNT];
+        uint32_t lo[CNT], hi[CNT], mask[CNT];
         double praw[CNT];
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
@@ -111,19 +115,19 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
             const sg_u4 r0 = ((sg_lds_u4)(uintptr_t)(rec + j))[0], r1 = ((sg_lds_u4)(uintptr_t)(rec + j))[1];
             const uint32_t sa0 = *(sg_lds_u32)(uintptr_t)(sya + j);
             const double A = __builtin_fma(g16, sg_f64(r1.x, r1.y), sg_f64(r0.x, r0.y));
-            const int H0 = (int)A;
+            ic0[q] = (int)A;  // < 8184 + 1008: the row continues behind the period's end (:491-507 is a matter of the signs)
             f[q] = (float)__builtin_amdgcn_fract(A);
-            const bool wrapped = H0 >= 8184;  // the chunk's one code wrap (:491-507) lies in front of this group
-            ic0[q] = wrapped ? H0 - 8184 : H0;
             const int bi = (int)(f[q] * (float)RW_BINS);
             be[q] = s_bin[j * RW_BIN_PITCH + bi];
-            const uint32_t *wp = s_str + j * STR_PITCH + (ic0[q] >> 4);
+            const uint32_t *wp = s_str + j * SG_STR_PITCH + (ic0[q] >> 4);
             lo[q] = wp[0];
             hi[q] = wp[1];
-            // sign masks of the symbol in force at the group start and of its successor
-            const uint32_t sa = sa0 + (wrapped ? 4u : 0u);
-            mcur[q] = ((sg_lds_u32)(uintptr_t)sa)[0];
-            mnext[q] = ((sg_lds_u32)(uintptr_t)sa)[1];
+            // XOR mask of the data / secondary-code signs (:517-518) on the window's 16 half chips: the chunk's first symbol
+            // up to the code wrap, its successor behind it -- one table row per pair of sign pairs, one entry per position of
+            // the wrap relative to the window
+            int pos;
+            asm("v_med3_i32 %0, %1, 0, 16" : "=v"(pos) : "v"(ic0[q] - (8184 - 16)));
+            mask[q] = *(sg_lds_u32)(uintptr_t)(sa0 + ((uint32_t)pos << 2));
             praw[q] = __builtin_fma(g16, sg_f64(r1.z, r1.w), sg_f64(r0.z, r0.w));
         }
         // ---- phase B: threshold compare, pattern masks in flight; the carrier's DDA word meanwhile
@@ -134,20 +138,16 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
             const float thr = __uint_as_float(be[q].x);
             const uint32_t po = be[q].y + (f[q] >= thr ? 16u : 0u);
             M[q] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_pat + j * 16) + po);
-            // undecided: the fraction too close to its bin's threshold (a NaN threshold = a bin near two of them), or to 0 / 1,
-            // where sample 0's own half chip hangs on the rounding history
-            undec |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(f[q] - thr) >= RW_DELTA) | !(__builtin_fabsf(f[q] - 0.5f) <= 0.5f - RW_DELTA));
+            // undecided: the fraction too close to its bin's threshold (a NaN threshold = a bin near two of them); 0 and 1 are
+            // thresholds of the first and the last bin, because sample 0's own half chip hangs on the rounding history there
+            undec |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(f[q] - thr) >= RW_DELTA));
             const double pg = praw[q] - __builtin_trunc(praw[q]);  // (a mirrored phase that is still negative stays negative)
             t[q] = __builtin_fma(511.0, pg, SG_BIAS);
         }
         // ---- phase C: window (signs applied), spread
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
-            uint32_t W = __builtin_amdgcn_alignbit(hi[q], lo[q], (uint32_t)ic0[q] << 1) ^ mcur[q];
-            // a window that runs over the end of the code period: the half chips behind it (the stream row continues with the
-            // period's start) carry the next symbol's signs
-            const uint32_t ms = ic0[q] > 8184 - 16 ? (~0u << (2 * (8184 - ic0[q]))) : 0u;
-            W ^= (mcur[q] ^ mnext[q]) & ms;
+            const uint32_t W = __builtin_amdgcn_alignbit(hi[q], lo[q], (uint32_t)ic0[q] << 1) ^ mask[q];
             X[q] = rw_spread(window_signed(W), M[q]);
         }
     }
@@ -204,7 +204,8 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
                uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
 {
     static_assert(NCH >= 1 && NCH <= SG_MAXCH, "1..12 channel positions per launch");
-    __shared__ uint32_t s_str[NCH * STR_PITCH];
+    __shared__ uint32_t s_str[NCH * SG_STR_PITCH];
+    __shared__ uint32_t s_mtab[16 * SG_MPOS];  // [sign pair of the first symbol * 4 + of its successor][position of the wrap]
     __shared__ int s_lut[2 * SG_LUT_N];
     __shared__ uint2 s_bin[NCH * RW_BIN_PITCH];
     __shared__ uint4 s_pat[NCH * 16];
@@ -252,15 +253,21 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         prn = prn < 1 ? 1 : prn;  // idle position: any valid row, zeroed below
         const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
         const bool on = j < nact;
-        const uint32_t w0 = src[0], w1 = src[1];
-        // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window
+        // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window at or
         // across the code wrap is one contiguous read
-        for (int t = tid; t < STR_WORDS; t += nthr) {
-            uint32_t w = src[t];
-            if (t == STR_WORDS - 1) w = (w & 0xffffu) | (w0 << 16);
-            s_str[j * STR_PITCH + t] = on ? w : 0u;
+        for (int t = tid; t < SG_STR_PITCH; t += nthr) {
+            uint32_t w;
+            if (t < STR_WORDS - 1) w = src[t];
+            else if (t == STR_WORDS - 1) w = (src[t] & 0xffffu) | (src[0] << 16);
+            else w = (src[t - STR_WORDS] >> 16) | (src[t - STR_WORDS + 1] << 16);
+            s_str[j * SG_STR_PITCH + t] = on ? w : 0u;
         }
-        if (tid == 0) s_str[j * STR_PITCH + STR_WORDS] = on ? ((w0 >> 16) | (w1 << 16)) : 0u;
+    }
+    for (int i = tid; i < 16 * SG_MPOS; i += nthr) {
+        const int pair = i / SG_MPOS, pos = i - pair * SG_MPOS;
+        const uint32_t mc = (uint32_t)(pair >> 2) * 0x55555555u, mn = (uint32_t)(pair & 3) * 0x55555555u;
+        // pos = clamp(first half chip of the window - (8184 - 16), 0, 16): the fields from 16 - pos on lie behind the wrap
+        s_mtab[i] = pos == 0 ? mc : pos == 16 ? mn : (mc ^ ((mc ^ mn) & (~0u << (2 * (16 - pos)))));
     }
     for (int i = tid; i < 2 * SG_LUT_N; i += nthr) {
         // table (plain / conjugate) x SG_LUT_N + entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps
@@ -272,9 +279,9 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         k = k >= 511 ? k - 511 : k;
         s_lut[i] = p_lut[(tab ? -k : k) & 511];
     }
-    // symbol sign masks: entry k = the XOR mask (sg x 0x55555555, sg = (data ^ secondary) | secondary << 1) of the k-th symbol
-    // after the one in force at the epoch start; data symbol = page bit, secondary = CS25[ibit % 25] (:517-518); the page
-    // changes when the symbol counter wraps inside the epoch (:497-506)
+    // symbol sign pairs: entry k = sg = (data ^ secondary) | secondary << 1 of the k-th symbol after the one in force at the
+    // epoch start (the XOR mask of a symbol on its half chips is sg x 0x55555555); data symbol = page bit, secondary =
+    // CS25[ibit % 25] (:517-518); the page changes when the symbol counter wraps inside the epoch (:497-506)
     for (int i = tid; i < NCH * SG_SYMS; i += nthr) {
         const int j = i / SG_SYMS, k = i - j * SG_SYMS;
         int ix = 0;
@@ -287,7 +294,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         const uint32_t dbit = (pg[ibit >> 5] >> (ibit & 31)) & 1u;
         const uint32_t sbit = (cs25 >> (ibit % 25)) & 1u;
         const uint32_t sg = (dbit ^ sbit) | (sbit << 1);
-        s_sym[i] = j < nact ? sg * 0x55555555u : 0u;
+        s_sym[i] = j < nact ? sg : 0u;
     }
     double rw_s[NCH];  // the channels' code steps in half chips (wave-uniform)
 #pragma unroll
@@ -340,9 +347,15 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
             cnt += in;
             thr = in ? th : thr;
         }
+        // 0 and 1 are thresholds too -- of sample 0's own half chip, which the approximate phase decides only away from them
+        // (k_synth knows its group-start phase exactly): bin 0 compares with 0 (never below it: the pattern offset makes up
+        // for the unconditional "f >= threshold"), the last bin with 1; a pattern threshold beside them leaves the bin undecidable
+        uint32_t off = (uint32_t)idb * 16u;
+        if (b == 0) { thr = cnt ? __builtin_nanf("") : 0.0f; off -= 16u; cnt = 0; }
+        if (b == RW_BINS - 1) { thr = cnt ? __builtin_nanf("") : 1.0f; cnt = 0; }
         if (cnt >= 2 || b == RW_BINS) thr = __builtin_nanf("");  // undecidable here
-        if (j >= nact) { thr = 4.0f; idb = 0; }
-        s_bin[j * RW_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), (uint32_t)idb * 16u);
+        if (j >= nact) { thr = 4.0f; off = 0u; }
+        s_bin[j * RW_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), off);
     }
     for (int t = tid; t < NCH * 16; t += nthr) {
         const int j = t >> 4, id = t & 15;  // id = number of thresholds <= f
@@ -385,8 +398,10 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     const double dl = onl ? p_dstep[ixl] : 0.0;
     const double sl = onl ? 2.0 * p_cstep[ixl] : 0.0, dabsl = __builtin_fabs(dl);
     const uint32_t dsgnl = (uint32_t)(d2u(dl) >> 32) & 0x80000000u;
-    // LDS byte address of the position's symbol masks, minus 4 x the symbol counter at the epoch start (idle: an all-zero row)
-    const uint32_t symbl = (uint32_t)(uintptr_t)(sg_lds_u32)s_sym + (uint32_t)jl * (SG_SYMS * 4u) - (onl ? (uint32_t)p_ib0[ixl] * 4u : 0u);
+    // the position's symbol sign pairs, indexed by the symbol counter (+ 500 once the page has flipped) minus its value at the
+    // epoch start (idle: an all-zero row)
+    const uint32_t *const syml = s_sym + jl * SG_SYMS - (onl ? p_ib0[ixl] : 0);
+    const uint32_t mtab0 = (uint32_t)(uintptr_t)(sg_lds_u32)s_mtab;
     SgRec *const recw = s_rec + wv * 2 * SG_MAXCH;
     uint32_t *const syaw = s_sya + wv * 2 * SG_MAXCH;
     const int cstep_w = bpe * nw;
@@ -402,15 +417,20 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     };
     auto stage = [&](const int buf) {
         SgRec r;
-        r.yc = lx + lx;
+        // a wrap that is pending at the chunk's first sample (:491) is taken here: every group of the chunk lies behind it
+        const bool pend = lx >= 4092.0;
+        const double x = pend ? lx - 4092.0 : lx;
+        r.yc = x + x;
         r.pm = u2d(d2u(lp) ^ ((uint64_t)dsgnl << 32));
         r.s = sl;
         r.dabs = dabsl;
         if (lane < NCH) {
             recw[buf * SG_MAXCH + lane] = r;
-            // (idle positions: steps zero, stream row zero, sign masks zero -- no contribution whatever the aliased checkpoint
+            // (idle positions: steps zero, stream row zero, sign pairs zero -- no contribution whatever the aliased checkpoint
             // holds; an undecided group listed on their account costs a replay, nothing else)
-            syaw[buf * SG_MAXCH + lane] = symbl + (onl ? ((lib & 0xffffu) + 500u * (lib >> 16)) * 4u : 0u);
+            const uint32_t ks = onl ? (lib & 0xffffu) + 500u * (lib >> 16) + (pend ? 1u : 0u) : 0u;
+            const uint32_t pair = syml[ks] * 4u + syml[ks + 1];
+            syaw[buf * SG_MAXCH + lane] = mtab0 + pair * (SG_MPOS * 4u);
         }
     };
     fetch(c);
@@ -558,7 +578,7 @@ template <bool ACC>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
-    const dim3 grid(ne * G.blocks_per_epoch), block(SG_THREADS);
+    const dim3 grid(ne * G.blocks_per_epoch), block(P->gthreads == 1024 ? 1024 : 512);
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
     switch (nch) {
         GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)

@@ -1,0 +1,214 @@
+"""GPU parity of k_synth_g (synth_group.hip), the default kernel of the reference geometry (BOC(1,1), 2.6 MS/s-like rates, automatic
+chunking): one 16-sample group per lane, start states in closed form from the chunk's exact checkpoint, chips from the
+resampled-window pattern look-up, carrier index from a fixed-point DDA, and k_repair_g for the groups whose chip pattern or table
+index hangs on the rounding history.  The result must be the oracle's, bit for bit, like the exact-replay kernel's (k_synth,
+GAL_CFG_EXACT_REPLAY); gal_synth_stats_t.kernel_family says which ran, .repaired_groups how many groups were replayed."""
+import numpy as np
+import pytest
+
+from oracle_binding import oracle_run
+from test_parity_gpu import _compare
+
+pytestmark = pytest.mark.gpu
+
+EXACT = 4  # GAL_CFG_EXACT_REPLAY
+
+
+@pytest.mark.parametrize("n_chan", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_group_kernel_every_channel_count(pkg, n_chan):
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=n_chan, n_slots=16, samples_per_epoch=52000, seed=300 + n_chan)
+    _, _, stats = _compare(pkg, p, 52000)
+    assert stats["kernel_family"] == 1 and stats["chunk_samples"] == 1024 and stats["window_mode"] == 1
+    # a chunk length of the caller's choosing, or the flag, selects the exact-replay kernel
+    _, _, stats = _compare(pkg, p, 52000, chunk_samples=1040)
+    assert stats["kernel_family"] == 0 and stats["repaired_groups"] == 0
+    _, _, stats = _compare(pkg, p, 52000, flags=EXACT)
+    assert stats["kernel_family"] == 0
+
+
+def test_group_kernel_negative_tiny_and_zero_phase(pkg):
+    """Both tables (plain / conjugate), steps far below the DDA's grid, and phases of exactly zero: 511 p = 0 is an index boundary,
+    the fraction word equals the bias, so the groups around it are listed and replayed."""
+    p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=8, n_slots=16, samples_per_epoch=52000, seed=311)
+    f = np.array([-3400.0, -1000.0, -3.0, -0.02, 1e-5, 2.5, 700.0, 3499.0])
+    for e in range(5):
+        p["f_carr"][e, :8] = f + 0.01 * e * np.sign(f)
+        p["f_code"][e, :8] = 1.023e6 + p["f_carr"][e, :8] * 0.0006493506493506494
+    p["carr_phase0"][0, :4] = 0.0
+    _, _, stats = _compare(pkg, p, 52000)
+    assert stats["kernel_family"] == 1 and stats["repaired_groups"] >= 1
+
+
+def test_group_kernel_gates(pkg):
+    """What keeps a batch on the exact-replay kernel: a carrier that stands still (every group of a channel sitting on an index
+    boundary would be listed), a carrier step beyond the table's extension behind a wrap (60 kHz at 2.6 MS/s), a sample rate
+    outside the hold form of the resampled windows, the CBOC mode."""
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=4, n_slots=8, samples_per_epoch=52000, seed=314)
+    q = p.copy()
+    q["f_carr"][1:, 2] = 0.0
+    _, _, stats = _compare(pkg, q, 52000)
+    assert stats["kernel_family"] == 0
+    q = p.copy()
+    q["f_carr"][:, 1] = 60000.0
+    _, _, stats = _compare(pkg, q, 52000)
+    assert stats["kernel_family"] == 0
+    q["f_carr"][:, 1] = 30000.0  # 16 x 511 x 30e3 / 2.6e6 = 94 entries per group: inside
+    _, _, stats = _compare(pkg, q, 52000)
+    assert stats["kernel_family"] == 1
+    r = pkg.workloads.make_synthetic(n_epochs=2, n_chan=4, n_slots=8, samples_per_epoch=50000, sample_rate=4.0e6, seed=3)
+    _, _, stats = _compare(pkg, r, 50000, rate=4.0e6)
+    assert stats["kernel_family"] == 0
+
+
+def test_group_kernel_doppler_sign_change_between_epochs(pkg):
+    """After a sign change the mirrored phase runs NEGATIVE until it crosses zero: the lower half of the DDA table, whose
+    entries follow (int)'s truncation towards zero (:509)."""
+    p = pkg.workloads.make_synthetic(n_epochs=8, n_chan=3, n_slots=16, samples_per_epoch=52000, seed=312)
+    for j in range(3):
+        f = np.linspace(40.0, -40.0, 8) * (j + 1)
+        p["f_carr"][:, j] = f
+        p["f_code"][:, j] = 1.023e6 + f * 0.0006493506493506494
+    _, _, stats = _compare(pkg, p, 52000)
+    assert stats["kernel_family"] == 1
+    # ... and with steps that change sign every epoch at a few kHz
+    p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=6, n_slots=8, samples_per_epoch=52000, seed=313)
+    for e in range(6):
+        p["f_carr"][e, :6] *= -1.0 if e & 1 else 1.0
+        p["f_code"][e, :6] = 1.023e6 + p["f_carr"][e, :6] * 0.0006493506493506494
+    _, _, stats = _compare(pkg, p, 52000)
+    assert stats["kernel_family"] == 1
+
+
+def test_group_kernel_ragged_sizes_and_more_channels_than_one_launch(pkg):
+    """Epoch lengths that are no multiple of 16 or of the 1024-sample chunk (a last group of 1..15 samples, odd output alignment),
+    one-chunk epochs, and 16 / 24 channels: the second launch accumulates, and k_repair_g replays a listed group over ALL of them."""
+    for n_samp in (16, 1000, 1024, 1025, 2604, 26001, 26007, 4096):
+        p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=5, n_slots=8, samples_per_epoch=n_samp, seed=n_samp + 1)
+        _, _, stats = _compare(pkg, p, n_samp)
+        assert stats["kernel_family"] == 1, n_samp
+    for n_chan, n_slots in ((16, 16), (24, 24), (13, 40)):
+        p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=52000, seed=315 + n_chan)
+        p["carr_phase0"][0, : n_chan // 2] = 0.0  # listed groups for certain
+        _, _, stats = _compare(pkg, p, 52000)
+        assert stats["kernel_family"] == 1 and stats["repaired_groups"] >= 1
+
+
+def test_group_kernel_page_flip_code_wraps_and_state_carry(pkg):
+    """Symbol counters at the page flip (:497-506), a code wrap pending at the first sample of an epoch (:491), windows across
+    the wrap, and a run split in two calls with the state carried by the caller."""
+    p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=6, n_slots=16, samples_per_epoch=260000, seed=316)
+    p["ibit0"][0, :6] = [499, 498, 480, 476, 0, 250]
+    for e in range(1, 6):
+        p["ibit0"][e, :6] = (p["ibit0"][0, :6] + 25 * e) % 500
+    p["code_phase0"][1, 0] = 4092.25
+    p["code_phase0"][2, 1] = 6137.9
+    p["code_phase0"][2, 2] = 4091.999
+    p["code_phase0"][3, 3] = 0.0
+    _, st, stats = _compare(pkg, p[:3], 260000)
+    assert stats["kernel_family"] == 1
+    q = p[3:].copy()
+    q["flags"][0, :6] = 0  # continues from the state the first half returned
+    _compare(pkg, q, 260000, state_in=st)
+
+
+def test_group_kernel_code_wrap_at_every_group_position(pkg):
+    """The code wrap placed at each of the 16 samples of a group and on either side of a group boundary, with the symbol's sign
+    changing across it: the window's splice of the two symbols' signs."""
+    n = 4096
+    for k in range(0, 40):
+        p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=4, n_slots=4, samples_per_epoch=n, seed=900 + k)
+        # wrap after about 1000 + k samples of epoch 0: code_phase0 = 4092 - (1000 + k) * step
+        step = p["f_code"][0, :4] / 2.6e6
+        p["code_phase0"][0, :4] = 4092.0 - (1000 + k) * step + np.array([0.0, 1e-9, -1e-9, 0.3]) * step
+        p["ibit0"][0, :4] = [10, 499, 24, 498]
+        _compare(pkg, p, n)
+
+
+def test_group_kernel_list_overflow_falls_back_to_exact_replay(pkg, monkeypatch):
+    """More undecided groups than the list holds: gal_synth_finish repeats the batch with the exact-replay kernel (fault-injection
+    build: the capacity is an environment variable there)."""
+    monkeypatch.setenv("GAL_G_LIST_CAP", "2")
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=12, n_slots=16, samples_per_epoch=52000, seed=77)
+    p["carr_phase0"][0, :12] = 0.0
+    iq, st, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["kernel_family"] == 0 and stats["synth_runs"] == 2
+    monkeypatch.delenv("GAL_G_LIST_CAP")
+    iq2, _, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["kernel_family"] == 1 and stats["synth_runs"] == 1 and np.array_equal(iq, iq2)
+
+
+def test_group_kernel_block_shapes(pkg, monkeypatch):
+    """512- and 1024-thread blocks, 1 .. 8 blocks per epoch (the plan picks by batch size; fault-injection build: forced)."""
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=9, n_slots=16, samples_per_epoch=260000, seed=78)
+    ref_iq, _ = oracle_run(p, 260000, 2.6e6)
+    for thr in ("512", "1024"):
+        for bpe in ("1", "2", "8"):
+            monkeypatch.setenv("GAL_G_THREADS", thr)
+            monkeypatch.setenv("GAL_G_BPE", bpe)
+            with pkg.SynthEngine(device=0, test_hooks=True) as eng:
+                iq, _, stats = eng.run_host(p)
+            assert stats["kernel_family"] == 1 and np.array_equal(iq, ref_iq), (thr, bpe)
+
+
+def test_group_kernel_randomised_soak_slice(pkg):
+    from fuzz_cases import random_case
+
+    rng = np.random.default_rng(4242)
+    seen = 0
+    for c in range(60):
+        p, n_samp, rate, chunk = random_case(pkg, rng, big=(c % 20 == 19))
+        with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0,
+                             chunk_samples=chunk) as eng:
+            iq, st, stats = eng.run_host(p)
+            assert eng.walk_counts()[2] == 0
+        seen += stats["kernel_family"] == 1
+        ref_iq, ref_st = oracle_run(p, n_samp, rate)
+        assert np.array_equal(iq, ref_iq) and stats["chain_mismatch"] == 0, (c, rate, p.shape, n_samp, chunk)
+        act = ref_st["prn"] > 0
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+    assert seen >= 3, seen
+
+
+def test_group_kernel_full_size_equals_exact_replay(pkg):
+    """M-SYN12 at BASELINE's size (1199 epochs x 260000 samples x 12 SVs = 3.7e9 channel-samples): about two thousand of the
+    19.5 million groups are listed and replayed; both kernels equal word for word, first and last epochs equal to the oracle."""
+    import torch
+
+    p = pkg.workloads.m_syn12()
+    outs = []
+    for flags in (0, EXACT):
+        with pkg.SynthEngine(samples_per_epoch=260000, n_slots=p.shape[1], device=0, flags=flags) as eng:
+            eng.plan(p)
+            out = torch.empty(eng.output_bytes() // 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr())
+            _, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0 and stats["kernel_family"] == (0 if flags else 1), stats
+            if not flags:
+                assert 200 <= stats["repaired_groups"] <= 20000, stats
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref_iq, _ = oracle_run(p[:2], 260000, 2.6e6)
+    assert np.array_equal(outs[0][: ref_iq.size].cpu().numpy(), ref_iq)
+
+
+def test_group_kernel_epoch_ranges_of_one_plan(pkg):
+    """gal_synth_execute_range: the list entries are relative to the LAUNCH (a range of the plan's epochs), and k_repair_g writes
+    into the range's own buffer."""
+    import torch
+
+    n = 52000
+    p = pkg.workloads.make_synthetic(n_epochs=9, n_chan=12, n_slots=16, samples_per_epoch=n, seed=4322)
+    p["carr_phase0"][0, :3] = 0.0  # fraction word = the bias: listed for certain
+    ref_iq, _ = oracle_run(p, n, 2.6e6)
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
+        eng.plan(p)
+        for world in (1, 2, 3):
+            parts = []
+            for r in range(world):
+                e0, ne = pkg.shard.epoch_range(r, world, p.shape[0])
+                out = torch.empty(ne * n * 2, dtype=torch.int16, device="cuda")
+                eng.execute(out.data_ptr(), e0, ne)
+                _, stats = eng.finish()
+                assert stats["chain_mismatch"] == 0 and stats["kernel_family"] == 1
+                parts.append(out.cpu().numpy())
+            assert np.array_equal(np.concatenate(parts), ref_iq), world
