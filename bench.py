@@ -219,7 +219,7 @@ def profiled_kernel_ms(kind="bench"):
         return None, None
     try:
         for r in csv.DictReader(open(files[-1])):
-            if "k_synth" in r["Name"] and "12" in r["Name"]:
+            if "k_synth" in r["Name"] and "12" in r["Name"] and "k_synth_g" in r["Name"]:
                 return round(float(r["AverageNs"]) / 1e6, 4), os.path.basename(files[-1])
     except Exception:
         pass
@@ -536,15 +536,22 @@ def main():
                 "chain_mismatch": stats["chain_mismatch"],
                 "pipeline_depth": depth, **({"hooks_build": True} if HOOKS_BUILD else {}),
                 **({"variant_lib": os.environ["GAL_SYNTH_LIB"]} if os.environ.get("GAL_SYNTH_LIB") else {}),
-                "window_mode": stats.get("window_mode"),  # 1: k_synth's resampled-window fast body (galsynth.h)
+                "window_mode": stats.get("window_mode"),  # 1: resampled-window chips (galsynth.h)
+                "kernel_family": stats.get("kernel_family"),  # 1: k_synth_g + k_repair_g (galsynth.h: gal_synth_stats_t)
                 "output_checksum": "%08x" % chk,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_synth<%d,false,%d,%d%s>%s" % (min(args.channels, 12), 1 if args.signal == "cboc" else 0,
+                "kernel": ("k_synth_g<%d,false>%s" % (min(args.channels, 12), " (+ accumulate launch)" if args.channels > 12 else "")
+                           if stats.get("kernel_family") == 1 else
+                           "k_synth<%d,false,%d,%d>%s" % (min(args.channels, 12), 1 if args.signal == "cboc" else 0,
                                                          (stats.get("window_mode") or 0) & 15,
-                                                         ",1" if (stats.get("window_mode") or 0) & 16 else "",
-                                                         " (+ accumulate launch)" if args.channels > 12 else ""),
+                                                         " (+ accumulate launch)" if args.channels > 12 else "")),
+                # family 1 (synth_group.hip): behind k_synth_g, k_repair_g replays the groups it could not decide -- a second,
+                # small kernel of the same pass; its time is in every step and in `sustained`, and reported here
+                **({"repair": {"kernel": "k_repair_g", "avg_ms": round(sum(x.get("ms_repair", 0.0) for x in step_stats) / len(step_stats), 4),
+                               "groups_per_launch": stats.get("repaired_groups"),
+                               "of_groups": int(samples_per_step // 16)}} if stats.get("kernel_family") == 1 else {}),
                 # achieved / frac: algorithmic bytes per launch / the kernel's launch duration with the kernel running ALONE
                 # (HIP events on its stream, one handle, measured live right behind the timed region).  Inside the timed
                 # region two handles are in flight and consecutive launches OVERLAP -- the tail of one runs beside the head

@@ -813,7 +813,10 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
     }
     // the groups k_synth_g could not decide (chip pattern or table index within the rounding drift of a boundary), exactly
-    if (h->P.fam == 1) galk_launch_repair_g(&h->P, iq, h->range_e0, h->stream);
+    if (h->P.fam == 1) {
+        HIP_TRY(hipEventRecord(h->ev[3], h->stream));  // (k_synth_g's time and k_repair_g's are reported apart)
+        galk_launch_repair_g(&h->P, iq, h->range_e0, h->stream);
+    }
     HIP_TRY(hipGetLastError());
     return GAL_OK;
 }
@@ -950,6 +953,11 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     float ms_walk = 0, ms_synth = 0;
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
     hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[2]);
+    float ms_repair = 0;
+    if (h->P.fam == 1 && h->nact_max != 0) {
+        hipEventElapsedTime(&ms_synth, h->ev[1], h->ev[3]);
+        hipEventElapsedTime(&ms_repair, h->ev[3], h->ev[2]);
+    }
     int *ctr_walk = h->h_ctr, *ctr_end = h->h_ctr;  // counters after the synthesis kernel
     if (ctr_walk[CTR_UNVERIFIED] != 0) {
         // stragglers (itinerary mismatches / tie epochs beyond the enqueued passes): iterate from the host
@@ -1042,6 +1050,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;
+    h->stats.ms_repair = h->stats.synth_runs == 1 ? ms_repair : 0.0f;
     h->stats.window_mode = h->P.rw;
     h->legs_walked = ctr_end[CTR_WALKS];
     h->legs_translated = ctr_end[CTR_SHIFTS];

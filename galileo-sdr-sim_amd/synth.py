@@ -74,6 +74,8 @@ class _Stats(ctypes.Structure):
         ("synth_runs", ctypes.c_int32),
         ("kernel_family", ctypes.c_int32),
         ("repaired_groups", ctypes.c_int32),
+        ("ms_repair", ctypes.c_float),
+        ("reserved", ctypes.c_int32),
     ]
 
 

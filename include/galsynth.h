@@ -123,6 +123,8 @@ typedef struct gal_synth_stats {
                                    chip pattern or table index hangs on the rounding history replayed exactly afterwards
                                    (BOC(1,1), 0.74 <= 2 f_code / fs < 1 -- the reference's 2.6 MS/s; the default there)      */
     int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
+    float   ms_repair;          /* family 1: device time of that replay (k_repair_g, behind the synthesis kernel; not in ms_synth) */
+    int32_t reserved;
 } gal_synth_stats_t;
 
 typedef struct gal_synth gal_synth_t;

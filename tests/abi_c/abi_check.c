@@ -15,12 +15,13 @@ _Static_assert(offsetof(gal_chan_epoch_t, page_init) == 112, "page_init");
 _Static_assert(offsetof(gal_chan_state_t, page) == 8, "state.page");
 _Static_assert(offsetof(gal_synth_cfg_t, flags) == 28, "cfg.flags");
 _Static_assert(sizeof(gal_synth_cfg_t) == 40, "gal_synth_cfg_t");
-_Static_assert(sizeof(gal_synth_stats_t) == 48, "gal_synth_stats_t");
+_Static_assert(sizeof(gal_synth_stats_t) == 56, "gal_synth_stats_t");
 _Static_assert(offsetof(gal_synth_stats_t, ms_walk) == 24, "stats.ms_walk");
 _Static_assert(offsetof(gal_synth_stats_t, window_mode) == 32, "stats.window_mode");
 _Static_assert(offsetof(gal_synth_stats_t, synth_runs) == 36, "stats.synth_runs");
 _Static_assert(offsetof(gal_synth_stats_t, kernel_family) == 40, "stats.kernel_family");
 _Static_assert(offsetof(gal_synth_stats_t, repaired_groups) == 44, "stats.repaired_groups");
+_Static_assert(offsetof(gal_synth_stats_t, ms_repair) == 48, "stats.ms_repair");
 
 int main(int argc, char **argv)
 {

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(pkg):
     import ctypes
 
     st = pkg.synth._Stats
-    assert ctypes.sizeof(st) == 48 and st.kernel_family.offset == 40 and st.repaired_groups.offset == 44 and st.ms_walk.offset == 24 and st.window_mode.offset == 32 and st.synth_runs.offset == 36
+    assert ctypes.sizeof(st) == 56 and st.ms_repair.offset == 48 and st.kernel_family.offset == 40 and st.repaired_groups.offset == 44 and st.ms_walk.offset == 24 and st.window_mode.offset == 32 and st.synth_runs.offset == 36
 
 
 def test_version_and_tables_without_gpu(pkg):

@@ -34,7 +34,9 @@ def test_small_batches_bit_exact(pkg, n_chan):
 def test_full_epoch_size_bit_exact(pkg):
     """Reference geometry: 260000 samples per epoch, 12 channels, several epochs."""
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=12, n_slots=16, samples_per_epoch=260000, seed=5)
-    iq, st, stats = _compare(pkg, p, 260000)
+    iq, st, stats = _compare(pkg, p, 260000)  # the default kernel of this geometry: 16-sample groups out of 1024-sample chunks
+    assert stats["kernel_family"] == 1 and stats["chunk_samples"] == 1024 and stats["chunks_per_epoch"] == 254
+    iq, st, stats = _compare(pkg, p, 260000, flags=4)  # GAL_CFG_EXACT_REPLAY: one chunk per lane
     # a batch this small gets short chunks (one block per CU would need 65536 of them) that still divide the code period
     assert stats["chunk_samples"] == 416 and stats["chunks_per_epoch"] == 625 and 10400 % stats["chunk_samples"] == 0
     iq, st, stats = _compare(pkg, p, 260000, chunk_samples=1040)
@@ -42,12 +44,13 @@ def test_full_epoch_size_bit_exact(pkg):
 
 
 def test_chunk_length_follows_the_batch_size(pkg):
-    """gal_synth_plan picks the chunk length from the batch size: ~1024 samples (1040 = a tenth of the code period at
+    """The exact-replay kernel (GAL_CFG_EXACT_REPLAY; the default kernel of this geometry always takes 1024-sample chunks):
+    gal_synth_plan picks the chunk length from the batch size: ~1024 samples (1040 = a tenth of the code period at
     2.6 MS/s) from 263 epochs on, shorter for batches that would otherwise leave CUs without a block; same bits either way
     (the full-size tests cover 1040 against 1024 / 520)."""
     for n_ep, want in ((1, 416), (64, 416), (128, 416), (300, 1040)):
         p = pkg.workloads.make_synthetic(n_epochs=n_ep, n_chan=3, n_slots=4, samples_per_epoch=260000, seed=40 + n_ep)
-        with pkg.SynthEngine(samples_per_epoch=260000, n_slots=4, device=0) as eng:
+        with pkg.SynthEngine(samples_per_epoch=260000, n_slots=4, device=0, flags=4) as eng:
             eng.plan(p)
             assert eng.output_bytes() == n_ep * 260000 * 4
             import torch
