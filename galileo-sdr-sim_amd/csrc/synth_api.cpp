@@ -706,19 +706,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     if (const char *env = getenv("GAL_G_LIST_CAP")) P.gflist_cap = std::max(1, std::min(kGroupListCap, atoi(env)));  // overflow path
 #endif
     {
-        // k_synth_g: a block takes an epoch's chunks (or 1 / bpe of them), its waves one chunk at a time.  Block size and cut
-        // are chosen for the shortest tail: `slots` blocks run at a time, a batch of B blocks takes ceil(B / slots) rounds of
-        // (1 + 0.06 bpe) / bpe epoch times (the block's tables cost about 6 % of an epoch's samples to build)
+        // k_synth_g: a block takes an epoch's chunks (or 1 / bpe of them), its waves one chunk at a time
+        // measured (M-SYN12, kernel alone): 512 threads x 1 / 2 / 4 blocks per epoch 0.908 / 0.943 / 0.938 ms, 1024 threads x 1 / 2
+        // 1.055 / 1.107 -- blocks do not run in rounds (the last ones run on a half-empty device, faster), so the cut only has to
+        // give every CU its two blocks: the smallest power of two with E x bpe >= 512, as long as every wave still gets a chunk
         int best_thr = 512, best_bpe = 1;
-        double best = 1e30;
-        for (int thr = 512; thr <= 1024; thr *= 2) {
-            const int slots = 256 * (1024 / thr), waves = thr / 64;
-            for (int bpe = 1; bpe <= 64 && (bpe == 1 || bpe * waves <= nchunks); bpe *= 2) {
-                const double rounds = std::ceil((double)E * bpe / slots);
-                const double cost = rounds * (1.0 / bpe + 0.06 * (thr == 1024 ? 0.7 : 1.0));
-                if (cost < best - 1e-9) { best = cost; best_thr = thr; best_bpe = bpe; }
-            }
-        }
+        while (E * best_bpe < 512 && best_bpe * 2 * (best_thr / 64) <= nchunks) best_bpe *= 2;
         P.gthreads = best_thr;
         P.gbpe = best_bpe;
 #ifdef GAL_TEST_HOOKS
@@ -891,7 +884,13 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     // carrier-DDA batches: the checkpoints are verified by a kernel of their own (k_verify_carr), on the walker stream behind
     // the chain and beside the synthesis; the completion record waits for both
-    const bool verify_beside = (h->P.cd || h->P.fam == 1) && ws != st && h->nact_max != 0;
+    bool verify_beside = (h->P.cd || h->P.fam == 1) && ws != st && h->nact_max != 0;
+#ifdef GAL_TEST_HOOKS
+    const bool no_verify = getenv("GAL_G_NOVERIFY") != nullptr;  // timing experiments only: what k_verify_carr costs the pipeline
+    if (no_verify) verify_beside = false;
+#else
+    const bool no_verify = false;
+#endif
     if (ws != st) {
         HIP_TRY(hipEventRecord(h->ev_walk, ws));
         HIP_TRY(hipStreamWaitEvent(st, h->ev_walk, 0));
@@ -902,7 +901,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     }
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
     HIP_TRY(hipEventRecord(h->ev[1], st));
-    int rc = enqueue_synth(h, (uint32_t *)iq_dev, !verify_beside);
+    int rc = enqueue_synth(h, (uint32_t *)iq_dev, !verify_beside && !no_verify);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], st));
     if (verify_beside) HIP_TRY(hipStreamWaitEvent(st, h->ev_ver, 0));

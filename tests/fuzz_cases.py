@@ -7,9 +7,13 @@ import numpy as np
 RESTART = 1
 
 
-def random_case(pkg, rng, big=False):
-    rate = float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 4.0e6, 4.092e6, 7.7e6, 8e6, 10e6, 12.5e6, 15.4e6, 16e6, 25e6, 25e6, 40e6]))
+def random_case(pkg, rng, big=False, group=False):
+    """group=True: batches the default kernel of the reference geometry can take (k_synth_g: rates in the hold form of the resampled
+    windows, automatic chunking; zero / sub-2^-40 Doppler steps still send a batch to the exact-replay kernel)."""
+    rate = float(rng.choice([2.2e6, 2.4e6, 2.6e6, 2.6e6, 2.6e6, 2.76e6])) if group else float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 4.0e6, 4.092e6, 7.7e6, 8e6, 10e6, 12.5e6, 15.4e6, 16e6, 25e6, 25e6, 40e6]))
     n_slots = int(rng.choice([4, 8, 16, 16, 24, 40, 64]))
+    if group and rng.random() < 0.7:
+        n_slots = int(rng.choice([8, 16, 16, 16]))
     n_chan = int(rng.integers(1, n_slots + 1))
     n_ep = int(rng.integers(1, 7))
     n_samp = int(rng.choice([rng.integers(16, 3000), rng.integers(3000, 70000), int(rate / 10) if rate <= 4.1e6 else 40000]))
@@ -27,7 +31,7 @@ def random_case(pkg, rng, big=False):
         r = rng.random()
         if r < 0.15:   # exactly zero or tiny Doppler in some epochs
             e = rng.integers(0, n_ep)
-            p["f_carr"][e:, j] = rng.choice([0.0, 1e-7, -3e-5, 0.02])
+            p["f_carr"][e:, j] = rng.choice([1e-5, 1e-7, -3e-5, 0.02] if group and rng.random() < 0.8 else [0.0, 1e-7, -3e-5, 0.02])
         elif r < 0.3:  # sign flip
             e = rng.integers(0, n_ep)
             p["f_carr"][e:, j] = -p["f_carr"][e:, j]
@@ -64,4 +68,11 @@ def random_case(pkg, rng, big=False):
                 p["carr_phase0"][e + 1, j] = rng.uniform(-0.999, 0.999)
                 p["page_init"][e + 1, j] = q["page_next"][0, 0]
     chunk = int(rng.choice([0, 0, 0, 4 * int(rng.integers(1, 400)), 16 * int(rng.integers(1, 100))]))
+    if group:
+        chunk = 0
+        for j in range(n_chan):  # phases ON an index boundary of the carrier table (511 p an integer) and next to the code's half chips
+            if rng.random() < 0.1:
+                p["carr_phase0"][0, j] = float(rng.integers(0, 511)) / 511.0 * float(rng.choice([1.0, -1.0]))
+            if rng.random() < 0.1:
+                p["code_phase0"][int(rng.integers(0, n_ep)), j] = float(rng.integers(0, 8184)) * 0.5 + float(rng.choice([0.0, 1e-12, -1e-12 + 0.5]))
     return p, n_samp, rate, chunk

@@ -4,7 +4,9 @@
 channels appearing, vanishing and being re-allocated, symbol counters near the page flip, code phases near the
 wrap).  Test infrastructure: uses the oracle as the checker.   python tools/fuzz_parity.py [n_cases] [seed] [big]
 GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_SINGLE_LEGS=0: the long-batch stitcher on every batch).
-GAL_FUZZ_CBOC=1 runs the opt-in CBOC(6,1,1/11) mode against the checker's CBOC loop."""
+GAL_FUZZ_CBOC=1 runs the opt-in CBOC(6,1,1/11) mode against the checker's CBOC loop.
+GAL_FUZZ_GROUP=1 draws batches the default kernel of the reference geometry (k_synth_g + k_repair_g) can take, and reports how
+many it took and how many 16-sample groups were replayed exactly."""
 import os
 import sys
 import time
@@ -23,8 +25,11 @@ pkg = load_pkg()
 CBOC = bool(os.environ.get("GAL_FUZZ_CBOC"))
 
 
+GROUP = bool(os.environ.get("GAL_FUZZ_GROUP"))
+
+
 def random_case(rng, big=False):
-    return _random_case(pkg, rng, big)
+    return _random_case(pkg, rng, big, group=GROUP)
 
 
 def main():
@@ -38,6 +43,7 @@ def main():
     n_run = 0
     samples = 0
     rejected = {}
+    fam1 = repaired = 0
     for c in range(n_cases):
         p, n_samp, rate, chunk = random_case(rng, big)
         try:
@@ -70,6 +76,8 @@ def main():
             bad += 1
             continue
         ref_iq, ref_st = oracle_run(p, n_samp, rate, cboc=CBOC)
+        fam1 += stats["kernel_family"] == 1
+        repaired += stats["repaired_groups"] + (stats2["repaired_groups"] if cut else 0)
         n_run += 1
         samples += p.shape[0] * n_samp
         act = ref_st["prn"] > 0
@@ -81,8 +89,8 @@ def main():
             print("case %d MISMATCH: rate %.4g slots %d epochs %d samples %d chunk %d passes %d" % (
                 c, rate, p.shape[1], p.shape[0], n_samp, chunk, stats["walk_passes"]))
             np.save(os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d.npy" % (seed, c)), p)
-    print("fuzz: %d cases, %d compared (%.1f M samples), %d bad, %d fallbacks, rejected %s, %.1f s" % (
-        n_cases, n_run, samples / 1e6, bad, fb_total, rejected, time.time() - t0))
+    print("fuzz: %d cases, %d compared (%.1f M samples), %d bad, %d fallbacks, %d by k_synth_g (%d groups replayed), rejected %s, %.1f s" % (
+        n_cases, n_run, samples / 1e6, bad, fb_total, fam1, repaired, rejected, time.time() - t0))
     sys.exit(1 if bad else 0)
 
 
