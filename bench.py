@@ -119,10 +119,13 @@ def leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp,
             "what": "execute + finish + copy into pinned host memory, double-buffered (PCIe-inclusive)"}
 
 
-def leg_file_sink(seconds=120):
+def leg_file_sink(pkg, seconds=120):
     """SURVEY.md 8(d), third timing: the drop-in itself -- the CLI with the reference's option surface on the RINEX
     scenario of BASELINE configs[0/1] (9 SVs with this navigation file), RINEX parsing, geodesy and I/NAV included,
-    writing the ishort stream to /dev/null and to a tmpfs file."""
+    writing the ishort stream to /dev/null and to a tmpfs file.  The file is then hashed and compared with the same scenario
+    through the library (front-end rows -> gal_synth_run_host, outside every timed region): what the timed command wrote is
+    the stream the C-ABI produces (src/galileo-sdr.cpp:438,542,658: (10 d - 1) epochs of 260000 int16 pairs)."""
+    import hashlib
     import re
     import subprocess
     import tempfile
@@ -149,12 +152,25 @@ def leg_file_sink(seconds=120):
             out[name] = {"value": float(m2.group(1)) if m2 else round(n_samples / float(m.group(1)) / 1e6, 1), "unit": "Msamples/s",
                          "process_time_s": float(m.group(1)), "wall_s_incl_startup": round(wall, 3),
                          "bytes": n_samples * 4}
+            if sink != "/dev/null":
+                h = hashlib.md5()
+                with open(sink, "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b""):
+                        h.update(blk)
+                rows = pkg.Scenario(nav, llh=(-6.0, 51.0, 100.0), start="2022/02/20,12:00:00", duration_s=float(seconds),
+                                    iono_enable=True).all()
+                with pkg.SynthEngine(device=-1) as eng:
+                    iq, _, _ = eng.run_host(rows)
+                lib_md5 = hashlib.md5(iq.tobytes()).hexdigest()
+                out[name].update({"file_bytes": os.path.getsize(sink), "md5": h.hexdigest(), "md5_equals_library": h.hexdigest() == lib_md5})
+                del iq
         finally:
             if sink != "/dev/null" and os.path.exists(sink):
                 os.remove(sink)
     out["what"] = ("galileo-sdr-sim -e 20feb2022.rnx -l -6,51,100 -t 2022/02/20,12:00:00 -d %d -o <sink>: front-end + HIP + D2H + "
                    "write; value from the CLI's own 'Process time' line (as the reference prints it), wall time includes "
-                   "HIP start-up and pinned allocations" % seconds)
+                   "HIP start-up and pinned allocations; md5_equals_library: the file against the same scenario through "
+                   "gal_synth_run_host (untimed)" % seconds)
     return out
 
 
@@ -251,18 +267,32 @@ def exchange_report(dist, backend, ctl, report):
     """The report of a run -- MAX of the time, SUM of samples and checksums, per-rank detail -- over RCCL (the default group)
     when the backend is nccl.  Should the communicator fail to come up on this node the measurement is not lost with it:
     the same reductions then go through the gloo group that carried the barriers, and the line says so
-    ("report_backend").  report(group, device) does the exchange; returns its four values + the backend used."""
+    ("report_backend").  Whether to fall back is AGREED over that gloo group (MIN of an ok flag) before any rank takes the
+    other path: a rank-local decision would leave the ranks in different collective sequences.  report(group, device) does
+    the exchange; returns its four values + the backend used."""
     if dist is None:
         return report(None, "cpu") + (None,)
     if backend != "nccl":
         return report(None, "cpu") + (backend,)
+    res, err = None, None
     try:
-        return report(None, "cuda") + ("rccl",)
+        res = report(None, "cuda")
     except Exception as exc:  # noqa: BLE001 -- whatever RCCL raises, the gloo group is the way out
-        if ctl["group"] is None:
-            raise
-        sys.stderr.write("bench: report over RCCL failed (%s: %s); falling back to the gloo group\n" % (type(exc).__name__, exc))
-        return report(ctl["group"], "cpu") + ("gloo (RCCL failed: %s)" % type(exc).__name__,)
+        err = exc
+    if ctl["group"] is None:
+        if err is not None:
+            raise err
+        return res + ("rccl",)
+    import torch
+
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=ctl["group"])
+    if int(ok.item()) == 1:
+        return res + ("rccl",)
+    why = type(err).__name__ if err is not None else "on another rank"
+    sys.stderr.write("bench: report over RCCL failed (%s%s); every rank falls back to the gloo group\n" % (
+        why, ": %s" % err if err is not None else ""))
+    return report(ctl["group"], "cpu") + ("gloo (RCCL failed: %s)" % why,)
 
 
 def main():
@@ -512,7 +542,12 @@ def main():
             "n_gpus": world,
             **({"rehearsal": "all %d ranks on GPU %d, backend %s: launch-path check, NOT a scaling measurement" % (
                 world, local_rank, backend)} if os.environ.get("GAL_BENCH_DEVICE") and world > 1 else {}),
-            **({"ranks": per_rank, "report_backend": report_backend} if per_rank else {}),
+            **({"ranks": per_rank, "report_backend": report_backend,
+                # walker chain + synthesis per step, slowest rank over the mean: what the split leaves on the table (strong split:
+                # shard.epoch_range cuts the ranges so that walk(prefix + range) + synth(range) is level)
+                "rank_imbalance": round(max(r["avg_walk_ms"] + r["avg_kernel_ms"] for r in per_rank) /
+                                        max(1e-9, sum(r["avg_walk_ms"] + r["avg_kernel_ms"] for r in per_rank) / len(per_rank)), 3)}
+               if per_rank else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "preroll_steps": preroll_steps,  # un-timed device wake-up in front of the warm-up steps (--preroll-ms)
@@ -595,7 +630,7 @@ def main():
                 eng.close()
             del outs[:], out
             torch.cuda.empty_cache()
-            line["e2e"]["file_sink"] = leg_file_sink()
+            line["e2e"]["file_sink"] = leg_file_sink(pkg)
             line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 24, local_rank, streams),
                                "syn24": leg_config(torch, pkg, "syn24", 600, 8, local_rank, streams),
                                # BASELINE config 4 at its FULL size: 600 s x 25 MS/s x 24 SVs = 15.0 G samples, 60 GB of IQ

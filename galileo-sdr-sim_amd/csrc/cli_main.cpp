@@ -71,7 +71,8 @@ void usage(const char *prog)
            "  --strict         Stop with an error where a satellite in view runs out of ephemeris (default: its channel\n"
            "                   keeps the last valid record; the reference indexes out of bounds there)\n"
            "  --sites <file>   One line lat,lon,hgt[,outfile] per receiver site: one process per site over the GPUs of the\n"
-           "                   node (--gpus N, default all; --per-gpu K processes per GPU, default 1); -o is the name stem\n"
+           "                   node (--gpus N, default all; --per-gpu K processes per GPU, default 1); -o is the name stem;\n"
+           "                   -P <port>: site k listens on port + k (default: no position listener)\n"
            "  --writers <n>    Threads that move finished batches into a regular output file (default 0: sequential write(); > 0: mapped file, n copy threads)\n"
            "  -v               Verbose\n"
            "  -U/-b/-a/-G/-p/-n/-g/-i     accepted for compatibility (file sink only)\n",
@@ -254,7 +255,7 @@ struct Site {
 };
 
 int run_sites(const char *self, const std::vector<std::string> &base_args, const char *sites_file, const char *out_stem,
-              int n_gpus, int per_gpu)
+              int n_gpus, int per_gpu, int udp_base)
 {
     std::vector<Site> sites;
     FILE *fp = fopen(sites_file, "r");
@@ -316,6 +317,8 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
             args.push_back(s.llh);
             args.push_back("-o");
             args.push_back(s.out);
+            args.push_back("-P");
+            args.push_back(std::to_string(udp_base > 0 ? udp_base + (int)next : 0));
             const pid_t pid = fork();
             if (pid < 0) {
                 perror("fork");
@@ -413,7 +416,7 @@ int main(int argc, char *argv[])
     std::vector<std::string> child_args;  // --sites: everything but -l / -o / --sites / --gpus / --per-gpu goes to the children
     int opt;
     while ((opt = getopt_long(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC", long_opts, nullptr)) != -1) {
-        if (opt != 'l' && opt != 'o' && opt != OPT_SITES && opt != OPT_GPUS && opt != OPT_PER_GPU && opt != '?' && opt != ':') {
+        if (opt != 'l' && opt != 'o' && opt != 'P' && opt != OPT_SITES && opt != OPT_GPUS && opt != OPT_PER_GPU && opt != '?' && opt != ':') {
             if (opt >= 1000) {
                 child_args.push_back(opt == OPT_STRICT ? "--strict" : "--writers");
             } else {
@@ -477,15 +480,13 @@ int main(int argc, char *argv[])
         exit(1);
     }
     if (sitesfile[0]) {
-        if (!udp_given) {  // several listeners cannot share the default port: the sites run without one unless -P says otherwise
-            child_args.push_back("-P");
-            child_args.push_back("0");
-        }
+        // several listeners cannot share a port: the sites run without the position listener unless -P names a base port, in
+        // which case site k (in file order) listens on port + k
         char self[4096];
         const ssize_t n = readlink("/proc/self/exe", self, sizeof(self) - 1);
         if (n <= 0) snprintf(self, sizeof(self), "%s", argv[0]);
         else self[n] = 0;
-        return run_sites(self, child_args, sitesfile, outfile, sites_gpus, sites_per_gpu);
+        return run_sites(self, child_args, sitesfile, outfile, sites_gpus, sites_per_gpu, udp_given ? sc.udp_port : 0);
     }
     if (outfile[0] == 0) {
         printf("[+] File sink not specified. Using galileosim.ishort\n");

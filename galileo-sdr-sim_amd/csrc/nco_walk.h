@@ -292,11 +292,14 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
     int flipped = 0;
     // The batch is nco_batch specialised for this chain -- phase and step positive, the phase only grows until the wrap,
     // cap 4092 -- with everything that depends only on the step hoisted out of the loop (the walk is one long dependency
-    // chain per lane: its length in instructions IS its run time).  Steps outside (2^-40, 4) chips take the general
+    // chain per lane: its length in instructions IS its run time).  Steps outside [2^-20, 4) chips take the general
     // nco_batch: same results either way, bit for bit (tests/test_walker_cpu.py against brute-force stepping).
     const uint64_t cb = d2u(cstep);
     const uint32_t ed = (uint32_t)(cb >> 52);
-    const bool lean = (cstep > 9.094947017729282e-13) && (cstep < 4.0) && (x >= 0.0);
+    // (2^-20: what gal_synth_plan admits.  Below about 2^-30 the quotient estimate t * inv_c -- the reciprocal of the step, not of
+    // its rounded value dk -- can overshoot floor(t / dk) by more than the one step the remainder test takes back, in this batch
+    // and in the general nco_batch alike: such steps are taken one by one)
+    const bool lean = (cstep >= 9.5367431640625e-07) && (cstep < 4.0) && (x >= 0.0);
     // the one binade in which the step is an odd multiple of half an ulp (round-to-even ties inside a batch)
     const uint32_t e_tie = ed + 1u + (uint32_t)__builtin_ctzll(cb | (1ull << 52));
     while (i < N) {
@@ -334,10 +337,13 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
             n = n < 0 ? 0 : n;
             n = (can & !odd_tie & (t >= 0.0)) ? n : 0;
             inc = dk;
-        } else {
+        } else if (cstep >= 9.5367431640625e-07) {
             const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
             n = b.n;
             inc = b.inc;
+        } else {  // below 2^-20 (never in the product: gal_synth_plan's limit) no quotient estimate is trusted: genuine steps only
+            n = 0;
+            inc = 0.0;
         }
         // checkpoints inside the batch come out of its closed form (every state of a batch is below the wrap, so the
         // pre-check state IS the state): the walk stops at binade crossings and wraps only -- 13 times per code period

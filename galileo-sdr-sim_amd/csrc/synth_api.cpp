@@ -11,6 +11,8 @@
 #include <cstring>
 #include <new>
 #include <chrono>
+#include <sched.h>
+#include <time.h>
 #include <vector>
 
 #include "synth_dev.h"
@@ -57,7 +59,7 @@ extern "C" double gal_hooks_rw_min_gap(void) { return kRwMinGap; }
 #endif
 
 extern "C" {
-void galk_warm(hipStream_t st, int signal, double ratio, int cd);
+void galk_warm(hipStream_t st, int signal, double ratio);
 void galk_warm_g(hipStream_t st);
 int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, const uint8_t *act, const int *nact,
                         uint32_t *iq, int e0, int ne, hipStream_t st);
@@ -140,7 +142,7 @@ struct gal_synth {
     // are first in line then, instead of queueing behind the pending synthesis workgroups of other handles
     hipStream_t walk_stream = nullptr;
     hipEvent_t ev_walk = nullptr;
-    hipEvent_t ev_ver = nullptr;  // k_verify_carr done (carrier-DDA batches)
+    hipEvent_t ev_ver = nullptr;  // k_verify_carr done (k_synth_g batches)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
@@ -179,6 +181,7 @@ struct gal_synth {
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
     // their smallest distance (rw_threshold_gap) -- reused only for the identical step
     std::vector<double> rw_s0, rw_g0, rw_e0;
+    int g_holdoff = 0;  // batches for which k_synth_g is not used although it could be: its last batch listed too many groups
 };
 
 // The stream the handle works on: the caller's (gal_synth_set_stream), or one of its own, made at first need.
@@ -344,7 +347,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return bail(fail(GAL_E_DEVICE, "table upload failed"));
     create_stage("tables (hipMalloc + uploads)");
     // code-object load now, not inside the first batch (the families this configuration can launch)
-    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate, 0);
+    galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
     {
         const double ratio = 2.0 * 1.023e6 / cfg->sample_rate;
         if (!(cfg->flags & (GAL_CFG_CBOC | GAL_CFG_EXACT_REPLAY)) && ratio >= 0.70 && ratio <= 1.02 && cfg->chunk_samples <= 0)
@@ -506,7 +509,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     int R = h->cfg.chunk_samples;
     // k_synth_g (synth_group.hip) where it applies: BOC(1,1) on resampled windows of the hold form, automatic chunking, an epoch
     // that spans fewer symbols than the kernel's mask table holds, list entries that fit 32 bits
+    // (and not while the handle is held off it: a batch whose code phase sits ON a pattern threshold group after group -- zero
+    // Doppler with the phase on the 1 / 1300 lattice of 2 x 1.023 / 2.6, a synthetic input -- lists a percent of its groups, and
+    // k_repair_g then costs more than the exact-replay kernel; the next 8 batches of the handle take that one)
+    if (h->g_holdoff > 0) h->g_holdoff -= 1;
     bool fam_g = !cboc && rw_ok && rw_mode == 1 && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) && nact_max > 0 &&
+                 h->g_holdoff == 0 &&
                  (double)N / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
                  (double)E * (double)((N + kGroupChunk - 1) / kGroupChunk) * 64.0 < 4294967296.0;
 #ifdef GAL_TEST_HOOKS
@@ -627,7 +635,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
-    const size_t o_wflag = take((size_t)E * ((tiles + 3) / 4) * 4 * 4 + 16);
     const size_t o_gflist = take(fam_g ? (size_t)kGroupListCap * 4 : 16);
     // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
     size_t single_legs = (size_t)kScanSingleBlockLegs;
@@ -698,7 +705,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 #endif
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
-    P.wflag = (uint32_t *)(base + o_wflag);
     P.fam = fam_g ? 1 : 0;
     P.gflist = (uint32_t *)(base + o_gflist);
     P.gflist_cap = kGroupListCap;
@@ -731,7 +737,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         P.rw = v == 0 ? 0 : (v >= 11 && v <= 13) ? (P.signal == 0 || v == 11 ? v - 10 : 0) : P.rw;
     }
 #endif
-    P.cd = 0;
 
     // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
     // goes over in one copy; one memset clears what must start at zero; one sync at the end: after plan() the batch
@@ -787,12 +792,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     return GAL_OK;
 }
 
-// verify_here: the carrier-DDA form of k_synth does not verify the carrier checkpoints itself; k_verify_carr does, in front of
-// it on the same stream (repair paths, handles without a walker stream) -- the first launch of a batch runs it on the walker
-// stream instead, beside the synthesis (gal_synth_execute_range)
+// verify_here: k_synth_g does not verify the carrier checkpoints itself (k_synth's exact replay does, on its way); k_verify_carr
+// does, in front of it on the same stream (repair paths, handles without a walker stream) -- the first launch of a batch runs it
+// on the walker stream instead, beside the synthesis (gal_synth_execute_range)
 static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
 {
-    if (verify_here && (h->P.cd || h->P.fam == 1) && h->nact_max != 0) galk_launch_verify_carr(&h->Pw, h->stream);
+    if (verify_here && h->P.fam == 1 && h->nact_max != 0) galk_launch_verify_carr(&h->Pw, h->stream);
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
         HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
         return GAL_OK;
@@ -882,9 +887,9 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     galk_launch_walk_code(P, h->aux_stream);
     galk_launch_pages(P, h->aux_stream);
     HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
-    // carrier-DDA batches: the checkpoints are verified by a kernel of their own (k_verify_carr), on the walker stream behind
-    // the chain and beside the synthesis; the completion record waits for both
-    bool verify_beside = (h->P.cd || h->P.fam == 1) && ws != st && h->nact_max != 0;
+    // k_synth_g batches: the carrier checkpoints are verified by a kernel of their own (k_verify_carr), on the walker stream
+    // behind the chain and beside the synthesis; the completion record waits for both
+    bool verify_beside = h->P.fam == 1 && ws != st && h->nact_max != 0;
 #ifdef GAL_TEST_HOOKS
     const bool no_verify = getenv("GAL_G_NOVERIFY") != nullptr;  // timing experiments only: what k_verify_carr costs the pipeline
     if (no_verify) verify_beside = false;
@@ -931,11 +936,30 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     // stream): poll the sequence number; the stream itself is looked at now and then, so that a failed launch or a
     // device fault ends the wait with its error instead of hanging it.
     {
+        // Waiting in three stages, so that a batch that is about to complete is seen at once and a long one does not cost a
+        // core: 50 us of pause-spinning, then up to 2 ms of sched_yield (other runnable threads of the process -- the CLI's
+        // producer and writer, other handles' callers -- get the core), then naps that grow from 20 us to 1 ms.
         const uint32_t want = h->seq;
+        const auto t_begin = std::chrono::steady_clock::now();
         unsigned spins = 0;
+        long nap_ns = 20000;
         while (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != want) {
-            __builtin_ia32_pause();
-            if ((++spins & 1023u) == 0) {
+            const bool look = (++spins & 255u) == 0;
+            if (!look) {
+                __builtin_ia32_pause();
+                continue;
+            }
+            const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+            if (waited_us >= 50.0) {
+                if (waited_us < 2000.0) {
+                    sched_yield();
+                } else {
+                    timespec ts{0, nap_ns};
+                    nanosleep(&ts, nullptr);
+                    nap_ns = nap_ns < 1000000 ? nap_ns * 2 : 1000000;
+                }
+            }
+            if ((spins & 4095u) == 0 || waited_us >= 2000.0) {  // a failed launch or a device fault ends the wait with its error
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipErrorNotReady) continue;
                 HIP_TRY(q);
@@ -1043,6 +1067,8 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     }
     h->stats.kernel_family = h->P.fam;
     h->stats.repaired_groups = h->P.fam == 1 ? ctr_end[CTR_GFLAGS] : 0;
+    if (h->P.fam == 1 && (double)ctr_end[CTR_GFLAGS] > 0.004 * (double)h->range_ne * (double)((h->P.N + 15) / 16) + 4096.0)
+        h->g_holdoff = 9;  // (this batch is exact like any other; the handle's next 8 go to the exact-replay kernel)
     h->stats.walk_passes = ctr_end[CTR_PASSES];
     h->enq_passes = ctr_end[CTR_PASSES] > 1 ? kDefaultPasses : 1;
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];

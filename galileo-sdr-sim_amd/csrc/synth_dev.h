@@ -80,9 +80,6 @@ struct DevPlan {
     int signal;           // 0 BOC(1,1) (the reference), 1 CBOC(6,1,1/11) (GAL_CFG_CBOC)
     int rw;               // resampled-window body of k_synth: 1 every code step has 0.74 <= 2 f_code / fs < 1 (holds),
                           // 2 / 3 every code step has 2 f_code / fs <= 0.133 / 0.266 (<= 2 / 4 advances), 0 classic per-sample window index
-    uint32_t *wflag;      // [E * blocks_per_epoch * 4] cd: one word per wave of the k_synth launch, 1 = synthesise it again exactly
-    int cd;               // 1: k_synth takes the carrier table index from a fixed-point DDA (rw == 1, BOC(1,1), every carrier step of
-                          // the batch below 120 / (16 x 511) cycles per sample: synth_kernels.hip, chan_step_rw_cd)
     int fam;              // synthesis kernel family: 0 k_synth (one chunk per lane, exact replay), 1 k_synth_g (one 16-sample group per
                           // lane from the chunk's checkpoint in closed form + k_repair_g for the undecided groups; synth_group.hip)
     int gbpe;             // k_synth_g: blocks per epoch

@@ -420,14 +420,15 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         // a wrap that is pending at the chunk's first sample (:491) is taken here: every group of the chunk lies behind it
         const bool pend = lx >= 4092.0;
         const double x = pend ? lx - 4092.0 : lx;
-        r.yc = x + x;
-        r.pm = u2d(d2u(lp) ^ ((uint64_t)dsgnl << 32));
+        // (idle positions: phases far from every boundary the kernel looks at -- their zero checkpoints would sit ON one, 511 p = 0,
+        // and list every group of the epoch)
+        r.yc = onl ? x + x : 0.5;
+        r.pm = onl ? u2d(d2u(lp) ^ ((uint64_t)dsgnl << 32)) : 0.25;
         r.s = sl;
         r.dabs = dabsl;
         if (lane < NCH) {
             recw[buf * SG_MAXCH + lane] = r;
-            // (idle positions: steps zero, stream row zero, sign pairs zero -- no contribution whatever the aliased checkpoint
-            // holds; an undecided group listed on their account costs a replay, nothing else)
+            // (idle positions: steps zero, stream row zero, sign pairs zero -- no contribution)
             const uint32_t ks = onl ? (lib & 0xffffu) + 500u * (lib >> 16) + (pend ? 1u : 0u) : 0u;
             const uint32_t pair = syml[ks] * 4u + syml[ks + 1];
             syaw[buf * SG_MAXCH + lane] = mtab0 + pair * (SG_MPOS * 4u);

@@ -39,8 +39,8 @@ using namespace galdev;
 // The file is compiled as eight translation units, side by side (Makefile: -DGAL_TU=0..7), because the instantiations of
 // k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
 // GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
-// by both libraries; TU 5 the family (0, 3), TU 6 (1, 1): CBOC on resampled windows, TU 7 (0, 1) with the carrier index from a
-// fixed-point DDA (CD = 1, opt-in).  Without GAL_TU everything lands in one translation unit (tools/kasm.sh).
+// by both libraries; TU 5 the family (0, 3), TU 6 (1, 1): CBOC on resampled windows.  Without GAL_TU everything lands in one
+// translation unit (tools/kasm.sh).  (The default kernel of the reference geometry, k_synth_g, is synth_group.hip.)
 #if !defined(GAL_TU)
 #define GAL_TU_WALK 1
 #define GAL_TU_SYNTH 1
@@ -390,8 +390,8 @@ __global__ void k_walk_carr(DevPlan P, int first)
 // k_verify_carr: every leg of the executed epochs walked once more, genuinely and in closed form, from its own first
 // checkpoint: each checkpoint of the leg and the state it hands to the next leg must come out bit for bit (CTR_MISMATCH
 // otherwise, which sends gal_synth_finish into the all-walked fallback).  This is what k_synth's exact replay establishes on
-// its way; the carrier-DDA form of k_synth (CD = 1) never forms the exact phase, so batches that run it get this kernel on
-// the walker stream, beside the synthesis.  Same lane order as k_walk_carr (a wave = 64 legs of one slot).
+// its way; k_synth_g (synth_group.hip) never forms the exact phase, so batches that run it get this kernel on the walker
+// stream, beside the synthesis.  Same lane order as k_walk_carr (a wave = 64 legs of one slot).
 __global__ void k_verify_carr(DevPlan P)
 {
     if (P.ctr[CTR_UNVERIFIED] != 0) return;  // chain not complete: gal_synth_finish iterates and launches this again
@@ -1421,8 +1421,7 @@ __device__ __forceinline__ uint32_t rw_phase_c(const ChanState &c, const RwTmp &
 {
     return rw_phase_c_m<MODE>(GAL_SIGN_MASK_ST(c.st), t);
 }
-// (the same with the XOR mask of the symbol's signs supplied by the caller: k_synth<.., CD = 1> keeps the sign bytes of four
-// channels in one register, so that the packed symbol states are not live in the fast groups)
+// (the same with the XOR mask of the symbol's signs supplied by the caller)
 template <int MODE>
 __device__ __forceinline__ uint32_t rw_phase_c_m(const uint32_t mask, const RwTmp &t)
 {
@@ -1661,91 +1660,6 @@ __device__ __forceinline__ void chan_step_cboc_fast(ChanState &c, const ChanGrou
 }
 
 
-// ---- Carrier table index from a fixed-point DDA (k_synth<.., CD = 1>; BOC(1,1) on resampled windows; opt-in).
-// The reference's index k = (int)(511 p) needs the EXACT phase p of the sequential recurrence only where 511 p is within
-// the recurrence's rounding drift of an integer.  Everywhere else any approximation of 511 p with a known error bound has
-// the same floor.  Per channel the kernel therefore keeps, instead of the phase itself,
-//     t = CD_BIAS + 511 * (mirrored phase),   CD_BIAS = 2^20 + 512 + 2^-26,
-// a double in the binade [2^20, 2^21), where a double is a fixed-point number with 32 fraction bits: the low word of t IS
-// the fraction of 511 p + 2^-26, the low 20 bits of the high word ARE floor(511 p + 512 + 2^-26), and the address of the
-// table entry is ONE v_lshl_add_u32 of the high word (the exponent bits are folded into the base, cd_addr).
-//   * per sample:  t += c, c = 511 |d|.  t is on the 2^-32 grid, so the rounded sum is t + RN(c) EXACTLY (the host keeps
-//     batches away in which c lies half way between two grid points, where the direction would depend on t's parity):
-//     one v_add_f64 that is a 52-bit integer addition.  With the shift-add that is 2 VALU instructions where the
-//     exact-phase step has 5 (add, fract, mul, cvt, shift-add).
-//   * per full group:  t += kappa, kappa = 16 (c - RN(c)) (from LDS: s_ka), which takes the systematic part of the grid
-//     error out, and t -= 511 once t >= CD_BIAS + 511: the wrap of the phase, exact on the grid.
-//   * error: t differs from CD_BIAS + 511 p_exact by < 16 * 2^-33 (the group's systematic part before its correction)
-//     + 65 * 2^-33 (the roundings of the corrections) + 2^-33 (chunk start) + 1040 * 511 * 2^-53 (drift of the exact
-//     recurrence from the real line) < 9.7e-9 < 2^-26.  So the index can differ from the reference's only if the fraction
-//     of 511 p lies within 2^-26 of an integer, i.e. the low word of t is below CD_AMB = 2^7 (probability 2^-25 per
-//     channel-sample).  Every lane keeps the minimum of the low words of its chunk (v_min3_u32, one per two
-//     channel-samples); a wave in which any lane ends below CD_AMB -- about one in fifty -- raises its flag in
-//     DevPlan::wflag, and a second launch of the EXACT-phase kernel (k_synth<.., CD = 0> with the flags as its filter:
-//     blocks and waves without a flag leave at once) synthesises those waves' chunks again, after this kernel in stream
-//     order.  Nothing of that handling sits inside this kernel's sample loop (an in-loop repair was measured: its live
-//     ranges push the channel states into scratch).
-//   * table (per Doppler sign): entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps at 1, so
-//     511 p wraps at 511 -- entries 1023.. repeat 512.. and serve the samples of a group that follow a wrap); i < 512
-//     (mirrored phase still negative after a Doppler sign change): (int) truncates towards zero, so entry i holds k = i - 511.
-// The carrier checkpoints, which the exact replay verifies on its way, are verified by k_verify_carr: a genuine closed-form
-// walk of every leg (nco_walk.h) on the walker stream, beside this kernel.
-// (timing experiments only: tools/build_variant.sh x -DGAL_CD_DOCHECK=0 takes the chunk-end walk out)
-#ifndef GAL_CD_PIN
-#define GAL_CD_PIN 0  // scheduling unit of the DDA body: 2^k - 1 -> 2^k samples.  One sample: 1.214 ms (kernel without the chunk-end
-                      // walk, same box), two: 1.262, four: 1.54, eight: 1.84, none: 1.69 -- wider units spill (profiles/r03u_dda.md)
-#endif
-#ifndef GAL_CD_DOCHECK
-#define GAL_CD_DOCHECK 0  // 1: the chunk's carrier walk inside k_synth (the first form of the verification: 0.15 ms per launch)
-#endif
-#define CD_LUT_N 1152
-#define CD_AMB 128u
-#define CD_BIAS (1049088.0 + 1.4901161193847656250e-08)
-
-__device__ __forceinline__ uint32_t cd_min3(const uint32_t a, const uint32_t b, const uint32_t c)
-{
-    uint32_t d;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-// LDS byte address of the entry t points at (lutd: address of entry 0 minus the exponent bits of [2^20, 2^21) << 2)
-__device__ __forceinline__ uint32_t cd_addr(const double t, const uint32_t lutd)
-{
-    uint32_t a;
-    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"((uint32_t)(d2u(t) >> 32)), "s"(lutd));
-    return a;
-}
-
-// one sample of one channel in a resampled group, carrier from the DDA; lo = the fraction word of this sample
-__device__ __forceinline__ void chan_step_rw_cd(double &t, const uint32_t X, const int U, const double cr, const uint32_t lutd,
-                                                int &acc, uint32_t &lo)
-{
-    const int v = __builtin_amdgcn_sbfe((int)X, (uint32_t)(2 * U), 2);
-    const int e = *(const __attribute__((address_space(3))) int *)(uintptr_t)cd_addr(t, lutd);
-    gal_acc(acc, e, v);
-    lo = (uint32_t)d2u(t);
-    t = t + cr;
-}
-
-// slow groups (code wrap inside): chan_step_wrap with the carrier from the DDA
-__device__ __forceinline__ void chan_step_wrap_cd(ChanState &c, ChanGroup &g, double &t, const double cs2, const double cr,
-                                                  const uint32_t lutd, int &acc, uint32_t &lo)
-{
-    const bool ge = c.y >= 8184.0;
-    c.y = c.y - (ge ? 8184.0 : 0.0);
-    g.m = ge ? g.mw : g.m;
-    const int ic = (int)c.y;
-    int off;
-    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(off) : "v"(ic), "v"(g.m));
-    const int v = __builtin_amdgcn_sbfe((int)g.W, (uint32_t)off, 2);
-    const int e = *(const __attribute__((address_space(3))) int *)(uintptr_t)cd_addr(t, lutd);
-    gal_acc(acc, e, v);
-    lo = (uint32_t)d2u(t);
-    c.y = c.y + cs2;
-    t = t + cr;
-}
-
 #define GAL_CH_LIST(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11)
 #define GAL_MAX_NCH 12
 // ACC: add onto samples already in `iq` (second and later channel groups when > 12 channels are active)
@@ -1753,29 +1667,17 @@ __device__ __forceinline__ void chan_step_wrap_cd(ChanState &c, ChanGroup &g, do
 // RW: 1, 2 = fast groups take their 16 chip values from a RESAMPLED window (rw_phase_a/b/c) instead of indexing the
 //     window per sample; 1 needs 0.74 <= 2 f_code / fs < 1 on every channel of the batch (2.6 MS/s), 2 needs
 //     2 f_code / fs <= 0.133 (15.4 MS/s and above: config 4's 25 MS/s); the host decides (DevPlan::rw)
-// CD: 1 = the carrier table index comes from a fixed-point DDA instead of the exact phase (see chan_step_rw_cd); BOC(1,1) on
-//     resampled windows of form 1 only; the host decides (DevPlan::cd: every carrier step of the batch small enough)
-template <int NCH, bool ACC, int SIG = 0, int RW = 0, int CD = 0>
+template <int NCH, bool ACC, int SIG = 0, int RW = 0>
 __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_WAVES))) void k_synth(const DevPlan *__restrict__ Pd, SynGeom G,
                                                      const uint8_t *__restrict__ act_all,
-                                                     const int *__restrict__ nact_all, uint32_t *__restrict__ iq,
-                                                     uint32_t *__restrict__ wflag)
+                                                     const int *__restrict__ nact_all, uint32_t *__restrict__ iq)
 {
-    // wflag: one word per wave of the launch.  CD = 1: OUT, 1 = some lane of the wave met a sample whose DDA index is not
-    // certain (chan_step_rw_cd).  CD = 0: null, or IN as the filter of the launch that synthesises exactly those waves again.
     static_assert(NCH <= GAL_MAX_NCH, "extend GAL_CH_LIST");
-    if constexpr (CD == 0) {
-        if (wflag != nullptr) {
-            const uint4 f = *reinterpret_cast<const uint4 *>(wflag + (size_t)blockIdx.x * (SYN_BLOCK / 64));
-            if (__builtin_amdgcn_readfirstlane((int)(f.x | f.y | f.z | f.w)) == 0) return;
-        }
-    }
     __shared__ uint32_t s_str[NCH * STR_PITCH];
     // entry k + 512 of table 0: LUT[k & 511], of table 1: LUT[-k & 511]; CBOC: the same pair for TA, then for TB
     constexpr bool CBRW = SIG == 1 && RW != 0;  // CBOC on resampled windows: 8-byte (TA, TB) entries, k >= 0 tables only
     constexpr int LUT_TABLES = CBRW ? 1 : SIG == 1 ? 4 : 2;
-    static_assert(CD == 0 || (SIG == 0 && RW == 1), "carrier DDA: BOC(1,1) on resampled windows of form 1");
-    __shared__ int s_lut[CD ? 2 * CD_LUT_N : LUT_TABLES * 1024 * (CBRW ? 2 : 1)];
+    __shared__ int s_lut[LUT_TABLES * 1024 * (CBRW ? 2 : 1)];
     // RW: per channel the hold patterns of a 16-sample group (see rw_phase_a)
     constexpr int BINS = CBRW ? CB_BINS : RW_BINS, BPITCH = CBRW ? CB_BIN_PITCH : RW_BIN_PITCH;
     __shared__ uint2 s_bin[RW ? NCH * BPITCH : 1];
@@ -1787,8 +1689,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     __shared__ float s_thr6[CBRW ? NCH * 16 : 1];
     // CBOC on resampled windows: the code steps (used once per 16-sample group) live here instead of in 24 VGPRs -- this
     // instantiation needs two spread words per channel and 8-byte table reads, and spilled inside the group loop without
-    __shared__ double s_csl[(CBRW || CD) ? GAL_MAX_NCH : 1];
-    __shared__ double s_ka[CD ? GAL_MAX_NCH : 1];  // CD: the per-group corrections of the DDA (GAL_CD_YADV), used once per group
+    __shared__ double s_csl[CBRW ? GAL_MAX_NCH : 1];
     __shared__ double s_tie[GAL_MAX_NCH];
     __shared__ int s_rwbad;  // RW: a channel's group has more holds / advances than the pattern masks hold (the host's
                              // gate excludes it; if it happens all the same, every group of the block runs the slow body)
@@ -1838,13 +1739,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #pragma unroll
         for (int q = 0; q < LUT_PER_THREAD; ++q) {
             const int i = tid + q * SYN_BLOCK;
-            if constexpr (CD) {  // table (plain / conjugate) x CD_LUT_N + entry: see chan_step_rw_cd
-                const int tab = i >= CD_LUT_N, ii = i - tab * CD_LUT_N;
-                int k = ii < 512 ? ii - 511 : ii - 512;
-                k = k >= 511 ? k - 511 : k;
-                k = k >= 511 ? k - 511 : k;
-                lv[q] = p_lut[(tab ? -k : k) & 511];
-            } else if constexpr (CBRW) {  // int i = (table (plain / conjugate) x 512 + k) x 2 + (0: TA, 1: TB)
+            if constexpr (CBRW) {  // int i = (table (plain / conjugate) x 512 + k) x 2 + (0: TA, 1: TB)
                 const int k = (i >> 1) & 511;
                 lv[q] = p_lut[((i & 1) << 9) + (((i >> 10) ? -k : k) & 511)];
             } else {
@@ -1881,15 +1776,8 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
         // ---- hold patterns, step A: the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted: thread
         // (channel, u) ranks its own; thread (channel, 16) writes the sentinel and the tie binade of the code step
         if (tid == 0) s_rwbad = 0;
-        if constexpr (CBRW || CD != 0) {
+        if constexpr (CBRW) {
             if (tid < NCH) s_csl[tid] = rw_step_of(tid);
-        }
-        if constexpr (CD != 0) {  // (c = 511 |d| and kappa exactly as the chunk prologue forms them)
-            if (tid < NCH) {
-                const double c_ = tid < nact ? 511.0 * __builtin_fabs(p_dstep[e * G.S + (int)((awv[tid >> 2] >> (8 * (tid & 3))) & 0xffu)]) : 0.0;
-                const double cg_ = (c_ + 1048576.0) - 1048576.0;
-                s_ka[tid] = 16.0 * (c_ - cg_);
-            }
         }
         if (tid < NCH * 16) {
             const int j = tid >> 4, u = (tid & 15) + 1;
@@ -2020,15 +1908,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // classes is the one that wraps in this chunk -- about one wave in four instead of every wave, and when it does,
     // many of its lanes need the slow body, not one in ten.
     const int L = (tg * (SYN_BLOCK / 64) + (tid >> 6)) * 64 + (tid & 63);
-    if (L >= G.nchunks) {
-        if constexpr (CD != 0) {
-            if ((tid & 63) == 0) wflag[(size_t)blockIdx.x * (SYN_BLOCK / 64) + (tid >> 6)] = 0u;
-        }
-        return;
-    }
-    if constexpr (CD == 0) {
-        if (wflag != nullptr && wflag[(size_t)blockIdx.x * (SYN_BLOCK / 64) + (tid >> 6)] == 0u) return;
-    }
+    if (L >= G.nchunks) return;
     const int c = (L % G.per) * G.cls + L / G.per;  // (identity for cls == 1)
     const int n0 = c * G.R;
     int nsteps = G.N - n0;
@@ -2041,7 +1921,6 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 #define GAL_MIRROR_BITS(p, ds) p = u2d(((uint64_t)(GAL_HI(p) ^ (GAL_HI(ds) & 0x80000000u)) << 32) | (uint32_t)d2u(p));
     double yv[NCH], pv[NCH], csv[NCH], dsv[NCH];
     uint32_t stv[NCH];
-    [[maybe_unused]] uint32_t sgnv[NCH];  // CD: 1 = negative Doppler (conjugate table)
     {
         // ---- phase 2: the chunk's checkpoints (per lane) and the epoch's NCO steps (scalar)
         double cx[NCH];
@@ -2086,23 +1965,14 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
             double pm = pv[j];
             GAL_MIRROR_BITS(pm, dsv[j])  // mirrored: see ChanState
             pv[j] = on ? pm : 0.0;
-            if constexpr (CD != 0) {  // Y = 511 x mirrored phase, c = 511 |d| (chan_step_rw_cd)
-                sgnv[j] = on ? (GAL_HI(dsv[j]) >> 31) : 0u;
-                pv[j] = on ? __builtin_fma(511.0, pv[j], CD_BIAS) : CD_BIAS + 0.5;  // (idle: a fraction far from 0)
-                dsv[j] = uniform_f64(511.0 * __builtin_fabs(dsv[j]));
-                // (kappa -- what 16 sample steps lose because t + c lands on the 2^-32 grid, i.e. adds RN(c) instead of c -- is
-                // tabulated in LDS by the block prologue: s_ka)
-            }
         }
     }
 #define GAL_DECL(j)                                                                         \
     ChanState ch##j = {0.0, 0.0, 0u};                                                       \
     double cs##j = 0.0, ds##j = 0.0;                                                        \
-    [[maybe_unused]] uint32_t cdsg##j = 0u;                                                 \
     if (j < NCH) {                                                                          \
         ch##j.y = yv[j < NCH ? j : 0]; ch##j.p = pv[j < NCH ? j : 0]; ch##j.st = stv[j < NCH ? j : 0]; \
         cs##j = csv[j < NCH ? j : 0]; ds##j = dsv[j < NCH ? j : 0];                         \
-        if constexpr (CD != 0) cdsg##j = sgnv[j < NCH ? j : 0];                             \
     }
     GAL_CH_LIST(GAL_DECL)
 #undef GAL_DECL
@@ -2111,22 +1981,6 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     // (cast first, offset second: the generic-pointer offset in between is not always folded away by the compiler)
     // (CBOC on resampled windows: 512-entry tables of 8-byte entries, entry k = 0 first)
     const uint32_t lut0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)s_lut + (CBRW ? 0u : 512u * 4u));
-    // CD: per channel the base cd_addr adds the high word of t to: entry 0 of the channel's table (plain / conjugate) minus the
-    // exponent field of [2^20, 2^21), shifted like the index
-    [[maybe_unused]] const uint32_t cdl0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_int_ptr)s_lut);
-    [[maybe_unused]] const int cd_chunk = c;
-    [[maybe_unused]] uint32_t cd_amb = ~0u;  // the smallest fraction word this lane has seen in its chunk
-#define GAL_CDL(j)                                                                                                      \
-    [[maybe_unused]] const uint32_t lutd##j = __builtin_amdgcn_readfirstlane(cdl0 + cdsg##j * (CD_LUT_N * 4u) - (0x41300000u << 2));
-    GAL_CH_LIST(GAL_CDL)
-#undef GAL_CDL
-    // CD: byte (j & 3) of sgp[j >> 2] = the sign byte (bits 23:16) of channel j's packed symbol state
-    [[maybe_unused]] uint32_t sgp[3] = {0u, 0u, 0u};
-    if constexpr (CD != 0) {
-#define GAL_SGP(j) if (j < NCH) sgp[(j) >> 2] |= ((ch##j.st >> 16) & 0xffu) << (8 * ((j) & 3));
-        GAL_CH_LIST(GAL_SGP)
-#undef GAL_SGP
-    }
     uint32_t *out = iq + (size_t)er * G.N + n0;  // iq holds the executed range only
     // 64-byte bursts: a lane stores 16 samples back to back so that a half cache line leaves the CU whole
     // (16-byte pieces ~3000 cycles apart were measured at 2.9x the algorithmic HBM write traffic, 64-byte
@@ -2201,7 +2055,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // (no `j < nact` tests inside the group loop: see the zero-filled stream rows above)
 // RW: the once-per-group code advance (GAL_ADV) assumes fl(y + s) = y + RN_q(s) within a binade, which holds in every
 // binade but the channel's tie binade [tl, 2 tl) (s_tie, block prologue): groups that could touch it run the slow body
-#define GAL_ROOM(j) if (j < NCH) { const double r = thr2 - ch##j.y; room = r < room ? r : room; negp |= CD ? 0 : (int)GAL_HI(ch##j.p); \
+#define GAL_ROOM(j) if (j < NCH) { const double r = thr2 - ch##j.y; room = r < room ? r : room; negp |= (int)GAL_HI(ch##j.p); \
         if constexpr (RW) { const double tl = s_tie[j], yy = ch##j.y;                                                       \
             const double r2 = yy < tl ? (tl - tieb) - yy : (yy < 2.0 * tl ? -1.0 : 1048576.0);                              \
             room = r2 < room ? r2 : room; } }
@@ -2223,12 +2077,10 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
 // channel never contributes zero)
 /* the channel's code step: a register, or (CBOC on resampled windows) an LDS read */
 typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
-#define GAL_CS(j) ((CBRW || CD) ? ((lds_vf64_ptr)s_csl)[(j) < GAL_MAX_NCH ? (j) : 0] : cs##j)
+#define GAL_CS(j) (CBRW ? ((lds_vf64_ptr)s_csl)[(j) < GAL_MAX_NCH ? (j) : 0] : cs##j)
 #define GAL_STEP_C(j) if (j < NCH && j < nact) chan_step_cboc<j, CBRW ? 1 : 0>(ch##j, csl##j, ds##j, sg4##j, str0, Pd, ix##j, acc);
 #define GAL_STEP_S(j) if (j < NCH) chan_step_wrap(ch##j, gr##j, cs##j, ds##j, sg4##j, acc);
-/* (CD: the sign byte of the channel's symbol state is mirrored in sgp, see GAL_RW_C) */
-#define GAL_END(j) if (j < NCH) { group_end(ch##j, gr##j, Pd, ix##j);                                                    \
-                                  if constexpr (CD != 0) sgp[(j) >> 2] = gal_bfi(0xffu << (8 * ((j) & 3)), (ch##j.st >> 16) << (8 * ((j) & 3)), sgp[(j) >> 2]); }
+#define GAL_END(j) if (j < NCH) group_end(ch##j, gr##j, Pd, ix##j);
 // pin the step: without this the instruction selector floats the pure-arithmetic parts of all 16 steps apart
 // (all NCO chains first, all accumulates last) and spills hundreds of values
 #define GAL_PIN(a, b, c, d)                                                                              \
@@ -2246,28 +2098,10 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
 #define GAL_RW_B6(j) if (j < NCH) unsafe##j = rw_phase_b6<j>(rt##j, s_pat6);
 /* CBOC: an idle position (all-zero stream row) has B == C everywhere, so its (B + C) word is cleared by hand */
 #define GAL_RW_C(j) if (j < NCH) { if constexpr (CBRW) { rw_phase_d_cboc(rt##j, gx##j, gxb##j); gxb##j = j < nact ? gxb##j : 0u; } \
-                                   else if constexpr (CD != 0)                                                                  \
-                                       gx##j = rw_phase_c_m<RW>(__builtin_amdgcn_perm(sgp[(j) >> 2], sgp[(j) >> 2], 0x01010101u * ((j) & 3)), rt##j); \
                                    else gx##j = rw_phase_c<RW>(ch##j, rt##j); }
 #define GAL_STEP_R(j) if (j < NCH) { if constexpr (CBRW) chan_step_rw_cboc(ch##j, gx##j, gxb##j, u, ds##j, sg4##j, acc); \
                                      else chan_step_rw(ch##j, gx##j, u, ds##j, sg4##j, acc); }
 #define GAL_PIN_R(a, b, c, d) asm volatile("" : "+v"(acc), "+v"(ch##a.p), "+v"(ch##b.p), "+v"(ch##c.p), "+v"(ch##d.p));
-/* ---- CD: the carrier index from the DDA (chan_step_rw_cd).  td: the group's t, lq: the fraction word of the even sample */
-#define GAL_STEP_D(j) [[maybe_unused]] uint32_t lo##j = ~0u; if (j < NCH) chan_step_rw_cd(ch##j.p, gx##j, u, ds##j, lutd##j, acc, lo##j);
-/* the smallest fraction word of the part: one v_min3_u32 per two channel-samples */
-#define GAL_AMB_D(a, b, c, d) { cd_amb = cd_min3(cd_amb, lo##a, lo##b); if ((c) < NCH) cd_amb = cd_min3(cd_amb, lo##c, lo##d); }
-#define GAL_PIN_D(a, b, c, d) asm volatile("" : "+v"(acc), "+v"(cd_amb), "+v"(ch##a.p), "+v"(ch##b.p), "+v"(ch##c.p), "+v"(ch##d.p));
-/* end of a group: the correction kappa (full groups only: the handful of tail samples lose less than 16 x 2^-35 without) */ \
-/* and the wrap of the phase -- t - 511 is exact on the grid */
-#define GAL_CD_YADV(j)                                                                                                  \
-    if (j < NCH) {                                                                                                      \
-        const double tn_ = GSZ == SYN_GROUP ? ch##j.p + ((lds_vf64_ptr)s_ka)[(j) < GAL_MAX_NCH ? (j) : 0] : ch##j.p;   \
-        ch##j.p = tn_ >= CD_BIAS + 511.0 ? tn_ - 511.0 : tn_;                                                           \
-    }
-#define GAL_STEP_SD(j) [[maybe_unused]] uint32_t lo##j = ~0u; if (j < NCH) chan_step_wrap_cd(ch##j, gr##j, ch##j.p, csl##j, ds##j, lutd##j, acc, lo##j);
-#define GAL_PIN_SD(a, b, c, d)                                                                           \
-    asm volatile("" : "+v"(acc), "+v"(cd_amb), "+v"(ch##a.y), "+v"(ch##a.p), "+v"(ch##b.y), "+v"(ch##b.p), \
-                      "+v"(ch##c.y), "+v"(ch##c.p), "+v"(ch##d.y), "+v"(ch##d.p));
 // RW: the code NCO over the 16 samples of a fast group in three instructions.  Within a binade (and outside the tie
 // binade, which GAL_ROOM keeps away) every sequential step adds the same S = RN_q(cs2) = fl(y + cs2) - y, and y + 16 S
 // is a multiple of q below the binade's end, hence exact: fma(S, 16, y) IS the 16th sequential sum.  If that value
@@ -2316,25 +2150,13 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
             if (fast) {                                                          \
                 sf##a -= 1;                                                      \
                 GAL_RW_C(a) GAL_RW_C(b) GAL_RW_C(c) GAL_RW_C(d)                  \
-                if constexpr (CD != 0) {                                         \
-                    _Pragma("unroll") for (int u = 0; u < GSZ; ++u)              \
-                    {                                                            \
-                        int acc = o[u];                                          \
-                        GAL_STEP_D(a) GAL_STEP_D(b) GAL_STEP_D(c) GAL_STEP_D(d)  \
-                        GAL_AMB_D(a, b, c, d)                                    \
-                        if ((u & GAL_CD_PIN) == GAL_CD_PIN) { GAL_PIN_D(a, b, c, d) } \
-                        o[u] = acc;                                              \
-                    }                                                            \
-                    GAL_CD_YADV(a) GAL_CD_YADV(b) GAL_CD_YADV(c) GAL_CD_YADV(d)  \
-                } else {                                                         \
-                    GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)              \
-                    _Pragma("unroll") for (int u = 0; u < GSZ; ++u)              \
-                    {                                                            \
-                        int acc = o[u];                                          \
-                        GAL_STEP_R(a) GAL_STEP_R(b) GAL_STEP_R(c) GAL_STEP_R(d)  \
-                        if (u & 1) { GAL_PIN_R(a, b, c, d) }                     \
-                        o[u] = acc;                                              \
-                    }                                                            \
+                GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                  \
+                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
+                {                                                                \
+                    int acc = o[u];                                              \
+                    GAL_STEP_R(a) GAL_STEP_R(b) GAL_STEP_R(c) GAL_STEP_R(d)      \
+                    if (u & 1) { GAL_PIN_R(a, b, c, d) }                         \
+                    o[u] = acc;                                                  \
                 }                                                                \
                 GAL_ADV(a) GAL_ADV(b) GAL_ADV(c) GAL_ADV(d)                      \
             }                                                                    \
@@ -2375,19 +2197,6 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
                     GAL_PIN(a, b, c, d)                                          \
                     o[u] = acc;                                                  \
                 }                                                                \
-            } else if constexpr (CD != 0) {                                      \
-                GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)      \
-                [[maybe_unused]] const double csl##a = GAL_CS(a), csl##b = GAL_CS(b), csl##c = GAL_CS(c), csl##d = GAL_CS(d); \
-                _Pragma("unroll") for (int u = 0; u < GSZ; ++u)                  \
-                {                                                                \
-                    int acc = o[u];                                              \
-                    GAL_STEP_SD(a) GAL_STEP_SD(b) GAL_STEP_SD(c) GAL_STEP_SD(d)  \
-                    GAL_AMB_D(a, b, c, d)                                        \
-                    GAL_PIN_SD(a, b, c, d)                                       \
-                    o[u] = acc;                                                  \
-                }                                                                \
-                GAL_CD_YADV(a) GAL_CD_YADV(b) GAL_CD_YADV(c) GAL_CD_YADV(d)      \
-                GAL_END(a) GAL_END(b) GAL_END(c) GAL_END(d)                      \
             } else {                                                             \
                 GAL_BEGIN_S(a) GAL_BEGIN_S(b) GAL_BEGIN_S(c) GAL_BEGIN_S(d)      \
                 GAL_SGN4(a) GAL_SGN4(b) GAL_SGN4(c) GAL_SGN4(d)                  \
@@ -2470,12 +2279,6 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
 #undef GAL_RW_C1
 #undef GAL_STEP_R
 #undef GAL_PIN_R
-#undef GAL_STEP_D
-#undef GAL_AMB_D
-#undef GAL_PIN_D
-#undef GAL_CD_YADV
-#undef GAL_STEP_SD
-#undef GAL_PIN_SD
 #undef GAL_PIN
 #undef GAL_SGN4
 #undef GAL_BEGIN_F
@@ -2487,10 +2290,6 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
 
     }  // SIG == 0
 
-    if constexpr (CD != 0) {  // (lane 0 of a wave that got here is active: positions grow with the lane)
-        const bool again = __builtin_amdgcn_ballot_w64(cd_amb < CD_AMB) != 0;
-        if ((tid & 63) == 0) wflag[(size_t)blockIdx.x * (SYN_BLOCK / 64) + (tid >> 6)] = again ? 1u : 0u;
-    }
     // --- chain self-check: replayed end state must equal the walker's next checkpoint bit for bit (all loads first).
     {
         const double *const q_cpx = Pd->cp_x, *const q_cpp = Pd->cp_p;
@@ -2509,13 +2308,6 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
     if (j < NCH && j < nact) {                                                        \
         const uint32_t v = ei[j < NCH ? j : 0];                                       \
         bad += d2u(ch##j.y) != d2u(2.0 * ex[j < NCH ? j : 0]);                        \
-        if constexpr (CD != 0 && !GAL_CD_DOCHECK) { } else                           \
-        if constexpr (CD != 0) { /* the chunk's carrier walk in closed form (exact: nco_walk.h) must end at the next checkpoint */ \
-            const double d_ = p_dstep[ix##j];                                         \
-            const double pe_ = carr_walk_track(q_cpp[(size_t)ix##j * G.CP1 + cd_chunk], d_, 1.0 / __builtin_fabs(d_), nsteps, nsteps, \
-                                               nsteps, [](int, double) {}).p;          \
-            bad += pe_ != ep[j < NCH ? j : 0];                                        \
-        } else                                                                        \
         { double pm = ep[j < NCH ? j : 0]; GAL_MIRROR_BITS(pm, ds##j)                 \
           bad += ch##j.p != pm; } /* numeric: the mirrored form may leave -0.0 for +0.0 */ \
         bad += (ch##j.st & 0x3ffu) != ((v & 0x1ffu) | ((v >> 16) << 9));              \
@@ -2636,9 +2428,9 @@ extern "C" void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state,
 #endif  // GAL_TU_WALK
 
 #if GAL_TU_SYNTH
-template <bool ACC, int SIG, int RW = 0, int CD = 0>
+template <bool ACC, int SIG, int RW = 0>
 static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact,
-                          uint32_t *iq, int e0, int ne, hipStream_t st, uint32_t *wflag)
+                          uint32_t *iq, int e0, int ne, hipStream_t st)
 {
     const dim3 grid(ne * P->blocks_per_epoch), block(SYN_BLOCK);
     SynGeom G;
@@ -2646,7 +2438,7 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1; G.blocks_per_epoch = P->blocks_per_epoch;
     G.cls = P->cls > 0 ? P->cls : 1;
     G.per = P->nchunks / G.cls;
-#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC, SIG, RW, CD>), grid, block, 0, st, Pd, G, act, nact, iq, wflag); break;
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth<n, ACC, SIG, RW>), grid, block, 0, st, Pd, G, act, nact, iq); break;
     if constexpr (SIG == 1) {
         // the opt-in CBOC mode is built for 4, 8 and 12 positions only (a third of the compile time of this file went
         // into its 24 instantiations): positions beyond the active count are idle and skipped like in any epoch with
@@ -2670,36 +2462,33 @@ static int launch_synth_t(const DevPlan *P, const DevPlan *Pd, int nch, const ui
 // One launcher and one no-op kernel per k_synth family (each family is its own code object in the product build; HIP
 // loads a code object at the first launch of any of its kernels -- ~10 ms for the larger ones --, which galk_warm moves
 // from the caller's first batch into gal_synth_create).
-#define GAL_FAMILY(K, SIG, RW, CD)                                                                                   \
+#define GAL_FAMILY(K, SIG, RW)                                                                                       \
     __global__ void k_warm_f##K() {}                                                                                 \
     extern "C" void galk_warm_f##K(hipStream_t st) { hipLaunchKernelGGL(k_warm_f##K, dim3(1), dim3(64), 0, st); }    \
     extern "C" int galk_launch_synth_f##K(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate,               \
                                           const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne,         \
-                                          hipStream_t st, uint32_t *wflag)                                            \
+                                          hipStream_t st)                                                             \
     {                                                                                                                \
-        return accumulate ? launch_synth_t<true, SIG, RW, CD>(P, Pd, nch, act, nact, iq, e0, ne, st, wflag)           \
-                          : launch_synth_t<false, SIG, RW, CD>(P, Pd, nch, act, nact, iq, e0, ne, st, wflag);         \
+        return accumulate ? launch_synth_t<true, SIG, RW>(P, Pd, nch, act, nact, iq, e0, ne, st)                      \
+                          : launch_synth_t<false, SIG, RW>(P, Pd, nch, act, nact, iq, e0, ne, st);                    \
     }
 #if GAL_TU_FAMILY(1)
-GAL_FAMILY(1, 0, 0, 0)
+GAL_FAMILY(1, 0, 0)
 #endif
 #if GAL_TU_FAMILY(2)
-GAL_FAMILY(2, 0, 1, 0)
+GAL_FAMILY(2, 0, 1)
 #endif
 #if GAL_TU_FAMILY(3)
-GAL_FAMILY(3, 0, 2, 0)
+GAL_FAMILY(3, 0, 2)
 #endif
 #if GAL_TU_FAMILY(4)
-GAL_FAMILY(4, 1, 0, 0)
+GAL_FAMILY(4, 1, 0)
 #endif
 #if GAL_TU_FAMILY(5)
-GAL_FAMILY(5, 0, 3, 0)
+GAL_FAMILY(5, 0, 3)
 #endif
 #if GAL_TU_FAMILY(6)
-GAL_FAMILY(6, 1, 1, 0)
-#endif
-#if GAL_TU_FAMILY(7)
-GAL_FAMILY(7, 0, 1, 1)
+GAL_FAMILY(6, 1, 1)
 #endif
 #undef GAL_FAMILY
 #endif  // GAL_TU_SYNTH
@@ -2708,9 +2497,8 @@ GAL_FAMILY(7, 0, 1, 1)
 #define GAL_FAMILY_DECL(K)                                                                                           \
     extern "C" void galk_warm_f##K(hipStream_t st);                                                                  \
     extern "C" int galk_launch_synth_f##K(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate,               \
-                                          const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st, \
-                                          uint32_t *wflag);
-GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_FAMILY_DECL(5) GAL_FAMILY_DECL(6) GAL_FAMILY_DECL(7)
+                                          const uint8_t *act, const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st);
+GAL_FAMILY_DECL(1) GAL_FAMILY_DECL(2) GAL_FAMILY_DECL(3) GAL_FAMILY_DECL(4) GAL_FAMILY_DECL(5) GAL_FAMILY_DECL(6)
 #undef GAL_FAMILY_DECL
 
 __global__ void k_warm() {}
@@ -2719,7 +2507,7 @@ extern "C" void galk_touch(hipStream_t st) { hipLaunchKernelGGL(k_warm, dim3(1),
 // families a handle of this configuration can launch are loaded now (the walkers, the classic body, and the resampled-window
 // form whose gate the rate can pass: synth_api.cpp, gal_synth_plan); should a batch need another one after all, HIP loads it
 // at that launch.
-extern "C" void galk_warm(hipStream_t st, int signal, double ratio, int cd)
+extern "C" void galk_warm(hipStream_t st, int signal, double ratio)
 {
     hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st);
     const bool rw1 = ratio >= 0.70 && ratio <= 1.02;
@@ -2729,10 +2517,7 @@ extern "C" void galk_warm(hipStream_t st, int signal, double ratio, int cd)
         return;
     }
     galk_warm_f1(st);
-    if (rw1) {  // (the exact-phase form of the same body loads at its first launch, should a batch's Doppler call for it)
-        if (cd) galk_warm_f7(st);
-        else galk_warm_f2(st);
-    }
+    if (rw1) galk_warm_f2(st);
     if (ratio <= 0.14) galk_warm_f3(st);
     else if (ratio <= 0.28) galk_warm_f5(st);
 }
@@ -2741,17 +2526,11 @@ extern "C" int galk_launch_synth(const DevPlan *P, const DevPlan *Pd, int nch, i
                                  const int *nact, uint32_t *iq, int e0, int ne, hipStream_t st)
 {
     if (P->signal == 1)
-        return P->rw == 1 ? galk_launch_synth_f6(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st, nullptr)
-                          : galk_launch_synth_f4(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st, nullptr);
-    if (P->rw == 1) {
-        if (!P->cd || accumulate) return galk_launch_synth_f2(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st, nullptr);
-        // carrier index from the DDA; the waves that met an uncertain index are then synthesised again by the exact-phase
-        // kernel, which leaves at once everywhere else (chan_step_rw_cd)
-        const int rc = galk_launch_synth_f7(P, Pd, nch, 0, act, nact, iq, e0, ne, st, P->wflag);
-        return rc ? rc : galk_launch_synth_f2(P, Pd, nch, 0, act, nact, iq, e0, ne, st, P->wflag);
-    }
-    if (P->rw == 2) return galk_launch_synth_f3(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st, nullptr);
-    if (P->rw == 3) return galk_launch_synth_f5(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st, nullptr);
-    return galk_launch_synth_f1(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st, nullptr);
+        return P->rw == 1 ? galk_launch_synth_f6(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st)
+                          : galk_launch_synth_f4(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->rw == 1) return galk_launch_synth_f2(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->rw == 2) return galk_launch_synth_f3(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    if (P->rw == 3) return galk_launch_synth_f5(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
+    return galk_launch_synth_f1(P, Pd, nch, accumulate, act, nact, iq, e0, ne, st);
 }
 #endif  // GAL_TU_WALK

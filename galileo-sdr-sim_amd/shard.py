@@ -39,13 +39,33 @@ def rank_location_scenario(scenario_cls, nav_file, rank, duration_s=300.0, start
     return scenario_cls(nav_file, llh=llh, start=start, duration_s=duration_s, iono_enable=True, n_slots=n_slots).all(), llh
 
 
-def epoch_range(rank, world, n_epochs):
+WALK_COST = 0.1  # walking an epoch's NCO chains silently, relative to synthesising it (VALU work: walkers 37 M against
+                 # k_synth_g's 429 M wave-instructions per 1199 epochs, and legs in front of a range may be walked twice)
+
+
+def epoch_range(rank, world, n_epochs, walk_cost=WALK_COST):
     """Contiguous epoch range [first, first + count) of ONE scenario for rank `rank` (strong scaling, SURVEY.md
-    §8e-ii): every rank plans the whole scenario -- the NCO walk over all epochs is what gives it the exact
-    carrier state at its first epoch -- and synthesises only its own range (gal_synth_execute_range)."""
-    base, extra = divmod(n_epochs, world)
-    first = rank * base + min(rank, extra)
-    return first, base + (1 if rank < extra else 0)
+    §8e-ii): every rank plans the whole scenario and synthesises only its own range (gal_synth_execute_range).  The
+    carrier chain never restarts, so a rank WALKS the epochs [0, first + count) -- its prefix silently -- and the ranges are
+    cut so that walk(prefix + range) + synth(range) is the same on every rank: with w = walk_cost the boundaries satisfy
+    w b[r+1] + (b[r+1] - b[r]) = const, i.e. later ranks get shorter ranges (w = 0: equal ranges)."""
+    def bounds():
+        if walk_cost <= 0.0 or world == 1:
+            return [(k * n_epochs) // world for k in range(world + 1)]
+        q = 1.0 / (1.0 + walk_cost)
+        total = 1.0 - q ** world
+        b = [int(round(n_epochs * (1.0 - q ** k) / total)) for k in range(world + 1)]
+        m = 1 if n_epochs >= world else 0  # every rank at least one epoch where there are enough of them
+        b[0] = 0
+        for k in range(1, world):
+            b[k] = max(b[k], b[k - 1] + m)
+        b[world] = n_epochs
+        for k in range(world - 1, 0, -1):
+            b[k] = min(b[k], b[k + 1] - m)
+        return b
+
+    b = bounds()
+    return b[rank], b[rank + 1] - b[rank]
 
 
 def reduce_report(dist, device, elapsed_s, n_samples, checksum, group=None):

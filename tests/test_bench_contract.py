@@ -53,12 +53,28 @@ def test_report_exchange_falls_back_to_the_control_group():
             raise RuntimeError("NCCL error")
         return 1.5, 100, 7, [{"rank": 0}]
 
-    dist = object()
+    class FakeDist:  # the agreement on the fallback: MIN of the ranks' ok flags over the control group (here: one rank)
+        class ReduceOp:
+            MIN = "min"
+
+        def __init__(self, others_ok=1):
+            self.others_ok, self.calls = others_ok, []
+
+        def all_reduce(self, t, op=None, group=None):
+            self.calls.append((op, group))
+            t[0] = min(int(t[0]), self.others_ok)
+
+    dist = FakeDist()
     assert bench.exchange_report(None, "nccl", {"group": None}, report_ok) == (1.5, 100, 7, [{"rank": 0}], None)
     assert bench.exchange_report(dist, "gloo", {"group": None}, report_ok)[4] == "gloo" and calls[-1] == (None, "cpu")
     assert bench.exchange_report(dist, "nccl", {"group": "ctl"}, report_ok)[4] == "rccl" and calls[-1] == (None, "cuda")
+    assert dist.calls[-1] == ("min", "ctl")
     out = bench.exchange_report(dist, "nccl", {"group": "ctl"}, report_rccl_down)
     assert out[:4] == (1.5, 100, 7, [{"rank": 0}]) and out[4].startswith("gloo (RCCL failed: RuntimeError")
     assert calls[-2:] == [(None, "cuda"), ("ctl", "cpu")]
+    # RCCL worked HERE but failed on another rank: this rank falls back with the others instead of keeping its result
+    n = len(calls)
+    out = bench.exchange_report(FakeDist(others_ok=0), "nccl", {"group": "ctl"}, report_ok)
+    assert out[4] == "gloo (RCCL failed: on another rank)" and calls[n:] == [(None, "cuda"), ("ctl", "cpu")]
     with pytest.raises(RuntimeError):  # no control group to fall back to: the error is the caller's
         bench.exchange_report(dist, "nccl", {"group": None}, report_rccl_down)

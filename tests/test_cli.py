@@ -218,3 +218,30 @@ def test_cli_file_sink_variants_agree(tmp_path):
     for f in (a, b, c):
         data = f.read_bytes()
         assert len(data) == REF["G1"]["bytes"] and hashlib.md5(data).hexdigest() == REF["G1"]["md5"], f
+
+
+@pytest.mark.gpu
+def test_cli_120s_file_equals_library(pkg, tmp_path):
+    """BASELINE configs[0/1] literally -- the reference command line with -d 120 into a file (1199 epochs, 1 246 960 000 bytes:
+    src/galileo-sdr.cpp:438,542,658) -- against the same scenario through the library (front-end rows -> gal_synth_run_host);
+    bench.py's e2e.file_sink leg times this command and reports the same comparison (md5_equals_library)."""
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    out = os.path.join(shm, "galtest_%d_120s.ishort" % os.getpid())
+    try:
+        r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "120", "-U", "1", "-b", "1", "-P", "0",
+                            "-o", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert os.path.getsize(out) == 1199 * 260000 * 4
+        h = hashlib.md5()
+        with open(out, "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(blk)
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+    rows = pkg.Scenario(NAV, llh=(-6.0, 51.0, 100.0), start="2022/02/20,12:00:00", duration_s=120.0, iono_enable=True).all()
+    assert rows.shape == (1199, 16)
+    with pkg.SynthEngine(device=0) as eng:
+        iq, _, stats = eng.run_host(rows)
+    assert stats["chain_mismatch"] == 0 and stats["kernel_family"] == 1
+    assert h.hexdigest() == hashlib.md5(iq.tobytes()).hexdigest()

@@ -113,6 +113,23 @@ def test_code_other_rates_and_edges(W):
             assert (np.float64(axe).view(np.uint64), aie, afl) == (np.float64(bxe).view(np.uint64), bie, bfl)
 
 
+def test_code_small_steps_are_stepped_one_by_one(W):
+    """Steps below what gal_synth_plan admits (f_code / fs < 2^-20): the closed-form batches of code_walk estimate their quotient with
+    the reciprocal of the STEP, which can overshoot floor(t / dk) by more than the one the remainder test takes back once the step
+    is within ~2^20 ulps of the phase (16 of 3000 cases with steps 1e-11 .. 2e-9 near binade tops and the wrap) -- such
+    steps are taken one by one; at and above 2^-20 the batches are exact (steps 2^-20 .. 2^-12 here, the rates elsewhere)."""
+    rng = np.random.default_rng(9)
+    for t in range(400):
+        c = float(10.0 ** rng.uniform(-11.5, -6.5)) if t % 2 else float(2.0 ** rng.uniform(-20.0, -12.0))
+        k = int(rng.integers(1, 12))
+        top = 2.0 ** k if t % 3 else 4092.0
+        x = top - c * float(rng.integers(0, 40000)) - (rng.random() < 0.5) * 2.0 ** (k - 52) * float(rng.integers(0, 8))
+        x = min(max(x, 0.0), 4092.0)
+        (ax, ai, axe, aie, afl), (bx, bi, bxe, bie, bfl) = _code_pair(W, x, int(rng.integers(0, 500)), c, 60000, 1024)
+        assert np.array_equal(ax.view(np.uint64), bx.view(np.uint64)) and np.array_equal(ai, bi), (x, c)
+        assert (np.float64(axe).view(np.uint64), aie, afl) == (np.float64(bxe).view(np.uint64), bie, bfl), (x, c)
+
+
 def _chain_truth(W, p, d, N):
     ends = np.zeros(len(d))
     for e in range(len(d)):

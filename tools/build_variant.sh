@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../galileo-sdr-sim_amd"
 name=$1; shift
 mkdir -p variants/obj_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value"
-for k in 1 2 3 4 5 6 7; do
+for k in 1 2 3 4 5 6; do
   /opt/rocm/bin/hipcc $FLAGS -DGAL_TU=$k "$@" -c csrc/synth_kernels.hip -o variants/obj_$name/f$k.o &
 done
 wait
