@@ -721,7 +721,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         P.gthreads = best_thr;
         P.gbpe = best_bpe;
 #ifdef GAL_TEST_HOOKS
-        if (const char *env = getenv("GAL_G_THREADS")) P.gthreads = atoi(env) == 1024 ? 1024 : 512;
+        if (const char *env = getenv("GAL_G_THREADS")) P.gthreads = atoi(env);
         if (const char *env = getenv("GAL_G_BPE")) P.gbpe = atoi(env) > 0 ? atoi(env) : P.gbpe;
 #endif
     }

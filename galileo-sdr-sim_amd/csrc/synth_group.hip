@@ -409,11 +409,17 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     // checkpoint of chunk cc: x (pre-check code phase, chips), p (carrier phase), ibit | flipped << 16
     double lx = 0.0, lp = 0.0;
     uint32_t lib = 0u;
+    // (global-address-space loads: a FLAT load counts on the LDS counter as well, and the sample loop's explicit lgkmcnt waits
+    // would then wait for this prefetch instead of running a sample ahead)
+    typedef const __attribute__((address_space(1))) double *sg_gbl_f64;
+    typedef const __attribute__((address_space(1))) uint32_t *sg_gbl_u32;
+    const sg_gbl_f64 g_cpx = (sg_gbl_f64)(uintptr_t)p_cpx + cpl, g_cpp = (sg_gbl_f64)(uintptr_t)p_cpp + cpl;
+    const sg_gbl_u32 g_cpi = (sg_gbl_u32)(uintptr_t)p_cpi + cpl;
     auto fetch = [&](const int cc) {
         const int ce = cc < G.nchunks ? cc : G.nchunks - 1;
-        lx = p_cpx[cpl + ce];
-        lp = p_cpp[cpl + ce];
-        lib = p_cpi[cpl + ce];
+        lx = g_cpx[ce];
+        lp = g_cpp[ce];
+        lib = g_cpi[ce];
     };
     auto stage = [&](const int buf) {
         SgRec r;
@@ -579,7 +585,11 @@ template <bool ACC>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
-    const dim3 grid(ne * G.blocks_per_epoch), block(P->gthreads == 1024 ? 1024 : 512);
+#ifdef SG_FORCE_THREADS  // A/B builds (tools/build_variant_g.sh)
+    const dim3 grid(ne * G.blocks_per_epoch), block(SG_FORCE_THREADS);
+#else
+    const dim3 grid(ne * G.blocks_per_epoch), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
+#endif
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
     switch (nch) {
         GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)

@@ -23,7 +23,7 @@ acc = collections.defaultdict(list)
 for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        if "k_synth" not in r["Kernel_Name"]:
+        if "k_synth" not in r["Kernel_Name"]:  # (k_synth or k_synth_g: whichever the default bench runs)
             continue
         per[r["Dispatch_Id"]][r["Counter_Name"]] = per[r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     for d in per.values():

@@ -24,7 +24,7 @@ python3 - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]
 d = json.load(open("gpurun_out/%s_pmc_k_synth_all.json" % tag))
-out = {"kernel": "k_synth<12,false,0,1>", "workload": "M-SYN12 1199x260000x12ch, chunk 1040",
+out = {"kernel": "k_synth_g<12,false>", "workload": "M-SYN12 1199x260000x12ch, chunk 1024 (16-sample groups)",
        "write_size_kib": d.get("WRITE_SIZE"), "fetch_size_kib_raw": d.get("FETCH_SIZE"),
        "fetch_correction": "x2 (gfx950, MI355X_MICROARCH.md HBM section)",
        "hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"),
