@@ -254,13 +254,12 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
         const bool on = j < nact;
         // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window at or
-        // across the code wrap is one contiguous read
-        for (int t = tid; t < SG_STR_PITCH; t += nthr) {
-            uint32_t w;
-            if (t < STR_WORDS - 1) w = src[t];
-            else if (t == STR_WORDS - 1) w = (src[t] & 0xffffu) | (src[0] << 16);
-            else w = (src[t - STR_WORDS] >> 16) | (src[t - STR_WORDS + 1] << 16);
-            s_str[j * SG_STR_PITCH + t] = on ? w : 0u;
+        // across the code wrap is one contiguous read: a plain copy of words 0 .. 510, then the 69 spliced ones
+        for (int t = tid; t < STR_WORDS - 1; t += nthr) s_str[j * SG_STR_PITCH + t] = on ? src[t] : 0u;
+        if (tid < SG_STR_PITCH - (STR_WORDS - 1)) {
+            const int t = tid;  // row word 511 + t
+            const uint32_t w = t == 0 ? ((src[STR_WORDS - 1] & 0xffffu) | (src[0] << 16)) : ((src[t - 1] >> 16) | (src[t] << 16));
+            s_str[j * SG_STR_PITCH + STR_WORDS - 1 + t] = on ? w : 0u;
         }
     }
     for (int i = tid; i < 16 * SG_MPOS; i += nthr) {
@@ -338,20 +337,21 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     for (int t = tid; t < NCH * (RW_BINS + 1); t += nthr) {
         const int j = t / (RW_BINS + 1), b = t - j * (RW_BINS + 1);
         const float lo = (float)b * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / RW_BINS) + RW_EDGE;
-        int cnt = 0, idb = 0;
-        float thr = 4.0f;  // "no threshold near this bin": never reached, never close
-        for (int i = 0; i < 15; ++i) {
-            const float th = s_thr[j * 16 + i];
-            idb += th < lo;
-            const bool in = th >= lo && th < hi;
-            cnt += in;
-            thr = in ? th : thr;
-        }
+        // the thresholds are sorted (entry 15: the sentinel 2.0): the number below the bin by bisection, then the (at most two
+        // that matter) inside it
+        const float *th = s_thr + j * 16;
+        int idb = th[7] < lo ? 8 : 0;
+        idb += th[idb + 3] < lo ? 4 : 0;
+        idb += th[idb + 1] < lo ? 2 : 0;
+        idb += th[idb] < lo ? 1 : 0;
+        const float t0 = th[idb], t1 = idb < 15 ? th[idb + 1] : 2.0f;
+        int cnt = (t0 < hi) + (t1 < hi);
+        float thr = t0 < hi ? t0 : 4.0f;  // 4: "no threshold near this bin" -- never reached, never close
         // 0 and 1 are thresholds too -- of sample 0's own half chip, which the approximate phase decides only away from them
         // (k_synth knows its group-start phase exactly): bin 0 compares with 0 (never below it: the pattern offset makes up
         // for the unconditional "f >= threshold"), the last bin with 1; a pattern threshold beside them leaves the bin undecidable
         uint32_t off = (uint32_t)idb * 16u;
-        if (b == 0) { thr = cnt ? __builtin_nanf("") : 0.0f; off -= 16u; cnt = 0; }
+        if (b == 0) { thr = cnt ? __builtin_nanf("") : 0.0f; off -= cnt ? 0u : 16u; cnt = 0; }
         if (b == RW_BINS - 1) { thr = cnt ? __builtin_nanf("") : 1.0f; cnt = 0; }
         if (cnt >= 2 || b == RW_BINS) thr = __builtin_nanf("");  // undecidable here
         if (j >= nact) { thr = 4.0f; off = 0u; }
