@@ -181,6 +181,7 @@ struct gal_synth {
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
     // their smallest distance (rw_threshold_gap) -- reused only for the identical step
     std::vector<double> rw_s0, rw_g0, rw_e0;
+    double prev_wait_us = 0.0;  // how long the last gal_synth_finish waited for its batch (paces the next one's naps)
     int g_holdoff = 0;  // batches for which k_synth_g is not used although it could be: its last batch listed too many groups
 };
 
@@ -936,30 +937,34 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     // stream): poll the sequence number; the stream itself is looked at now and then, so that a failed launch or a
     // device fault ends the wait with its error instead of hanging it.
     {
-        // Waiting in three stages, so that a batch that is about to complete is seen at once and a long one does not cost a
-        // core: 50 us of pause-spinning, then up to 2 ms of sched_yield (other runnable threads of the process -- the CLI's
-        // producer and writer, other handles' callers -- get the core), then naps that grow from 20 us to 1 ms.
+        // Waiting without burning a core and without adding latency: 50 us of pause-spinning; then naps (nanosleep: ~70 us each
+        // with the kernel's timer slack) for as long as the batch is EXPECTED to need -- 70 % of what the handle's previous
+        // finish() had to wait, minus a nap; then sched_yield (other runnable threads of the process -- the CLI's producer and
+        // writer, other handles' callers -- get the core, a lone caller sees the record at once).  A handle's batches are alike,
+        // so in steady state the naps cover most of the wait and the yields only its last fifth.
         const uint32_t want = h->seq;
         const auto t_begin = std::chrono::steady_clock::now();
         unsigned spins = 0;
-        long nap_ns = 20000;
+        double waited_us = 0.0;
+        const double nap_until_us = 0.7 * h->prev_wait_us - 150.0;
         while (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) != want) {
             const bool look = (++spins & 255u) == 0;
             if (!look) {
                 __builtin_ia32_pause();
                 continue;
             }
-            const double waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+            waited_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+            bool napped = false;
             if (waited_us >= 50.0) {
-                if (waited_us < 2000.0) {
-                    sched_yield();
-                } else {
-                    timespec ts{0, nap_ns};
+                if (waited_us < nap_until_us) {
+                    timespec ts{0, 50000};
                     nanosleep(&ts, nullptr);
-                    nap_ns = nap_ns < 1000000 ? nap_ns * 2 : 1000000;
+                    napped = true;
+                } else {
+                    sched_yield();
                 }
             }
-            if ((spins & 4095u) == 0 || waited_us >= 2000.0) {  // a failed launch or a device fault ends the wait with its error
+            if ((spins & 4095u) == 0 || napped) {  // a failed launch or a device fault ends the wait with its error
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipErrorNotReady) continue;
                 HIP_TRY(q);
@@ -972,6 +977,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
                 break;
             }
         }
+        h->prev_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
     }
     float ms_walk = 0, ms_synth = 0;
     hipEventElapsedTime(&ms_walk, h->ev[0], h->ev[1]);
