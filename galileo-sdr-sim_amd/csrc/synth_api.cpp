@@ -123,7 +123,8 @@ constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block 
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
 constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = chunk length of its batches (synth_group.hip: SG_CHUNK)
 constexpr int kGroupSyms = 64;      // ... symbol masks per channel and epoch (SG_SYMS)
-constexpr int kGroupListCap = 1 << 16;  // ... capacity of the undecided-group list (a 120 s batch lists ~2000)
+constexpr int kGroupListMin = 1 << 16;  // ... least capacity of the undecided-group list (a 120 s batch lists ~2000 of 19.5 M groups);
+                                        // a plan's list holds 0.5 % of its groups + this
 constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + stitch (which translates on the spot), one spare --
                                     // no-op launches in front of k_synth when the chain is complete after one, as it normally
                                     // is; a handle whose last batch got by with one enqueues one (gal_synth_finish iterates and
@@ -351,7 +352,8 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
     {
         const double ratio = 2.0 * 1.023e6 / cfg->sample_rate;
-        if (!(cfg->flags & (GAL_CFG_CBOC | GAL_CFG_EXACT_REPLAY)) && ratio >= 0.70 && ratio <= 1.02 && cfg->chunk_samples <= 0)
+        if (!(cfg->flags & (GAL_CFG_CBOC | GAL_CFG_EXACT_REPLAY)) && ((ratio >= 0.70 && ratio <= 1.02) || ratio <= 0.28) &&
+            cfg->chunk_samples <= 0)
             galk_warm_g(nullptr);
     }
     create_stage("warm launches enqueued");
@@ -435,6 +437,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
     // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel, thresholds a bin apart
     bool rw_ok = true;
+    double cs2_max = 0.0;  // largest code step of the batch, half chips per sample
     bool g_ok = true;   // k_synth_g: every carrier step in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries
                         // per group (the table's extension behind a wrap), and a phase that moves: a carrier that stands still
                         // ON an index boundary would have every one of its groups listed for the exact replay
@@ -479,6 +482,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             }
             if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
+                cs2_max = std::max(cs2_max, cs2);
                 const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
                 rw_ok = mode != 0 && (rw_mode == 0 || rw_mode == mode);
                 rw_mode = mode;
@@ -487,7 +491,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                 if (rw_ok && cs2 != h->rw_s0[s]) {
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
-                    h->rw_e0[s] = mode == 1 ? rw_threshold_edge(cs2) : 0.0;
+                    h->rw_e0[s] = rw_threshold_edge(cs2);
                     // CBOC: the half-period parity pattern steps by 6 s per sample; only the hold form (1) exists there
                     if (cboc) h->rw_g0[s] = mode == 1 ? std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2)) : 0.0;
                 }
@@ -514,9 +518,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     // Doppler with the phase on the 1 / 1300 lattice of 2 x 1.023 / 2.6, a synthetic input -- lists a percent of its groups, and
     // k_repair_g then costs more than the exact-replay kernel; the next 8 batches of the handle take that one)
     if (h->g_holdoff > 0) h->g_holdoff -= 1;
-    bool fam_g = !cboc && rw_ok && rw_mode == 1 && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) && nact_max > 0 &&
-                 h->g_holdoff == 0 &&
-                 (double)N / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
+    bool fam_g = !cboc && rw_ok && rw_mode >= 1 && rw_mode <= 3 && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
+                 nact_max > 0 && h->g_holdoff == 0 &&
+                 (double)N * cs2_max / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
                  (double)E * (double)((N + kGroupChunk - 1) / kGroupChunk) * 64.0 < 4294967296.0;
 #ifdef GAL_TEST_HOOKS
     if (getenv("GAL_SYNTH_RW")) fam_g = false;  // the forced window forms are k_synth's
@@ -636,7 +640,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
-    const size_t o_gflist = take(fam_g ? (size_t)kGroupListCap * 4 : 16);
+    const size_t g_groups = (size_t)E * (size_t)((N + 15) / 16);
+    const size_t g_cap = std::min<size_t>((size_t)kGroupListMin + g_groups / 200, (size_t)1 << 30);
+    const size_t o_gflist = take(fam_g ? g_cap * 4 : 16);
     // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
     size_t single_legs = (size_t)kScanSingleBlockLegs;
 #ifdef GAL_TEST_HOOKS
@@ -708,17 +714,21 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.ctr = (int *)(base + o_ctr);
     P.fam = fam_g ? 1 : 0;
     P.gflist = (uint32_t *)(base + o_gflist);
-    P.gflist_cap = kGroupListCap;
+    P.gflist_cap = (int)g_cap;
 #ifdef GAL_TEST_HOOKS
-    if (const char *env = getenv("GAL_G_LIST_CAP")) P.gflist_cap = std::max(1, std::min(kGroupListCap, atoi(env)));  // overflow path
+    if (const char *env = getenv("GAL_G_LIST_CAP")) P.gflist_cap = std::max(1, std::min((int)g_cap, atoi(env)));  // overflow path
 #endif
     {
         // k_synth_g: a block takes an epoch's chunks (or 1 / bpe of them), its waves one chunk at a time
         // measured (M-SYN12, kernel alone): 512 threads x 1 / 2 / 4 blocks per epoch 0.908 / 0.943 / 0.938 ms, 1024 threads x 1 / 2
         // 1.055 / 1.107 -- blocks do not run in rounds (the last ones run on a half-empty device, faster), so the cut only has to
         // give every CU its two blocks: the smallest power of two with E x bpe >= 512, as long as every wave still gets a chunk
+        // -- and, where an epoch is long enough that a block's tables are cheap beside its samples (16 chunks per wave and more:
+        // BASELINE config 4's 2442-chunk epochs, not the reference's 254), on until the batch is 4096 blocks: 600 such epochs as
+        // 600 blocks ran as one full round and a second one of 88 (5.7 ms per launch; cut in 8: see DESIGN.md 5.1)
         int best_thr = 512, best_bpe = 1;
         while (E * best_bpe < 512 && best_bpe * 2 * (best_thr / 64) <= nchunks) best_bpe *= 2;
+        while (E * best_bpe < 4096 && nchunks / (best_bpe * 2 * (best_thr / 64)) >= 16) best_bpe *= 2;
         P.gthreads = best_thr;
         P.gbpe = best_bpe;
 #ifdef GAL_TEST_HOOKS

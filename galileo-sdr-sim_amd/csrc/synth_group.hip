@@ -80,12 +80,23 @@ __device__ __forceinline__ uint32_t sg_min3(const uint32_t a, const uint32_t b, 
     return d;
 }
 
+// all 16 fields = field d of w (a two's-complement 2-bit value 00 / 01 / 11)
+__device__ __forceinline__ uint32_t sg_rep(const uint32_t w, const int d)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)w, 2 * d, 1);      // 0 / ~0: the field's low bit
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)w, 2 * d + 1, 1);  // ... its high bit
+    return gal_bfi(0x55555555u, lo, hi);
+}
+
 __device__ __forceinline__ double sg_f64(const uint32_t lo, const uint32_t hi) { return u2d(((uint64_t)hi << 32) | lo); }
 
 // One part: CNT channel positions J0 .. J0+CNT-1 of one 16-sample group, in phases, each run for all positions of the part
 // before the next one starts, so that the part waits ONCE for each round of LDS reads.  o[]: the group's int16 pairs (I, Q) as
 // they go to memory; amb: the smallest fraction word the lane has seen; undec: lanes with an undecided chip pattern.
-template <int J0, int CNT>
+// MODE: the form of the resampled window (k_synth's RW): 1 = the window advances every sample except at <= 4 HOLDS (code step 0.74 ..
+// 1 half chips per sample: the reference's 2.6 MS/s), 2 = it advances at <= 2 samples of the group (code step <= 0.133: 15.4 MS/s and
+// above), 3 = at <= 4 samples (<= 0.266: 7.7 .. 15.4 MS/s)
+template <int J0, int CNT, int MODE>
 __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &undec, const double g16, const SgRec *rec, const uint32_t *sya,
                                         const double *s_c511, const uint32_t *s_lutd,
                                         const uint32_t *s_str, const uint2 *s_bin, const uint4 *s_pat)
@@ -148,7 +159,18 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const uint32_t W = __builtin_amdgcn_alignbit(hi[q], lo[q], (uint32_t)ic0[q] << 1) ^ mask[q];
-            X[q] = rw_spread(window_signed(W), M[q]);
+            if constexpr (MODE == 1) {
+                X[q] = rw_spread(window_signed(W), M[q]);
+            } else {  // field 0 everywhere, field 1 from the first advance on, field 2 from the second, ...
+                const uint32_t w = window_signed(W);
+                uint32_t x = gal_bfi(M[q].x, sg_rep(w, 1), sg_rep(w, 0));
+                x = gal_bfi(M[q].y, sg_rep(w, 2), x);
+                if constexpr (MODE == 3) {
+                    x = gal_bfi(M[q].z, sg_rep(w, 3), x);
+                    x = gal_bfi(M[q].w, sg_rep(w, 4), x);
+                }
+                X[q] = x;
+            }
         }
     }
     // ---- the 16 samples: chip value from field u of X, table address from the high word of t.  The table reads are issued
@@ -198,7 +220,7 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
 }
 
 // ACC: add onto samples already in `iq` (second and later channel groups when more than 12 channels are active)
-template <int NCH, bool ACC>
+template <int NCH, bool ACC, int MODE>
 __global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(SG_WAVES_PER_EU)))
 void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restrict__ act_all, const int *__restrict__ nact_all,
                uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
@@ -369,7 +391,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         double gp = 0.0;  // floor(f), f < 1
         for (int u = 1; u <= 15; ++u) {
             const double g = __builtin_floor(f + (double)u * s);
-            if (g == gp) {  // sample u HOLDS the half chip of sample u - 1
+            if ((MODE >= 2) ? (g != gp) : (g == gp)) {  // MODE 1: sample u HOLDS the half chip of sample u - 1; 2, 3: ADVANCES
                 const uint32_t m = ~0u << (2 * u);
                 m0 = d == 0 ? m : m0; m1 = d == 1 ? m : m1; m2 = d == 2 ? m : m2; m3 = d == 3 ? m : m3;
                 ++d;
@@ -377,7 +399,8 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
             gp = g;
         }
         if (j >= nact) m0 = m1 = m2 = m3 = 0u;
-        else if (d > 4) s_rwbad = 1;  // more holds than the masks carry (the host's gate excludes it): every group is listed
+        else if (d > (MODE == 2 ? 2 : 4)) s_rwbad = 1;  // more holds / advances than the masks carry (the host's gate excludes it):
+                                                        // every group is listed
         s_pat[t] = make_uint4(m0, m1, m2, m3);
     }
     __syncthreads();
@@ -471,7 +494,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         const SgRec *rec = recw + buf * SG_MAXCH;
         const uint32_t *sya = syaw + buf * SG_MAXCH;
         // balanced parts: 5, 6, 7, 9, 10, 11 positions are cut 3+2, 3+3, 4+3, 3+3+3, 4+3+3, 4+4+3
-#define SG_PART(J0, CNT) sg_part<J0, CNT>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat); \
+#define SG_PART(J0, CNT) sg_part<J0, CNT, MODE>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat); \
                          __builtin_amdgcn_sched_barrier(0);
         if constexpr (NCH <= 4) { SG_PART(0, NCH) }
         else if constexpr (NCH == 5) { SG_PART(0, 3) SG_PART(3, 2) }
@@ -505,14 +528,19 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
 // chunk's checkpoint advanced by 16 g samples in closed form (nco_walk.h) -- for ALL active channels of the epoch (every
 // channel group of a > 12-channel batch), written over what the synthesis launches left.  A row of 16 lanes takes one
 // group: lane r the slots r, r + 16, ..; the row then sums its 16 x (I, Q) and lane u stores sample u (:536-537).
-__global__ void k_repair_g(DevPlan P, SynGeom G, uint32_t *__restrict__ iq, const uint32_t *__restrict__ flist, const int flist_cap)
+__global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t *__restrict__ iq, const uint32_t *__restrict__ flist,
+                                                  const int flist_cap)
 {
+    __shared__ int s_lut[512];  // int16 pairs (2 cos, 2 sin): the one table the 16 samples gather from
     const int n_raw = P.ctr[CTR_GFLAGS];
     const int n = n_raw < flist_cap ? n_raw : flist_cap;
     if (n_raw > flist_cap && blockIdx.x == 0 && threadIdx.x == 0) P.ctr[CTR_GOVER] = 1;  // gal_synth_finish repeats the batch exactly
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = threadIdx.x & 15;
     const int nrows = (gridDim.x * blockDim.x) >> 4;
+    if (((int)blockIdx.x * (int)blockDim.x >> 4) >= n) return;  // no row of this block has a group
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_lut[i] = P.lut[i];
+    __syncthreads();
     for (int i = gt >> 4; i < n; i += nrows) {
         const uint32_t ent = flist[i];
         const int g = (int)(ent & 63u);
@@ -534,33 +562,47 @@ __global__ void k_repair_g(DevPlan P, SynGeom G, uint32_t *__restrict__ iq, cons
             const uint32_t cib = P.cp_ib[cp];
             const CodeEnd ce = code_walk(P.cp_x[cp], (int)(cib & 0xffffu), cst, 1.0 / cst, 16 * g, 1 << 30, [](int, double, int, int) {});
             double x = ce.x;
-            int ibit = ce.ibit;
-            int flipped = (int)(cib >> 16) | ce.flipped;
             double p = carr_walk_track(P.cp_p[cp], d, 1.0 / __builtin_fabs(d), 16 * g, 16 * g + 1, 16 * g + 1, [](int, double) {}).p;
+            // Everything the 16 samples read from memory, fetched in one go (a load per sample and table would make this a
+            // chain of ~50 dependent memory round trips): the symbol in force and its successor (:497-506: at most one code wrap
+            // inside 16 samples), the two stream words the half chips in front of the wrap can fall into and the two behind it
+            int ib0 = ce.ibit, fl0 = (int)(cib >> 16) | ce.flipped;
+            int ib1 = ib0 + 1, fl1 = fl0;
+            if (ib1 >= GAL_N_SYM_PAGE) {
+                ib1 = 0;
+                fl1 = 1;
+            }
+            const uint32_t *pg0 = (fl0 ? P.page_next : P.page_cur) + (size_t)idx * GAL_PAGE_WORDS;
+            const uint32_t *pg1 = (fl1 ? P.page_next : P.page_cur) + (size_t)idx * GAL_PAGE_WORDS;
             const uint32_t *str = P.str + (size_t)(prn - 1) * STR_WORDS;
+            int wb = (int)(x * 2.0) >> 4;
+            wb = wb > STR_WORDS - 1 ? STR_WORDS - 1 : wb;
+            const uint32_t pw0 = pg0[ib0 >> 5], pw1 = pg1[ib1 >> 5];
+            const uint32_t wa0 = str[wb], wa1 = str[wb + 1 < STR_WORDS ? wb + 1 : wb], wh0 = str[0], wh1 = str[1];
+            // data symbol (:517) and secondary code (:518) of both symbols: 1 = the factor -1
+            const int db0 = (int)((pw0 >> (ib0 & 31)) & 1u), sb0 = (int)((P.cs25 >> (ib0 % 25)) & 1u);
+            const int db1 = (int)((pw1 >> (ib1 & 31)) & 1u), sb1 = (int)((P.cs25 >> (ib1 % 25)) & 1u);
+            bool wrapped = false;
             for (int u = 0; u < cnt; ++u) {
                 if (x >= 4092.0) {  // :491-507
                     x -= 4092.0;
-                    ibit++;
-                    if (ibit >= GAL_N_SYM_PAGE) {
-                        ibit = 0;
-                        flipped = 1;
-                    }
+                    wrapped = true;
                 }
                 const int k = ((int)(511.0 * p)) & 511;  // :509-510
                 const int icode = (int)(x * 2.0);        // :512
                 // stream field of half chip h: bit 0 = E1B ^ E1C chip, bit 1 = E1C chip ^ (h & 1); a chip bit 1 is the
                 // value -1, and the BOC(1,1) sub-carrier makes the even half chip -chip, the odd one +chip
                 // (src/gal-sig.cpp:9-233)
-                const uint32_t fld = (str[icode >> 4] >> (2 * (icode & 15))) & 3u;
+                const int wi = icode >> 4;
+                const uint32_t w = wrapped ? (wi == 0 ? wh0 : wh1) : (wi == wb ? wa0 : wa1);
+                const uint32_t fld = (w >> (2 * (icode & 15))) & 3u;
                 const uint32_t cbit = (fld >> 1) ^ ((uint32_t)icode & 1u), bbit = (fld & 1u) ^ cbit;
                 const int sub = (icode & 1) ? 1 : -1;
                 const int E1B_chip = sub * (bbit ? -1 : 1), E1C_chip = sub * (cbit ? -1 : 1);
-                const uint32_t *pg = (flipped ? P.page_next : P.page_cur) + (size_t)idx * GAL_PAGE_WORDS;
-                const int databit = ((pg[ibit >> 5] >> (ibit & 31)) & 1u) ? -1 : 1;   // :517
-                const int secCode = ((P.cs25 >> (ibit % 25)) & 1u) ? -1 : 1;          // :518
-                const int v = E1B_chip * databit - E1C_chip * secCode;               // :520-521, in {-2, 0, 2}
-                const int ent2 = P.lut[k];  // int16 pair (2 cos, 2 sin)
+                const int databit = (wrapped ? db1 : db0) ? -1 : 1;   // :517
+                const int secCode = (wrapped ? sb1 : sb0) ? -1 : 1;   // :518
+                const int v = E1B_chip * databit - E1C_chip * secCode;  // :520-521, in {-2, 0, 2}
+                const int ent2 = s_lut[k];  // int16 pair (2 cos, 2 sin)
                 aI[u] += (v / 2) * (int)(short)(ent2 & 0xffff);
                 aQ[u] += (v / 2) * (int)(short)((uint32_t)ent2 >> 16);
                 x = x + cst;           // :528
@@ -581,7 +623,7 @@ __global__ void k_repair_g(DevPlan P, SynGeom G, uint32_t *__restrict__ iq, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool ACC>
+template <bool ACC, int MODE>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
@@ -590,7 +632,7 @@ static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const 
 #else
     const dim3 grid(ne * G.blocks_per_epoch), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
 #endif
-#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
     switch (nch) {
         GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
         GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
@@ -619,13 +661,20 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
 {
     if (P->R != SG_CHUNK) return -2;
     const SynGeom G = sg_geom(P, e0);
-    return accumulate ? launch_synth_g_t<true>(P, Pd, nch, act, nact, iq, e0, ne, st, G)
-                      : launch_synth_g_t<false>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+#define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
+                                                  : launch_synth_g_t<false, m>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+    switch (P->rw) {
+        SG_MODE_CASE(1) SG_MODE_CASE(2) SG_MODE_CASE(3)
+    default: return -3;
+    }
+#undef SG_MODE_CASE
 }
 
 // behind the last synthesis launch of the batch, same stream
 extern "C" void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hipStream_t st)
 {
     const SynGeom G = sg_geom(P, e0);
-    hipLaunchKernelGGL(k_repair_g, dim3(128), dim3(256), 0, st, *P, G, iq, P->gflist, P->gflist_cap);
+    // (512 blocks x 16 rows: a batch of the reference geometry lists ~2000 groups, one of BASELINE config 4's ~16 000 per 600 epochs;
+    // blocks without a group leave at once)
+    hipLaunchKernelGGL(k_repair_g, dim3(512), dim3(256), 0, st, *P, G, iq, P->gflist, P->gflist_cap);
 }

@@ -60,6 +60,24 @@ def test_group_kernel_gates(pkg):
     assert stats["kernel_family"] == 0
 
 
+@pytest.mark.parametrize("rate,want", [(25e6, 2), (16e6, 2), (40e6, 2), (8e6, 3), (12.5e6, 3)])
+def test_group_kernel_advance_forms_at_high_sample_rates(pkg, rate, want):
+    """The forms of the resampled window for code steps <= 2/15 (<= 2 advances per group: 15.4 MS/s and above, BASELINE config 4's
+    25 MS/s) and <= 4/15 (<= 4 advances: 7.7 .. 15.4 MS/s): 24 channels in two launches, page flips, a code wrap inside a chunk."""
+    n = 60000
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=24, n_slots=24, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e5))
+    p["ibit0"][0, :4] = [499, 498, 0, 250]
+    p["code_phase0"][0, :3] = [4091.9, 4090.0, 4085.0]   # wraps within the first few hundred samples
+    p["carr_phase0"][0, 5:8] = 0.0                          # listed groups for certain
+    _, _, stats = _compare(pkg, p, n, rate=rate)
+    if stats["kernel_family"] == 1:                         # (a rate whose pattern thresholds crowd stays on the exact-replay kernel)
+        assert stats["window_mode"] == want and stats["chunk_samples"] == 1024 and stats["repaired_groups"] >= 1
+    else:
+        assert rate not in (25e6, 8e6), stats               # these two qualify
+    _, _, stats = _compare(pkg, p, n, rate=rate, flags=EXACT)
+    assert stats["kernel_family"] == 0
+
+
 def test_group_kernel_doppler_sign_change_between_epochs(pkg):
     """After a sign change the mirrored phase runs NEGATIVE until it crosses zero: the lower half of the DDA table, whose
     entries follow (int)'s truncation towards zero (:509)."""
