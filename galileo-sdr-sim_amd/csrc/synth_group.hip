@@ -567,6 +567,14 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
             // chain of ~50 dependent memory round trips): the symbol in force and its successor (:497-506: at most one code wrap
             // inside 16 samples), the two stream words the half chips in front of the wrap can fall into and the two behind it
             int ib0 = ce.ibit, fl0 = (int)(cib >> 16) | ce.flipped;
+            if (x >= 4092.0) {  // a wrap pending at the group's first sample (:491) is taken here: it may land anywhere in the
+                x -= 4092.0;    // period (an epoch may start with code_phase0 up to 6138), a wrap by stepping lands at its start
+                ib0 += 1;
+                if (ib0 >= GAL_N_SYM_PAGE) {
+                    ib0 = 0;
+                    fl0 = 1;
+                }
+            }
             int ib1 = ib0 + 1, fl1 = fl0;
             if (ib1 >= GAL_N_SYM_PAGE) {
                 ib1 = 0;

@@ -129,6 +129,21 @@ def test_group_kernel_page_flip_code_wraps_and_state_carry(pkg):
     _compare(pkg, q, 260000, state_in=st)
 
 
+def test_group_kernel_listed_group_with_a_pending_wrap_that_lands_mid_period(pkg):
+    """An epoch may start with a code phase up to 1.5 periods (include/galsynth.h): the wrap its first sample takes (:491) lands in
+    the middle of the period, not at its start -- in k_synth_g's loader and in k_repair_g, which is made to replay exactly that
+    group (a carrier phase of 0 sits on an index boundary: the first groups are listed)."""
+    for rate, n in ((2.6e6, 5000), (25e6, 3000), (8e6, 3000)):
+        p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=8, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e4))
+        p["code_phase0"][:, 0] = [6137.9, 4092.0, 5000.25]
+        p["code_phase0"][:, 1] = [4093.5, 6000.0, 4092.0 + 1e-9]
+        p["ibit0"][:, 0] = [499, 10, 498]
+        p["flags"][1:, :6] = 1  # every epoch starts a fresh carrier at phase 0: its first group is listed
+        p["carr_phase0"][:, :6] = 0.0
+        _, _, stats = _compare(pkg, p, n, rate=rate)
+        assert stats["kernel_family"] == 1 and stats["repaired_groups"] >= 3, (rate, stats)
+
+
 def test_group_kernel_code_wrap_at_every_group_position(pkg):
     """The code wrap placed at each of the 16 samples of a group and on either side of a group boundary, with the symbol's sign
     changing across it: the window's splice of the two symbols' signs."""
