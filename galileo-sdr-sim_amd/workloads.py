@@ -8,6 +8,10 @@ distributions the survey specifies, generated on the host with a fixed seed.
   M-SYN24: 24 channels, 2.5 M samples/epoch (25 MS/s).
   M-DYN:   M-SYN12 with Doppler from a 10 Hz circular-motion track (r = 100 m, v = 10 m/s).
 
+Generator: numpy's PCG64 (`np.random.default_rng(seed)`), seed 20241008 -- SURVEY.md 8(d) names std::mt19937_64 with the same
+seed: the DISTRIBUTIONS are the survey's, the stream is not (a C++ generator has no place in this Python module, and the
+checksums the bench reports since round 1 are PCG64's).
+
 The code phase of epoch e+1 continues from epoch e the way the reference's geometry would make it
 (code_phase0 advances by samples*f_code*delt modulo 4092, symbol counter accordingly), so page flips
 and symbol wraps land mid-epoch exactly as in a real scenario.
