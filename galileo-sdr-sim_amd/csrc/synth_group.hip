@@ -40,14 +40,11 @@ using namespace galnco;
 using namespace galdev;
 
 #ifndef SG_THREADS
-#define SG_THREADS 1024  // largest block: 16 waves share one epoch's tables (58 KB of LDS).  The launch picks 512 (two blocks per CU)
-                         // or 1024 (one): four waves per SIMD either way
+#define SG_THREADS 1024  // largest block the kernel is compiled for (its waves' records are sized for 16); the launch takes 512
+                         // threads: 8 waves share one epoch's tables (61 KB of LDS), two blocks per CU, four waves per SIMD
 #endif
 #ifndef SG_WAVES_PER_EU
 #define SG_WAVES_PER_EU 4
-#endif
-#ifndef SG_AHEAD
-#define SG_AHEAD 1      // samples by which the carrier-table reads run ahead of their multiply-adds (1 or 2)
 #endif
 #define SG_CHUNK 1024   // samples per wave iteration: 64 lanes x 16
 #define SG_SYMS 64      // symbol sign pairs per channel and epoch (host gate: an epoch spans fewer symbols)
@@ -72,13 +69,6 @@ typedef uint32_t sg_u4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) sg_u4 *sg_lds_u4;
 typedef const __attribute__((address_space(3))) int *sg_lds_int;
 typedef const __attribute__((address_space(3))) uint32_t *sg_lds_u32;
-
-__device__ __forceinline__ uint32_t sg_min3(const uint32_t a, const uint32_t b, const uint32_t c)
-{
-    uint32_t d;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 
 // all 16 fields = field d of w (a two's-complement 2-bit value 00 / 01 / 11)
 __device__ __forceinline__ uint32_t sg_rep(const uint32_t w, const int d)
@@ -174,10 +164,11 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         }
     }
     // ---- the 16 samples: chip value from field u of X, table address from the high word of t.  The table reads are issued
-    // SG_AHEAD samples ahead of the multiply-adds that consume them and waited for with explicit counts: written as volatile
-    // asm, because the compiler's own schedule issues two reads, waits, uses them, issues two more -- two exposed LDS latencies
-    // per sample.  (Its own wait counts stay valid: more reads in flight than it knows of only make them conservative.  No
-    // scalar-memory load is in flight here, so the LDS reads return in order.)
+    // one sample ahead of the multiply-adds that consume them and waited for with explicit counts: written as volatile asm,
+    // because the compiler's own schedule issues two reads, waits, uses them, issues two more -- two exposed LDS latencies per
+    // sample.  (Its own wait counts stay valid: more reads in flight than it knows of only make them conservative.  No scalar-
+    // memory or FLAT load is in flight here, so the counter counts LDS reads, which return in order.  Two samples ahead: 0.6 %,
+    // inside the noise.)
     __builtin_amdgcn_sched_barrier(0);
     int e[16][CNT];
     uint32_t lw[16][CNT];
@@ -188,26 +179,25 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         lw[u][q] = (uint32_t)d2u(t[q]);                                                                                   \
         t[q] = t[q] + c511[q];                                                                                            \
     }
-#pragma unroll
-    for (int u = 0; u < SG_AHEAD; ++u) { SG_ISSUE(u) }
+// the reads of sample u have landed once no more than the CNT issued behind them are outstanding (none behind the last sample's);
+// the operands tie the multiply-adds and the running minimum of the fraction words to the wait
+#define SG_WAIT(TXT, u)                                                                                                               \
+    if constexpr (CNT == 1) asm volatile(TXT : "+v"(e[u][0]), "+v"(amb) :: "memory");                                                 \
+    if constexpr (CNT == 2) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory");                                  \
+    if constexpr (CNT == 3) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory");                   \
+    if constexpr (CNT == 4) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory");
+    SG_ISSUE(0)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        if (u + SG_AHEAD < 16) { SG_ISSUE(u + SG_AHEAD) }
-        // reads of sample u have landed once no more than the ones issued behind them are outstanding
-        constexpr int kAhead = SG_AHEAD;
-        const int behind = (16 - 1 - u < kAhead ? 16 - 1 - u : kAhead) * CNT;
-        if constexpr (CNT == 1) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(amb) :: "memory");
-                                  else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(e[u][0]), "+v"(amb) :: "memory");
-                                  else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[u][0]), "+v"(amb) :: "memory"); }
-        if constexpr (CNT == 2) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory");
-                                  else if (behind == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory");
-                                  else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory"); }
-        if constexpr (CNT == 3) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory");
-                                  else if (behind == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory");
-                                  else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory"); }
-        if constexpr (CNT == 4) { if (behind == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory");
-                                  else if (behind == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory");
-                                  else asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory"); }
+        if (u < 15) {
+            SG_ISSUE(u + 1)
+            if constexpr (CNT == 1) { SG_WAIT("s_waitcnt lgkmcnt(1)", u) }
+            if constexpr (CNT == 2) { SG_WAIT("s_waitcnt lgkmcnt(2)", u) }
+            if constexpr (CNT == 3) { SG_WAIT("s_waitcnt lgkmcnt(3)", u) }
+            if constexpr (CNT == 4) { SG_WAIT("s_waitcnt lgkmcnt(4)", u) }
+        } else {
+            SG_WAIT("s_waitcnt lgkmcnt(0)", u)
+        }
         int acc = o[u];
 #pragma unroll
         for (int q = 0; q < CNT; ++q) gal_acc(acc, e[u][q], __builtin_amdgcn_sbfe((int)X[q], (uint32_t)(2 * u), 2));
@@ -215,6 +205,7 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         for (int q = 0; q < CNT; ++q) amb = amb < lw[u][q] ? amb : lw[u][q];
         o[u] = acc;
     }
+#undef SG_WAIT
 #undef SG_ISSUE
     __builtin_amdgcn_sched_barrier(0);
 }

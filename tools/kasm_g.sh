@@ -2,7 +2,7 @@
 # kasm_g.sh [mangled-name-fragment] : disassemble csrc/synth_group.hip for gfx950 and cut one kernel out into /tmp/kasm_g.s;
 # prints its register / spill counts and instruction mix
 cd "$(dirname "$0")/../galileo-sdr-sim_amd" || exit 1
-frag=${1:-k_synth_gILi12ELb0E}
+frag=${1:-k_synth_gILi12ELb0ELi1E}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value $KASM_FLAGS -S --cuda-device-only -o /tmp/sg.s csrc/synth_group.hip || exit 1
 a=$(grep -n "^_Z9${frag}" /tmp/sg.s | head -1 | cut -d: -f1)
 b=$(grep -n "amdhsa_kernel _Z9${frag}" /tmp/sg.s | cut -d: -f1)
