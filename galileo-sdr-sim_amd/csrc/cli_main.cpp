@@ -68,6 +68,7 @@ void usage(const char *prog)
            "                   the loopback interface; a port given here is bound on all interfaces, as the reference's)\n"
            "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
            "  -C               CBOC(6,1,1/11) sub-carrier of the E1 OS ICD instead of the reference's BOC(1,1) (opt-in)\n"
+           "  --exact-replay   Synthesise with the exact-replay kernel only (every sample of both NCO recurrences stepped; the same bytes, slower)\n"
            "  --strict         Stop with an error where a satellite in view runs out of ephemeris (default: its channel\n"
            "                   keeps the last valid record; the reference indexes out of bounds there)\n"
            "  --sites <file>   One line lat,lon,hgt[,outfile] per receiver site: one process per site over the GPUs of the\n"
@@ -401,13 +402,14 @@ int main(int argc, char *argv[])
     sc.duration_s = 300.0;
     sc.iono_enable = 1;
     sc.n_slots = GAL_MAX_CHAN;
-    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false;
+    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false, exact_replay = false;
     int batch_epochs = 128, n_writers = -1, sites_gpus = 0, sites_per_gpu = 1;
     sc.udp_port = GAL_SCEN_UDP_PORT;  // the reference always listens for position updates (src/galileo-sdr.cpp:185)
     sc.udp_loopback = 1;              // ... on every interface; the default listener here takes local datagrams only
 
-    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU };
+    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU, OPT_EXACT };
     static const struct option long_opts[] = {{"strict", no_argument, nullptr, OPT_STRICT},
+                                              {"exact-replay", no_argument, nullptr, OPT_EXACT},
                                               {"sites", required_argument, nullptr, OPT_SITES},
                                               {"writers", required_argument, nullptr, OPT_WRITERS},
                                               {"gpus", required_argument, nullptr, OPT_GPUS},
@@ -418,7 +420,7 @@ int main(int argc, char *argv[])
     while ((opt = getopt_long(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC", long_opts, nullptr)) != -1) {
         if (opt != 'l' && opt != 'o' && opt != 'P' && opt != OPT_SITES && opt != OPT_GPUS && opt != OPT_PER_GPU && opt != '?' && opt != ':') {
             if (opt >= 1000) {
-                child_args.push_back(opt == OPT_STRICT ? "--strict" : "--writers");
+                child_args.push_back(opt == OPT_STRICT ? "--strict" : opt == OPT_EXACT ? "--exact-replay" : "--writers");
             } else {
                 char name[3] = {'-', (char)opt, 0};
                 child_args.push_back(name);
@@ -463,6 +465,7 @@ int main(int argc, char *argv[])
         case 'r': realtime = true; break;
         case 'C': cboc = true; break;
         case OPT_STRICT: sc.strict_eph = 1; break;
+        case OPT_EXACT: exact_replay = true; break;
         case OPT_SITES: snprintf(sitesfile, sizeof(sitesfile), "%s", optarg); break;
         case OPT_WRITERS: n_writers = atoi(optarg); break;
         case OPT_GPUS: sites_gpus = atoi(optarg); break;
@@ -525,6 +528,7 @@ int main(int argc, char *argv[])
     cfg.n_slots = sc.n_slots;
     cfg.device = getenv("GAL_DEVICE") ? atoi(getenv("GAL_DEVICE")) : -1;
     if (cboc) cfg.flags |= GAL_CFG_CBOC;
+    if (exact_replay) cfg.flags |= GAL_CFG_EXACT_REPLAY;
     const size_t epoch_bytes = (size_t)cfg.samples_per_epoch * 4;
 
     if (n_writers < 0) {

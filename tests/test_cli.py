@@ -245,3 +245,13 @@ def test_cli_120s_file_equals_library(pkg, tmp_path):
         iq, _, stats = eng.run_host(rows)
     assert stats["chain_mismatch"] == 0 and stats["kernel_family"] == 1
     assert h.hexdigest() == hashlib.md5(iq.tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+def test_cli_exact_replay_flag_gives_the_same_bytes(tmp_path):
+    """--exact-replay (GAL_CFG_EXACT_REPLAY): the exact-replay kernel instead of the default one of this geometry; G1's md5 either way."""
+    out = tmp_path / "g1x.ishort"
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "10", "-I", "1", "-P", "0", "--exact-replay",
+                        "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert hashlib.md5(out.read_bytes()).hexdigest() == REF["G1"]["md5"]
