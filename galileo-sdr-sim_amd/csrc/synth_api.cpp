@@ -352,7 +352,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
     {
         const double ratio = 2.0 * 1.023e6 / cfg->sample_rate;
-        if (!(cfg->flags & (GAL_CFG_CBOC | GAL_CFG_EXACT_REPLAY)) && ((ratio >= 0.70 && ratio <= 1.02) || ratio <= 0.28) &&
+        if (!(cfg->flags & GAL_CFG_EXACT_REPLAY) && ((ratio >= 0.70 && ratio <= 1.02) || (ratio <= 0.28 && !(cfg->flags & GAL_CFG_CBOC))) &&
             cfg->chunk_samples <= 0)
             galk_warm_g(nullptr);
     }
@@ -492,11 +492,12 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
                     h->rw_e0[s] = rw_threshold_edge(cs2);
+                    if (cboc) h->rw_e0[s] = mode == 1 ? std::min(h->rw_e0[s], rw_threshold_edge(6.0 * cs2)) : 0.0;
                     // CBOC: the half-period parity pattern steps by 6 s per sample; only the hold form (1) exists there
                     if (cboc) h->rw_g0[s] = mode == 1 ? std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2)) : 0.0;
                 }
                 if (rw_ok) rw_ok = h->rw_g0[s] > (cboc ? kRwMinGapCboc : kRwMinGap);
-                if (rw_ok && g_ok) g_ok = h->rw_e0[s] > kRwMinGap;
+                if (rw_ok && g_ok) g_ok = h->rw_e0[s] > (cboc ? kRwMinGapCboc : kRwMinGap);
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;
@@ -518,7 +519,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     // Doppler with the phase on the 1 / 1300 lattice of 2 x 1.023 / 2.6, a synthetic input -- lists a percent of its groups, and
     // k_repair_g then costs more than the exact-replay kernel; the next 8 batches of the handle take that one)
     if (h->g_holdoff > 0) h->g_holdoff -= 1;
-    bool fam_g = !cboc && rw_ok && rw_mode >= 1 && rw_mode <= 3 && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
+    bool fam_g = rw_ok && rw_mode >= 1 && rw_mode <= (cboc ? 1 : 3) && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
                  nact_max > 0 && h->g_holdoff == 0 &&
                  (double)N * cs2_max / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
                  (double)E * (double)((N + kGroupChunk - 1) / kGroupChunk) * 64.0 < 4294967296.0;

@@ -31,6 +31,7 @@
 // on the walker stream, beside this kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "nco_walk.h"
 #include "synth_dev.h"
@@ -86,12 +87,17 @@ __device__ __forceinline__ double sg_f64(const uint32_t lo, const uint32_t hi) {
 // MODE: the form of the resampled window (k_synth's RW): 1 = the window advances every sample except at <= 4 HOLDS (code step 0.74 ..
 // 1 half chips per sample: the reference's 2.6 MS/s), 2 = it advances at <= 2 samples of the group (code step <= 0.133: 15.4 MS/s and
 // above), 3 = at <= 4 samples (<= 0.266: 7.7 .. 15.4 MS/s)
-template <int J0, int CNT, int MODE>
+// SIG: 0 = BOC(1,1) as the reference generates it; 1 = the opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC; hold form only): a second
+// pattern look-up per group -- the PARITY of the BOC(6,1) half period of every sample, k_synth's rw_phase_a6 / b6 -- two chip words
+// (the (B - C) and the (B + C) factor of every sample), 8-byte table entries (TA[k], TB[k]) and two multiply-adds per sample
+template <int J0, int CNT, int MODE, int SIG, int BINS, int BPITCH>
 __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &undec, const double g16, const SgRec *rec, const uint32_t *sya,
                                         const double *s_c511, const uint32_t *s_lutd,
-                                        const uint32_t *s_str, const uint2 *s_bin, const uint4 *s_pat)
+                                        const uint32_t *s_str, const uint2 *s_bin, const uint4 *s_pat, const uint2 *s_bin6,
+                                        const uint32_t *s_pat6, const int nact)
 {
     uint32_t X[CNT];
+    [[maybe_unused]] uint32_t XB[CNT];
     double t[CNT];
     // the DDA's step 511 |d| and the table base of the part's positions: wave-uniform and constant over the epoch, but read
     // from LDS for every group -- kept in registers for all twelve positions they would cost 36 of them
@@ -110,6 +116,9 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         uint2 be[CNT];
         uint32_t lo[CNT], hi[CNT], mask[CNT];
         double praw[CNT];
+        [[maybe_unused]] float f6[CNT];
+        [[maybe_unused]] uint2 be6[CNT];
+        [[maybe_unused]] int i12[CNT];
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const int j = J0 + q;
@@ -118,8 +127,14 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
             const double A = __builtin_fma(g16, sg_f64(r1.x, r1.y), sg_f64(r0.x, r0.y));
             ic0[q] = (int)A;  // < 8184 + 1008: the row continues behind the period's end (:491-507 is a matter of the signs)
             f[q] = (float)__builtin_amdgcn_fract(A);
-            const int bi = (int)(f[q] * (float)RW_BINS);
-            be[q] = s_bin[j * RW_BIN_PITCH + bi];
+            const int bi = (int)(f[q] * (float)BINS);
+            be[q] = s_bin[j * BPITCH + bi];
+            if constexpr (SIG == 1) {  // the BOC(6,1) half period of sample u is (int)(6 y_u) = i12 + floor(f6 + u 6 s)
+                const double y6 = 6.0 * A;
+                i12[q] = (int)y6;
+                f6[q] = (float)__builtin_amdgcn_fract(y6);
+                be6[q] = s_bin6[j * CB_BIN_PITCH + (int)(f6[q] * (float)CB_BINS)];
+            }
             const uint32_t *wp = s_str + j * SG_STR_PITCH + (ic0[q] >> 4);
             lo[q] = wp[0];
             hi[q] = wp[1];
@@ -133,9 +148,18 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         }
         // ---- phase B: threshold compare, pattern masks in flight; the carrier's DDA word meanwhile
         uint4 M[CNT];
+        [[maybe_unused]] uint32_t p6[CNT];
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const int j = J0 + q;
+            if constexpr (SIG == 1) {
+                const float thr6 = __uint_as_float(be6[q].x);
+                const uint32_t po6 = be6[q].y + (f6[q] >= thr6 ? 4u : 0u);  // be6.y = 4 x (thresholds below the bin)
+                // (pattern: parity relative to sample 0's half period, whose own parity is added here)
+                p6[q] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(s_pat6 + j * 16) + po6) ^
+                        (((uint32_t)i12[q] & 1u) ? 0xAAAAAAAAu : 0u);
+                undec |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(f6[q] - thr6) >= RW_DELTA));
+            }
             const float thr = __uint_as_float(be[q].x);
             const uint32_t po = be[q].y + (f[q] >= thr ? 16u : 0u);
             M[q] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_pat + j * 16) + po);
@@ -149,7 +173,18 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
 #pragma unroll
         for (int q = 0; q < CNT; ++q) {
             const uint32_t W = __builtin_amdgcn_alignbit(hi[q], lo[q], (uint32_t)ic0[q] << 1) ^ mask[q];
-            if constexpr (MODE == 1) {
+            if constexpr (SIG == 1) {
+                // fields (B != C, sign of C x secondary) per SAMPLE; the half chip of sample u is ic0 + u - (holds before u): its
+                // parity comes out of the hold masks.  X: the (B - C) factor of every sample as a signed 2-bit field; XB: the (B + C)
+                // factor, whose sign is bit 1 ^ 1 ^ parity(half chip) ^ parity(half period) (k_synth: rw_phase_c1_cboc / _d_cboc)
+                const uint32_t x = rw_spread(W, M[q]);
+                const uint32_t hp = (M[q].x ^ M[q].y ^ M[q].z ^ M[q].w) & 0xAAAAAAAAu;
+                const uint32_t hw = hp ^ 0x22222222u ^ (((uint32_t)ic0[q] & 1u) ? 0xAAAAAAAAu : 0u);
+                X[q] = window_signed(x);
+                const uint32_t sb = x ^ hw ^ p6[q];
+                const uint32_t lo1 = ~x & 0x55555555u;  // B == C: this term is the one that is non-zero
+                XB[q] = (J0 + q) < nact ? (lo1 | (sb & (lo1 << 1))) : 0u;  // (an idle position's all-zero row has B == C everywhere)
+            } else if constexpr (MODE == 1) {
                 X[q] = rw_spread(window_signed(W), M[q]);
             } else {  // field 0 everywhere, field 1 from the first advance on, field 2 from the second, ...
                 const uint32_t w = window_signed(W);
@@ -170,22 +205,31 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
     // memory or FLAT load is in flight here, so the counter counts LDS reads, which return in order.  Two samples ahead: 0.6 %,
     // inside the noise.)
     __builtin_amdgcn_sched_barrier(0);
-    int e[16][CNT];
+    typedef int sg_i2 __attribute__((ext_vector_type(2)));
+    typename std::conditional<SIG == 1, sg_i2, int>::type e[16][CNT];
     uint32_t lw[16][CNT];
 #define SG_ISSUE(u)                                                                                                       \
     _Pragma("unroll") for (int q = 0; q < CNT; ++q) {                                                                     \
-        asm volatile("v_lshl_add_u32 %0, %1, 2, %2\n\tds_read_b32 %0, %0"                                                 \
-                     : "=&v"(e[u][q]) : "v"((uint32_t)(d2u(t[q]) >> 32)), "v"(lutd[q]) : "memory");                       \
+        if constexpr (SIG == 1) {                                                                                         \
+            uint32_t a_;                                                                                                  \
+            asm volatile("v_lshl_add_u32 %1, %2, 3, %3\n\tds_read_b64 %0, %1"                                             \
+                         : "=&v"(e[u][q]), "=&v"(a_) : "v"((uint32_t)(d2u(t[q]) >> 32)), "v"(lutd[q]) : "memory");        \
+        } else {                                                                                                          \
+            asm volatile("v_lshl_add_u32 %0, %1, 2, %2\n\tds_read_b32 %0, %0"                                             \
+                         : "=&v"(e[u][q]) : "v"((uint32_t)(d2u(t[q]) >> 32)), "v"(lutd[q]) : "memory");                   \
+        }                                                                                                                 \
         lw[u][q] = (uint32_t)d2u(t[q]);                                                                                   \
         t[q] = t[q] + c511[q];                                                                                            \
     }
 // the reads of sample u have landed once no more than the CNT issued behind them are outstanding (none behind the last sample's);
-// the operands tie the multiply-adds and the running minimum of the fraction words to the wait
+// the operands tie the multiply-adds of this sample (e), the running minimum of the fraction words (amb) and the multiply-adds of
+// the PREVIOUS sample (its finished accumulator) to the wait: without the last the compiler may sink a sample's multiply-adds
+// below later reads and park the loaded entries in scratch meanwhile (the CBOC form did: 290 spills)
 #define SG_WAIT(TXT, u)                                                                                                               \
-    if constexpr (CNT == 1) asm volatile(TXT : "+v"(e[u][0]), "+v"(amb) :: "memory");                                                 \
-    if constexpr (CNT == 2) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb) :: "memory");                                  \
-    if constexpr (CNT == 3) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb) :: "memory");                   \
-    if constexpr (CNT == 4) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb) :: "memory");
+    if constexpr (CNT == 1) asm volatile(TXT : "+v"(e[u][0]), "+v"(amb), "+v"(o[(u) ? (u) - 1 : 0]) :: "memory");                     \
+    if constexpr (CNT == 2) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(amb), "+v"(o[(u) ? (u) - 1 : 0]) :: "memory");      \
+    if constexpr (CNT == 3) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(amb), "+v"(o[(u) ? (u) - 1 : 0]) :: "memory"); \
+    if constexpr (CNT == 4) asm volatile(TXT : "+v"(e[u][0]), "+v"(e[u][1]), "+v"(e[u][2]), "+v"(e[u][3]), "+v"(amb), "+v"(o[(u) ? (u) - 1 : 0]) :: "memory");
     SG_ISSUE(0)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -200,7 +244,14 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
         }
         int acc = o[u];
 #pragma unroll
-        for (int q = 0; q < CNT; ++q) gal_acc(acc, e[u][q], __builtin_amdgcn_sbfe((int)X[q], (uint32_t)(2 * u), 2));
+        for (int q = 0; q < CNT; ++q) {
+            if constexpr (SIG == 1) {  // exactly one of the two factors is non-zero
+                gal_acc(acc, e[u][q].x, __builtin_amdgcn_sbfe((int)X[q], (uint32_t)(2 * u), 2));
+                gal_acc(acc, e[u][q].y, __builtin_amdgcn_sbfe((int)XB[q], (uint32_t)(2 * u), 2));
+            } else {
+                gal_acc(acc, e[u][q], __builtin_amdgcn_sbfe((int)X[q], (uint32_t)(2 * u), 2));
+            }
+        }
 #pragma unroll
         for (int q = 0; q < CNT; ++q) amb = amb < lw[u][q] ? amb : lw[u][q];
         o[u] = acc;
@@ -211,18 +262,24 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
 }
 
 // ACC: add onto samples already in `iq` (second and later channel groups when more than 12 channels are active)
-template <int NCH, bool ACC, int MODE>
+template <int NCH, bool ACC, int MODE, int SIG = 0>
 __global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(SG_WAVES_PER_EU)))
 void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restrict__ act_all, const int *__restrict__ nact_all,
                uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
 {
     static_assert(NCH >= 1 && NCH <= SG_MAXCH, "1..12 channel positions per launch");
+    static_assert(SIG == 0 || MODE == 1, "CBOC: hold form of the resampled window only");
+    // CBOC keeps two bin tables per channel (chip holds, half-period parity) of 64 bins each, as in k_synth
+    constexpr int BINS = SIG ? CB_BINS : RW_BINS, BPITCH = SIG ? CB_BIN_PITCH : RW_BIN_PITCH;
     __shared__ uint32_t s_str[NCH * SG_STR_PITCH];
     __shared__ uint32_t s_mtab[16 * SG_MPOS];  // [sign pair of the first symbol * 4 + of its successor][position of the wrap]
-    __shared__ int s_lut[2 * SG_LUT_N];
-    __shared__ uint2 s_bin[NCH * RW_BIN_PITCH];
+    __shared__ __attribute__((aligned(8))) int s_lut[2 * SG_LUT_N * (SIG ? 2 : 1)];  // CBOC: 8-byte entries (TA[k], TB[k])
+    __shared__ uint2 s_bin[NCH * BPITCH];
     __shared__ uint4 s_pat[NCH * 16];
     __shared__ float s_thr[NCH * 16];
+    __shared__ uint2 s_bin6[SIG ? NCH * CB_BIN_PITCH : 1];
+    __shared__ uint32_t s_pat6[SIG ? NCH * 16 : 1];
+    __shared__ float s_thr6[SIG ? NCH * 16 : 1];
     __shared__ uint32_t s_sym[NCH * SG_SYMS];
     __shared__ __attribute__((aligned(16))) SgRec s_rec[(SG_THREADS / 64) * 2 * SG_MAXCH];  // [wave][buffer][position]
     __shared__ double s_c511[SG_MAXCH];
@@ -281,7 +338,15 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         // pos = clamp(first half chip of the window - (8184 - 16), 0, 16): the fields from 16 - pos on lie behind the wrap
         s_mtab[i] = pos == 0 ? mc : pos == 16 ? mn : (mc ^ ((mc ^ mn) & (~0u << (2 * (16 - pos)))));
     }
-    for (int i = tid; i < 2 * SG_LUT_N; i += nthr) {
+    for (int i = tid; i < 2 * SG_LUT_N * (SIG ? 2 : 1); i += nthr) {
+        if constexpr (SIG == 1) {  // int i = (table (plain / conjugate) x SG_LUT_N + entry) x 2 + (0: TA, 1: TB); Pd->lut = [TA 512][TB 512]
+            const int ie = i >> 1, tab = ie >= SG_LUT_N, ii = ie - tab * SG_LUT_N;
+            int k = ii < 512 ? ii - 511 : ii - 512;
+            k = k >= 511 ? k - 511 : k;
+            k = k >= 511 ? k - 511 : k;
+            s_lut[i] = p_lut[((i & 1) << 9) + ((tab ? -k : k) & 511)];
+            continue;
+        }
         // table (plain / conjugate) x SG_LUT_N + entry i = floor(511 p + 512): i >= 512: LUT[(i - 512) mod 511] (the phase wraps
         // at 1, so 511 p wraps at 511); i < 512 (mirrored phase still negative after a Doppler sign change): (int) truncates
         // towards zero (:509), so entry i holds k = i - 511
@@ -325,7 +390,8 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         for (int q = 0; q < NCH; ++q) ix = tid == q ? ixs[q] : ix;
         const double d = (tid < NCH && tid < nact) ? p_dstep[ix] : 0.0;
         s_c511[tid] = 511.0 * __builtin_fabs(d);
-        s_lutd[tid] = (uint32_t)(uintptr_t)(sg_lds_int)s_lut + (((uint32_t)(d2u(d) >> 32) >> 31) ? SG_LUT_N * 4u : 0u) - (0x41300000u << 2);
+        s_lutd[tid] = SIG ? (uint32_t)(uintptr_t)(sg_lds_int)s_lut + (((uint32_t)(d2u(d) >> 32) >> 31) ? SG_LUT_N * 8u : 0u) - (0x41300000u << 3)
+                          : (uint32_t)(uintptr_t)(sg_lds_int)s_lut + (((uint32_t)(d2u(d) >> 32) >> 31) ? SG_LUT_N * 4u : 0u) - (0x41300000u << 2);
     }
     // ---- hold patterns (k_synth<.., RW = 1>, rw_phase_a): step A, the 15 thresholds T_u = 1 - frac(u s) of each channel, sorted
     for (int t = tid; t < NCH * 16; t += nthr) {
@@ -344,31 +410,68 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         } else {
             s_thr[j * 16 + 15] = 2.0f;
         }
+        if constexpr (SIG == 1) {  // the same ranking for the BOC(6,1) half periods: step 6 s per sample
+            const double s6 = 6.0 * s;
+            if (u <= 15) {
+                const double us = (double)u * s6;
+                const double T = 1.0 - (us - __builtin_floor(us));
+                int rank = 0;
+                for (int v = 1; v <= 15; ++v) {
+                    const double vs = (double)v * s6;
+                    const double Tv = 1.0 - (vs - __builtin_floor(vs));
+                    rank += (Tv < T) || (Tv == T && v < u);
+                }
+                s_thr6[j * 16 + rank] = (float)T;
+            } else {
+                s_thr6[j * 16 + 15] = 2.0f;
+            }
+        }
     }
     __syncthreads();
-    // ---- step B: the bin tables (NCH x 129 entries) and the 16 patterns of each channel
-    for (int t = tid; t < NCH * (RW_BINS + 1); t += nthr) {
-        const int j = t / (RW_BINS + 1), b = t - j * (RW_BINS + 1);
-        const float lo = (float)b * (1.0f / RW_BINS) - RW_EDGE, hi = (float)(b + 1) * (1.0f / RW_BINS) + RW_EDGE;
-        // the thresholds are sorted (entry 15: the sentinel 2.0): the number below the bin by bisection, then the (at most two
-        // that matter) inside it
-        const float *th = s_thr + j * 16;
-        int idb = th[7] < lo ? 8 : 0;
-        idb += th[idb + 3] < lo ? 4 : 0;
-        idb += th[idb + 1] < lo ? 2 : 0;
-        idb += th[idb] < lo ? 1 : 0;
-        const float t0 = th[idb], t1 = idb < 15 ? th[idb + 1] : 2.0f;
-        int cnt = (t0 < hi) + (t1 < hi);
-        float thr = t0 < hi ? t0 : 4.0f;  // 4: "no threshold near this bin" -- never reached, never close
-        // 0 and 1 are thresholds too -- of sample 0's own half chip, which the approximate phase decides only away from them
-        // (k_synth knows its group-start phase exactly): bin 0 compares with 0 (never below it: the pattern offset makes up
-        // for the unconditional "f >= threshold"), the last bin with 1; a pattern threshold beside them leaves the bin undecidable
-        uint32_t off = (uint32_t)idb * 16u;
-        if (b == 0) { thr = cnt ? __builtin_nanf("") : 0.0f; off -= cnt ? 0u : 16u; cnt = 0; }
-        if (b == RW_BINS - 1) { thr = cnt ? __builtin_nanf("") : 1.0f; cnt = 0; }
-        if (cnt >= 2 || b == RW_BINS) thr = __builtin_nanf("");  // undecidable here
-        if (j >= nact) { thr = 4.0f; off = 0u; }
-        s_bin[j * RW_BIN_PITCH + b] = make_uint2(__float_as_uint(thr), off);
+    // ---- step B: the bin tables (NCH x (BINS + 1) entries) and the 16 patterns of each channel
+    auto build_bins = [&](uint2 *bins, const float *thrs, const int nbins, const int pitch, const uint32_t unit) {
+        for (int t = tid; t < NCH * (nbins + 1); t += nthr) {
+            const int j = t / (nbins + 1), b = t - j * (nbins + 1);
+            const float lo = (float)b * (1.0f / (float)nbins) - RW_EDGE, hi = (float)(b + 1) * (1.0f / (float)nbins) + RW_EDGE;
+            // the thresholds are sorted (entry 15: the sentinel 2.0): the number below the bin by bisection, then the (at most two
+            // that matter) inside it
+            const float *th = thrs + j * 16;
+            int idb = th[7] < lo ? 8 : 0;
+            idb += th[idb + 3] < lo ? 4 : 0;
+            idb += th[idb + 1] < lo ? 2 : 0;
+            idb += th[idb] < lo ? 1 : 0;
+            const float t0 = th[idb], t1 = idb < 15 ? th[idb + 1] : 2.0f;
+            int cnt = (t0 < hi) + (t1 < hi);
+            float thr = t0 < hi ? t0 : 4.0f;  // 4: "no threshold near this bin" -- never reached, never close
+            // 0 and 1 are thresholds too -- of sample 0's own half chip (half period), which the approximate phase decides only away
+            // from them (k_synth knows its group-start phase exactly): bin 0 compares with 0 (never below it: the pattern offset
+            // makes up for the unconditional "f >= threshold"), the last bin with 1; a pattern threshold beside them leaves the bin
+            // undecidable
+            uint32_t off = (uint32_t)idb * unit;
+            if (b == 0) { thr = cnt ? __builtin_nanf("") : 0.0f; off -= cnt ? 0u : unit; cnt = 0; }
+            if (b == nbins - 1) { thr = cnt ? __builtin_nanf("") : 1.0f; cnt = 0; }
+            if (cnt >= 2 || b == nbins) thr = __builtin_nanf("");  // undecidable here
+            if (j >= nact) { thr = 4.0f; off = 0u; }
+            bins[j * pitch + b] = make_uint2(__float_as_uint(thr), off);
+        }
+    };
+    build_bins(s_bin, s_thr, BINS, BPITCH, 16u);
+    if constexpr (SIG == 1) {
+        build_bins(s_bin6, s_thr6, CB_BINS, CB_BIN_PITCH, 4u);
+        for (int t = tid; t < NCH * 16; t += nthr) {
+            // pattern `id` (id thresholds <= f6): bit 2u+1 = parity of floor(f6 + u 6s), the number of half periods sample u lies
+            // beyond sample 0's
+            const int j = t >> 4, id = t & 15;
+            const double s6 = 6.0 * rw_step_of(j);
+            const double Tlo = id ? (double)s_thr6[j * 16 + id - 1] : 0.0;
+            double Thi = (double)s_thr6[j * 16 + id];
+            Thi = Thi > 1.0 ? 1.0 : Thi;
+            const double f = 0.5 * (Tlo + Thi);
+            uint32_t w = 0u;
+            for (int u = 1; u <= 15; ++u)
+                if ((long long)__builtin_floor(f + (double)u * s6) & 1LL) w |= 2u << (2 * u);
+            s_pat6[t] = j < nact ? w : 0u;
+        }
     }
     for (int t = tid; t < NCH * 16; t += nthr) {
         const int j = t >> 4, id = t & 15;  // id = number of thresholds <= f
@@ -485,9 +588,13 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         const SgRec *rec = recw + buf * SG_MAXCH;
         const uint32_t *sya = syaw + buf * SG_MAXCH;
         // balanced parts: 5, 6, 7, 9, 10, 11 positions are cut 3+2, 3+3, 4+3, 3+3+3, 4+3+3, 4+4+3
-#define SG_PART(J0, CNT) sg_part<J0, CNT, MODE>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat); \
+#define SG_PART(J0, CNT) sg_part<J0, CNT, MODE, SIG, BINS, BPITCH>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat, s_bin6, s_pat6, nact); \
                          __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NCH <= 4) { SG_PART(0, NCH) }
+        // (CBOC: parts of three -- a part's group start keeps 17 values per position alive, 13 in the BOC(1,1) form)
+        if constexpr (SIG == 1 && NCH == 4) { SG_PART(0, 2) SG_PART(2, 2) }
+        else if constexpr (SIG == 1 && NCH == 8) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 2) }
+        else if constexpr (SIG == 1 && NCH == 12) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 3) SG_PART(9, 3) }
+        else if constexpr (NCH <= 4) { SG_PART(0, NCH) }
         else if constexpr (NCH == 5) { SG_PART(0, 3) SG_PART(3, 2) }
         else if constexpr (NCH == 6) { SG_PART(0, 3) SG_PART(3, 3) }
         else if constexpr (NCH == 7) { SG_PART(0, 4) SG_PART(4, 3) }
@@ -522,7 +629,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
 __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t *__restrict__ iq, const uint32_t *__restrict__ flist,
                                                   const int flist_cap)
 {
-    __shared__ int s_lut[512];  // int16 pairs (2 cos, 2 sin): the one table the 16 samples gather from
+    __shared__ int s_lut[1024];  // int16 pairs (2 cos, 2 sin): the one table the 16 samples gather from; CBOC: [TA 512][TB 512]
     const int n_raw = P.ctr[CTR_GFLAGS];
     const int n = n_raw < flist_cap ? n_raw : flist_cap;
     if (n_raw > flist_cap && blockIdx.x == 0 && threadIdx.x == 0) P.ctr[CTR_GOVER] = 1;  // gal_synth_finish repeats the batch exactly
@@ -530,7 +637,7 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
     const int r = threadIdx.x & 15;
     const int nrows = (gridDim.x * blockDim.x) >> 4;
     if (((int)blockIdx.x * (int)blockDim.x >> 4) >= n) return;  // no row of this block has a group
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_lut[i] = P.lut[i];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_lut[i] = P.lut[i];  // (BOC(1,1): the second half repeats the first)
     __syncthreads();
     for (int i = gt >> 4; i < n; i += nrows) {
         const uint32_t ent = flist[i];
@@ -600,10 +707,22 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
                 const int E1B_chip = sub * (bbit ? -1 : 1), E1C_chip = sub * (cbit ? -1 : 1);
                 const int databit = (wrapped ? db1 : db0) ? -1 : 1;   // :517
                 const int secCode = (wrapped ? sb1 : sb0) ? -1 : 1;   // :518
-                const int v = E1B_chip * databit - E1C_chip * secCode;  // :520-521, in {-2, 0, 2}
-                const int ent2 = s_lut[k];  // int16 pair (2 cos, 2 sin)
-                aI[u] += (v / 2) * (int)(short)(ent2 & 0xffff);
-                aQ[u] += (v / 2) * (int)(short)((uint32_t)ent2 >> 16);
+                if (P.signal == 1) {
+                    // CBOC(6,1,1/11) (include/galsynth.h, GAL_CFG_CBOC; not in the reference): the code arrays carry sc_A = the
+                    // BOC(1,1) sub-carrier; sc_B from (int)(12 x), first half period negative; sc_A sc_B turns a value that carries
+                    // sc_A into one that carries sc_B.  Tables: 2 TA, 2 TB (int16 pairs), so the halved sums below are exact
+                    const int i12 = (int)(x * 12.0);
+                    const int ab = ((icode ^ i12) & 1) ? -1 : 1;
+                    const int Ba = E1B_chip * databit, Ca = E1C_chip * secCode;
+                    const int ta = s_lut[k], tb = s_lut[512 + k];
+                    aI[u] += ((Ba - Ca) / 2) * (int)(short)(ta & 0xffff) + ab * ((Ba + Ca) / 2) * (int)(short)(tb & 0xffff);
+                    aQ[u] += ((Ba - Ca) / 2) * (int)(short)((uint32_t)ta >> 16) + ab * ((Ba + Ca) / 2) * (int)(short)((uint32_t)tb >> 16);
+                } else {
+                    const int v = E1B_chip * databit - E1C_chip * secCode;  // :520-521, in {-2, 0, 2}
+                    const int ent2 = s_lut[k];  // int16 pair (2 cos, 2 sin)
+                    aI[u] += (v / 2) * (int)(short)(ent2 & 0xffff);
+                    aQ[u] += (v / 2) * (int)(short)((uint32_t)ent2 >> 16);
+                }
                 x = x + cst;           // :528
                 p = carr_step(p, d);   // :531-532
             }
@@ -622,7 +741,7 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool ACC, int MODE>
+template <bool ACC, int MODE, int SIG>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
@@ -631,11 +750,20 @@ static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const 
 #else
     const dim3 grid(ne * G.blocks_per_epoch), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
 #endif
-#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
-    switch (nch) {
-        GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
-        GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
-    default: return -1;
+#define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
+    if constexpr (SIG == 1) {
+        // the opt-in CBOC mode is built for 4, 8 and 12 positions only, like k_synth's (positions beyond the active count are idle)
+        if (nch < 1 || nch > 12) return -1;
+        switch ((nch + 3) / 4 * 4) {
+            GAL_CASE(4) GAL_CASE(8) GAL_CASE(12)
+        default: return -1;
+        }
+    } else {
+        switch (nch) {
+            GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
+            GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
+        default: return -1;
+        }
     }
 #undef GAL_CASE
     return 0;
@@ -660,8 +788,13 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
 {
     if (P->R != SG_CHUNK) return -2;
     const SynGeom G = sg_geom(P, e0);
-#define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
-                                                  : launch_synth_g_t<false, m>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+    if (P->signal == 1) {
+        if (P->rw != 1) return -3;
+        return accumulate ? launch_synth_g_t<true, 1, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G)
+                          : launch_synth_g_t<false, 1, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+    }
+#define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m, 0>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
+                                                  : launch_synth_g_t<false, m, 0>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
     switch (P->rw) {
         SG_MODE_CASE(1) SG_MODE_CASE(2) SG_MODE_CASE(3)
     default: return -3;

@@ -245,3 +245,29 @@ def test_group_kernel_epoch_ranges_of_one_plan(pkg):
                 assert stats["chain_mismatch"] == 0 and stats["kernel_family"] == 1
                 parts.append(out.cpu().numpy())
             assert np.array_equal(np.concatenate(parts), ref_iq), world
+
+
+@pytest.mark.parametrize("n_chan", [1, 4, 7, 12, 16])
+def test_group_kernel_cboc_mode(pkg, n_chan):
+    """The opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC; not the reference's signal: the checker's CBOC loop defines it) on k_synth_g: a
+    second pattern look-up per group (the parity of the BOC(6,1) half period), two chip words, 8-byte table entries; k_repair_g
+    replays the listed groups with the mode's formula.  Same bits as k_synth's CBOC bodies."""
+    CBOC = pkg.synth.GAL_CFG_CBOC
+    n = 52000
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=n_chan, n_slots=16, samples_per_epoch=n, seed=700 + n_chan)
+    p["ibit0"][0, 0] = 499
+    p["code_phase0"][0, 0] = 4091.9
+    p["carr_phase0"][0, : max(1, n_chan // 2)] = 0.0  # listed groups for certain
+    ref_iq, ref_st = oracle_run(p, n, 2.6e6, cboc=True)
+    outs = []
+    for flags in (CBOC, CBOC | EXACT):
+        with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0, flags=flags) as eng:
+            iq, st, stats = eng.run_host(p)
+        assert stats["chain_mismatch"] == 0 and stats["kernel_family"] == (0 if flags & EXACT else 1), stats
+        if not flags & EXACT:
+            assert stats["repaired_groups"] >= 1
+        assert np.array_equal(iq, ref_iq), (n_chan, flags, int(np.count_nonzero(iq != ref_iq)))
+        act = ref_st["prn"] > 0
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+        outs.append(iq)
+    assert np.array_equal(outs[0], outs[1])
