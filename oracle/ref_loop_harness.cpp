@@ -4,7 +4,8 @@
  * Nothing of the reference is copied into this repository.  oracle/Makefile (target _ref/libref_loop.so, only when
  * /root/reference is present) cuts, at build time and from where they lie, into git-ignored files under oracle/_ref/:
  *   ref_loop_body.inc    src/galileo-sdr.cpp:481-539     the `for (isamp ...)` statement, verbatim
- *   ref_loop_types.inc   include/structures.h:44-48,129-137,140-162   galtime_t, range_t, channel_t, verbatim
+ *   ref_loop_types.inc   include/structures.h:43-162     galtime_t, gtime_t, datetime_t, ephem_t, ionoutc_t, range_t,
+ *                                                        channel_t, verbatim (the header itself needs uhd/boost: :1-2)
  *   ref_loop_codegen.inc src/gal-sig.cpp:9-233           hex_to_binary_converter, sboc, codegen_E1B / codegen_E1C
  * and this file supplies ONLY the locals those fragments name, with the declarations galileo_task() gives them
  * (src/galileo-sdr.cpp:32,95-114,160-162), plus a generateINavMsg that installs the page the caller provides
@@ -20,19 +21,18 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <ctime>
 
 #include "constants.h" /* the reference's: tables, MAX_CHAN, CA_SEQ_LEN_E1, N_SYM_PAGE, TX_SAMPLERATE */
 
-#include "_ref/ref_loop_types.inc"   /* galtime_t, range_t, channel_t: reference text */
+#include "_ref/ref_loop_types.inc"   /* galtime_t ... channel_t: reference text       */
 #include "_ref/ref_loop_codegen.inc" /* code expansion: reference text                */
 
 #include "../include/galsynth.h" /* the record layout the tests use (ours) */
 
 namespace {
-/* What the fragment names besides chan/iq_buff: the ephemeris store and the page producer.  Only their SHAPE matters
- * to the loop (`eph = eph_vector[sv][current_eph[sv]]; generateINavMsg(grx, &chan[i], &eph, &iono);`). */
-struct ephem_t { int unused; };
-struct ionoutc_t { int unused; };
+/* What the fragment names besides chan/iq_buff: the ephemeris store and the page producer, with the reference's own
+ * ephem_t / ionoutc_t (`eph = eph_vector[sv][current_eph[sv]]; generateINavMsg(grx, &chan[i], &eph, &iono);`). */
 std::vector<ephem_t> eph_vector[GAL_NUM_PRN + 1];
 std::vector<int> current_eph;
 
