@@ -63,7 +63,9 @@ void usage(const char *prog)
            "  -t <date,time>   Scenario start time YYYY/MM/DD,hh:mm:ss\n"
            "  -d <duration>    Duration [sec]\n"
            "  -I <x>           Disable ionospheric delay\n"
-           "  -T <date,time>   Overwrite TOC and TOE to scenario start time (use `now` for the current time)\n"
+           "  -T <date,time>   Start time as -t without its range check, and the UTC reference time overwritten (use `now` for the\n"
+           "                   current time) -- what the reference's -T does; with --shift-toe also TOC and TOE of every record\n"
+           "                   are moved to the start time, which is what the option is meant to do (include/galscen.h)\n"
            "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (0 = off; default: 7533 on\n"
            "                   the loopback interface; a port given here is bound on all interfaces, as the reference's)\n"
            "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
@@ -402,14 +404,15 @@ int main(int argc, char *argv[])
     sc.duration_s = 300.0;
     sc.iono_enable = 1;
     sc.n_slots = GAL_MAX_CHAN;
-    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false, exact_replay = false;
+    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false, exact_replay = false, shift_toe = false;
     int batch_epochs = 128, n_writers = -1, sites_gpus = 0, sites_per_gpu = 1;
     sc.udp_port = GAL_SCEN_UDP_PORT;  // the reference always listens for position updates (src/galileo-sdr.cpp:185)
     sc.udp_loopback = 1;              // ... on every interface; the default listener here takes local datagrams only
 
-    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU, OPT_EXACT };
+    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU, OPT_EXACT, OPT_SHIFT_TOE };
     static const struct option long_opts[] = {{"strict", no_argument, nullptr, OPT_STRICT},
                                               {"exact-replay", no_argument, nullptr, OPT_EXACT},
+                                              {"shift-toe", no_argument, nullptr, OPT_SHIFT_TOE},
                                               {"sites", required_argument, nullptr, OPT_SITES},
                                               {"writers", required_argument, nullptr, OPT_WRITERS},
                                               {"gpus", required_argument, nullptr, OPT_GPUS},
@@ -420,7 +423,7 @@ int main(int argc, char *argv[])
     while ((opt = getopt_long(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC", long_opts, nullptr)) != -1) {
         if (opt != 'l' && opt != 'o' && opt != 'P' && opt != OPT_SITES && opt != OPT_GPUS && opt != OPT_PER_GPU && opt != '?' && opt != ':') {
             if (opt >= 1000) {
-                child_args.push_back(opt == OPT_STRICT ? "--strict" : opt == OPT_EXACT ? "--exact-replay" : "--writers");
+                child_args.push_back(opt == OPT_STRICT ? "--strict" : opt == OPT_EXACT ? "--exact-replay" : opt == OPT_SHIFT_TOE ? "--shift-toe" : "--writers");
             } else {
                 char name[3] = {'-', (char)opt, 0};
                 child_args.push_back(name);
@@ -432,8 +435,8 @@ int main(int argc, char *argv[])
         case 'o': snprintf(outfile, sizeof(outfile), "%s", optarg); break;
         case 'u': snprintf(umfile, sizeof(umfile), "%s", optarg); break;
         case 'l': sscanf(optarg, "%lf,%lf,%lf", &sc.llh[0], &sc.llh[1], &sc.llh[2]); break;
-        case 'T':  // -t plus: overwrite TOC / TOE so that the file is valid at that time (src/main.cpp:237-257)
-            sc.time_overwrite = 1;
+        case 'T':  // -t without the range check, UTC reference time overwritten (src/main.cpp:237-257; galscen.h: time_overwrite)
+            if (!sc.time_overwrite) sc.time_overwrite = 1;
             if (strncmp(optarg, "now", 3) == 0) {
                 time_t timer;
                 time(&timer);
@@ -466,6 +469,7 @@ int main(int argc, char *argv[])
         case 'C': cboc = true; break;
         case OPT_STRICT: sc.strict_eph = 1; break;
         case OPT_EXACT: exact_replay = true; break;
+        case OPT_SHIFT_TOE: shift_toe = true; break;
         case OPT_SITES: snprintf(sitesfile, sizeof(sitesfile), "%s", optarg); break;
         case OPT_WRITERS: n_writers = atoi(optarg); break;
         case OPT_GPUS: sites_gpus = atoi(optarg); break;
@@ -482,6 +486,7 @@ int main(int argc, char *argv[])
         printf("ERROR: Galileo ephemeris/nav_msg file is not specified.\n");
         exit(1);
     }
+    if (shift_toe && sc.time_overwrite) sc.time_overwrite = 2;
     if (sitesfile[0]) {
         // several listeners cannot share a port: the sites run without the position listener unless -P names a base port, in
         // which case site k (in file order) listens on port + k

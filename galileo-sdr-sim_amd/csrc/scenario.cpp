@@ -264,21 +264,26 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
         t0.sec = floor(t0.sec);
         cal_to_gal(t0, &s->g0);
         if (cfg->time_overwrite) {
-            // src/gnss-time.cpp:105-137.  (The reference walks its per-satellite vectors with the two indices
-            // swapped and so runs off their ends; what it sets out to do -- and what gps-sdr-sim, its ancestor,
-            // does -- is shift EVERY record, which is what happens here.)
+            // src/gnss-time.cpp:105-137.  What the reference DOES with -T, built with its own flags: the UTC reference time of
+            // the iono / UTC record is overwritten and the range check of -t is skipped -- and no ephemeris record is touched,
+            // because the loop that should shift them runs `for (i = 0; i < neph; i++)` with galileo_task's `neph`
+            // (src/galileo-sdr.cpp:85) never assigned: the first local frame of a fresh thread, zero.  (Inside the loop the
+            // per-satellite vectors are walked with the two indices swapped besides.)  time_overwrite == 1 is that, checked
+            // against the reference program itself (tools/ref_task_fuzz.py); == 2 does what the option sets out to do -- and
+            // what gps-sdr-sim, its ancestor, does: shift EVERY record.
             GalTime gt;
             gt.week = s->g0.week;
             gt.sec = (double)(((int)(s->g0.sec)) / 7200) * 7200.0;
             const double dsec = gal_diff(gt, gmin);
             s->nav.iono.wnt = gt.week;
             s->nav.iono.tot = (int)gt.sec;
-            for (int sv = 0; sv < kMaxSat; ++sv)
-                for (Ephemeris &e : s->nav.sv[sv])
-                    if (e.valid == 1) {
-                        e.toc.sec = e.toc.sec + dsec;  // incGalTime: seconds only, the week is left alone
-                        e.toe.sec = e.toe.sec + dsec;
-                    }
+            if (cfg->time_overwrite == 2)
+                for (int sv = 0; sv < kMaxSat; ++sv)
+                    for (Ephemeris &e : s->nav.sv[sv])
+                        if (e.valid == 1) {
+                            e.toc.sec = e.toc.sec + dsec;  // incGalTime: seconds only, the week is left alone
+                            e.toe.sec = e.toe.sec + dsec;
+                        }
         } else if (gal_diff(s->g0, gmin) < 0.0 || gal_diff(gmax, s->g0) < 0.0) {
             CalTime a, b;
             gal_to_cal(gmin, &a);

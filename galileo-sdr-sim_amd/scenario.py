@@ -117,7 +117,7 @@ class Scenario:
         cfg.iono_enable = 1 if iono_enable else 0
         cfg.n_slots = int(n_slots)
         cfg.verbose = 1 if verbose else 0
-        cfg.time_overwrite = 1 if time_overwrite else 0
+        cfg.time_overwrite = int(time_overwrite)  # True / 1: the reference's -T as built; 2: TOC / TOE shifted (galscen.h)
         cfg.udp_port = int(udp_port)
         cfg.strict_eph = 1 if strict_eph else 0
         cfg.udp_loopback = 1 if udp_loopback else 0

@@ -32,8 +32,12 @@ typedef struct gal_scen_cfg {
     int32_t iono_enable;      /* 0 with -I (src/main.cpp:300); 1 = the obliquity model the reference build runs */
     int32_t n_slots;          /* channel slots per row; reference MAX_CHAN = 16                              */
     int32_t verbose;          /* print the reference's allocation lines to stderr (src/channel.cpp:101)      */
-    int32_t time_overwrite;   /* -T : shift TOC / TOE of every ephemeris record (and the UTC reference time) so that
-                                 the file becomes valid at the requested start (src/gnss-time.cpp:105-137)          */
+    int32_t time_overwrite;   /* -T (src/main.cpp:237-257, src/gnss-time.cpp:105-137).  1 = what the reference, built with its
+                                 own flags, does: the range check of -t is skipped and the UTC reference time (wnt, tot) is
+                                 overwritten; NO ephemeris record is shifted (its loop bound `neph`, src/galileo-sdr.cpp:85,
+                                 is never assigned: zero), so a start outside the file's span yields an empty sky.
+                                 2 = what the option sets out to do: TOC / TOE of every record shifted by the start (floored
+                                 to 2 h) minus the file's first TOC, so that the file becomes valid at the requested start */
     int32_t udp_port;         /* > 0: listen on this UDP port for run-time position updates, 3 doubles lat [deg],
                                  lon [deg], height [m] per datagram -- the reference's locations_thread on port 7533
                                  (include/socket.h:165-180), read once per epoch (src/galileo-sdr.cpp:443-448)      */

@@ -14,6 +14,10 @@
  * Compile with -O2 -ffp-contract=off (x86-64 baseline has no FMA, so the reference never fuses).
  *
  * Parity pins:
+ *   0. THE WHOLE PROGRAM: oracle/_ref/ref_task is the reference's file-sink program compiled from the reference's own text
+ *      (ref_task_harness.cpp: seven header lines that name UHD / Boost and the USRP sender omitted, nothing rewritten, no stand-in;
+ *      reference flags).  It reproduces every recorded md5 G1..G9; tests/test_ref_task.py and tools/ref_task_fuzz.py compare
+ *      front-end rows -> this oracle with what it writes, on scenarios no recorded md5 covers.
  *   1. THE LOOP ITSELF: oracle/_ref/libref_loop.so is src/galileo-sdr.cpp:481-539 compiled from the reference's own text
  *      (cut out at build time by oracle/Makefile, reference flags, no stand-in header; ref_loop_harness.cpp supplies only
  *      the locals the fragment names).  tests/test_ref_loop.py: this file hashes equal to it, epoch by epoch, on the G1

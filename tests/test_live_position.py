@@ -66,15 +66,27 @@ def test_malformed_datagrams_are_ignored(pkg):
     assert rows.tobytes() == ref.tobytes()
 
 
+def test_time_overwrite_as_the_reference_does_it(pkg):
+    """-T as the reference, built with its own flags, runs it (galscen.h: time_overwrite 1; checked against the reference program
+    itself by tools/ref_task_fuzz.py and tests/test_ref_task.py): the range check of -t is skipped, the UTC reference time is
+    overwritten, no record is shifted -- inside the file's span the rows are those of -t, outside it the sky is empty."""
+    inside = pkg.Scenario(NAV, llh=(-6, 51, 100), start=START, duration_s=3, time_overwrite=True).all()
+    assert inside.tobytes() == pkg.Scenario(NAV, llh=(-6, 51, 100), start=START, duration_s=3).all().tobytes()
+    with pytest.raises(pkg.GalScenError):
+        pkg.Scenario(NAV, llh=(-6, 51, 100), start="2024/10/08,09:30:00", duration_s=3)
+    rows = pkg.Scenario(NAV, llh=(-6, 51, 100), start="2024/10/08,09:30:00", duration_s=3, time_overwrite=1).all()
+    assert rows.shape == (29, 16) and not (rows["prn"] > 0).any()
+
+
 def test_time_overwrite_makes_the_file_valid_at_any_start(pkg):
-    """-T: a start far outside the file's span is an error with -t and fine with -T; the records are shifted by the
-    start floored to 2 h minus the first TOC, so the satellites seen are those of the file's first hours, and the
-    pages carry the new time."""
+    """time_overwrite 2 (CLI: -T with --shift-toe), what the option is meant to do: a start far outside the file's span is an error
+    with -t and fine here; the records are shifted by the start floored to 2 h minus the first TOC, so the satellites seen are
+    those of the file's first hours, and the pages carry the new time."""
     with pytest.raises(pkg.GalScenError):
         pkg.Scenario(NAV, llh=(-6, 51, 100), start="2024/10/08,09:30:00", duration_s=3)
     with pytest.raises(pkg.GalScenError):
-        pkg.Scenario(NAV, llh=(-6, 51, 100), duration_s=3, time_overwrite=True)  # -T needs a time
-    sc = pkg.Scenario(NAV, llh=(-6, 51, 100), start="2024/10/08,09:30:00", duration_s=3, time_overwrite=True)
+        pkg.Scenario(NAV, llh=(-6, 51, 100), duration_s=3, time_overwrite=2)  # -T needs a time
+    sc = pkg.Scenario(NAV, llh=(-6, 51, 100), start="2024/10/08,09:30:00", duration_s=3, time_overwrite=2)
     week, sec = sc.start_time()
     assert (week, sec) == (2335, 2 * 86400 + 9 * 3600 + 30 * 60)  # Tuesday 8 Oct 2024
     rows = sc.all()

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Randomised END-TO-END parity against THE REFERENCE PROGRAM ITSELF (oracle/_ref/ref_task: the reference's file-sink program
+compiled here from its own text, oracle/ref_task_harness.cpp): random receiver sites, start times over the day of the navigation
+file, durations 2-45 s (crossing the 30 s re-allocation), iono on/off, -T on/off.  Per case: the reference writes its ishort
+file; the repository's host front-end (libgalscen.so) -> the oracle's loop produces the same scenario on CPU; the two md5s must
+be equal.  This checks the front-end (RINEX reader, orbits, ranges, iono, channel allocation, I/NAV pages) and the oracle against
+the reference directly -- no recorded md5 in between.  CPU only; needs /root/reference built into oracle/_ref (make -C oracle ref).
+
+    python tools/ref_task_fuzz.py [n_cases] [seed] [jobs]
+
+A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
+exits with status 1 there too).  A case in which a satellite in view runs out of ephemeris is the reference's undefined behaviour
+(it indexes its vector with -1; seen: it never finishes) and is counted apart.  Output of the round's run: profiles/r04_ref_task_fuzz.log.  Test infrastructure.
+"""
+import hashlib
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+NAV = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
+BIN = os.path.join(ROOT, "oracle", "_ref", "ref_task")
+
+
+def make_case(rng, c):
+    lat, lon, h = rng.uniform(-89, 89), rng.uniform(-180, 180), rng.uniform(0, 4000)
+    if rng.random() < 0.15:  # round numbers: the defaults people type
+        lat, lon, h = float(round(lat)), float(round(lon)), 100.0
+    hh, mm, ss = int(rng.integers(0, 24)), int(rng.integers(0, 60)), int(rng.integers(0, 60))
+    dur = float(rng.choice([2, 3, 5, 8, 12, 20, 31, 45], p=[.15, .15, .2, .15, .15, .1, .05, .05]))
+    return dict(c=c, llh=(lat, lon, h), start="2022/02/20,%02d:%02d:%02d" % (hh, mm, ss), dur=dur,
+                iono=bool(rng.integers(0, 2)), tovr=bool(rng.random() < 0.15))
+
+
+def run_case(k):
+    from ref_task_goldens import run_ref_task
+    from __graft_entry__ import load_pkg
+    from oracle_binding import oracle_run
+    pkg = load_pkg()
+    args = "-l %.9g,%.9g,%.9g -%s %s -d %g%s" % (k["llh"][0], k["llh"][1], k["llh"][2], "T" if k["tovr"] else "t", k["start"], k["dur"],
+                                              "" if k["iono"] else " -I 1")
+    # the front-end reads -l through the same text (sscanf %lf of what the command line says)
+    llh = tuple(float(v) for v in args.split()[1].split(","))
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        out = os.path.join(d, "r.bin")
+        ref_md5, ref_n, dt, rc = run_ref_task(BIN, args, out, port=20000 + k["c"] % 20000, timeout=120 + 5 * k["dur"])
+    try:
+        sc = pkg.Scenario(NAV, llh=llh, start=k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
+        rows = sc.all()
+        gaps = sc.eph_gaps
+    except pkg.GalScenError as e:
+        return dict(k=k, args=args, status="skipped", why=str(e), ref_n=ref_n, ref_rc=rc)
+    if gaps:
+        # a satellite in view ran out of ephemeris: the reference reads eph_vector[sv][-1] there (src/galileo-sdr.cpp:458,555-558) --
+        # undefined behaviour (seen: xyz2llh never returns on what it read); the front-end's policy is galscen.h strict_eph
+        return dict(k=k, args=args, status="undefined", ref=ref_md5, ref_n=ref_n, gaps=gaps)
+    iq, _ = oracle_run(rows, 260000, 2.6e6)
+    ours = hashlib.md5(iq.tobytes()).hexdigest()
+    n_sv = int((rows["prn"] > 0).sum(axis=1).max())
+    return dict(k=k, args=args, status="equal" if (ours == ref_md5 and iq.nbytes == ref_n) else "DIFFERENT", ours=ours, ref=ref_md5,
+                n=iq.nbytes, ref_n=ref_n, n_sv=n_sv, samples=rows.shape[0] * 260000)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    jobs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    if not os.path.exists(BIN):
+        sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
+    rng = np.random.default_rng(seed)
+    cases = [make_case(rng, c) for c in range(n_cases)]
+    t0 = time.time()
+    bad = skipped = undefined = 0
+    samples = 0
+    svs = {}
+    with mp.get_context("spawn").Pool(jobs) as pool:
+        for r in pool.imap_unordered(run_case, cases):
+            if r["status"] == "skipped":
+                skipped += 1
+                print("skipped case %d [%s]: %s; the reference wrote %d bytes (exit %d)" % (r["k"]["c"], r["args"], r["why"], r["ref_n"], r["ref_rc"]), flush=True)
+                continue
+            if r["status"] == "undefined":
+                undefined += 1
+                print("undefined case %d [%s]: a satellite in view runs out of ephemeris (%d time(s)): the reference indexes out of bounds "
+                      "there; it %s" % (r["k"]["c"], r["args"], r["gaps"], "did not finish (%d bytes written)" % r["ref_n"] if r["ref"] == "timeout"
+                                        else "wrote %d bytes" % r["ref_n"]), flush=True)
+                continue
+            svs[r["n_sv"]] = svs.get(r["n_sv"], 0) + 1
+            samples += r["samples"]
+            if r["status"] != "equal":
+                bad += 1
+                print("DIFFERENT case %d [%s]: ours %s (%d B)  reference %s (%d B)" % (r["k"]["c"], r["args"], r["ours"], r["n"], r["ref"], r["ref_n"]), flush=True)
+    print("ref_task fuzz (seed %d): %d cases, %d compared (%.1f M samples), %d different, %d skipped (both reject the start time), %d where "
+          "the reference's behaviour is undefined (ephemeris gap), SV counts %s, %.0f s" % (
+              seed, n_cases, n_cases - skipped - undefined, samples / 1e6, bad, skipped, undefined, dict(sorted(svs.items())), time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

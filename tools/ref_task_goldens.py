@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Runs the golden scenarios G1-G9 (tests/golden/reference_md5.json) through oracle/_ref/ref_task -- the reference's file-sink
+program compiled HERE from the reference's own text, no stand-in header or library (oracle/ref_task_harness.cpp) -- and prints
+each file's md5 next to the recorded one.  The recorded md5s came from builds this repository cannot reproduce (SURVEY.md
+Appendix A's stand-in headers; the judges' scratch builds); this run reproduces them admissibly.
+
+    python tools/ref_task_goldens.py [--O2] [names...]     (CPU only; needs /root/reference; ~3 min for all nine)
+
+--O2: additionally builds oracle/_ref/ref_task_O2 (the same recipe with -O2 appended) and runs G8 through it: the reference's
+answer changes with the optimisation level there, and the recorded `md5_reference_O2` is that build's.
+Output of the round's run: profiles/r04_ref_task_md5.log.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAV = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")  # the reference's rinex_files/20feb2022.rnx (a data fixture)
+REF = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_md5.json")))
+
+# the command line of every golden (reference_md5.json `args`; G1-G3: BASELINE.md section 2)
+ARGS = {
+    "G1": "-l -6,51,100 -t 2022/02/20,12:00:00 -d 10 -I 1",
+    "G2": "-l -6,51,100 -t 2022/02/20,12:00:00 -d 10",
+    "G4": REF["G4"]["args"], "G5": REF["G5"]["args"], "G6": REF["G6"]["args"], "G7": REF["G7"]["args"],
+    "G8": REF["G8"]["args"], "G9": REF["G9"]["args"],
+}
+
+
+_UNSHARE = None
+
+
+def _net_prefix():
+    """The reference binds the fixed UDP port 7533 for its live-position thread (include/socket.h:169) and gives up when it is
+    taken, so two instances cannot run side by side -- unless each gets a network namespace of its own."""
+    global _UNSHARE
+    if _UNSHARE is None:
+        try:
+            _UNSHARE = subprocess.run(["unshare", "-n", "true"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+        except OSError:
+            _UNSHARE = False
+    return ["unshare", "-n"] if _UNSHARE else []
+
+
+def run_ref_task(binary, args, out_path, port=5671, timeout=None):
+    """One run of the reference program: file sink (-U 1), no bit-stream thread (-b 1).  Returns (md5, bytes, seconds, status);
+    md5 None when the reference gave up before opening its sink, "timeout" when it did not finish within `timeout` seconds.  Instances are kept apart by network namespaces where the
+    system allows them, by a lock file otherwise."""
+    import fcntl
+    env = dict(os.environ, TERM="xterm")  # initscr() (src/galileo-sdr.cpp:432) wants a terminal type
+    cmd = _net_prefix() + [binary, "-e", NAV] + args.split() + ["-U", "1", "-b", "1", "-p", str(port), "-o", out_path]
+    t0 = time.time()
+    with open(os.path.join(tempfile.gettempdir(), "ref_task.lock"), "w") as lk:
+        if not _net_prefix():
+            fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            p = subprocess.run(cmd, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, timeout=timeout)
+        except subprocess.TimeoutExpired:  # (subprocess.run has killed the child it started)
+            return "timeout", os.path.getsize(out_path) if os.path.exists(out_path) else 0, time.time() - t0, None
+    dt = time.time() - t0
+    h = hashlib.md5()
+    n = 0
+    if not os.path.exists(out_path):  # the reference gave up before opening its sink (start outside the file's span, ...)
+        return None, 0, dt, p.returncode
+    with open(out_path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+            n += len(blk)
+    return h.hexdigest(), n, dt, p.returncode
+
+
+def main():
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or sorted(ARGS)
+    o2 = "--O2" in sys.argv[1:]
+    binary = os.path.join(ROOT, "oracle", "_ref", "ref_task")
+    if not os.path.exists(binary):
+        sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
+    bad = 0
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        for k in names:
+            md5, n, dt, rc = run_ref_task(binary, ARGS[k], os.path.join(d, k + ".bin"))
+            ok = md5 == REF[k]["md5"] and n == REF[k]["bytes"]
+            bad += not ok
+            print("%s  ref_task %s  %d B  %.1f s  exit %d   recorded %s  %s   [%s]" % (
+                k, md5, n, dt, rc, REF[k]["md5"], "EQUAL" if ok else "DIFFERENT", ARGS[k]), flush=True)
+            os.unlink(os.path.join(d, k + ".bin"))
+        if o2:
+            b2 = os.path.join(ROOT, "oracle", "_ref", "ref_task_O2")
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "REF_TASK_FLAGS=-O2", "REF_TASK_OUT=_ref/ref_task_O2"],
+                                  stdout=subprocess.DEVNULL)
+            md5, n, dt, rc = run_ref_task(b2, ARGS["G8"], os.path.join(d, "G8_O2.bin"))
+            ok = md5 == REF["G8"]["md5_reference_O2"]
+            bad += not ok
+            print("G8 (-O2 build)  ref_task_O2 %s  %d B  %.1f s  exit %d   recorded md5_reference_O2 %s  %s" % (
+                md5, n, dt, rc, REF["G8"]["md5_reference_O2"], "EQUAL" if ok else "DIFFERENT"), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
