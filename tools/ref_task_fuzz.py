@@ -6,7 +6,10 @@ file; the repository's host front-end (libgalscen.so) -> the oracle's loop produ
 be equal.  This checks the front-end (RINEX reader, orbits, ranges, iono, channel allocation, I/NAV pages) and the oracle against
 the reference directly -- no recorded md5 in between.  CPU only; needs /root/reference built into oracle/_ref (make -C oracle ref).
 
-    python tools/ref_task_fuzz.py [n_cases] [seed] [jobs]
+    python tools/ref_task_fuzz.py [n_cases] [seed] [jobs] [--cli]
+
+--cli (on the GPU box; the binary travels there with oracle/_ref/): the other side is the PRODUCT -- the galileo-sdr-sim CLI, front-end ->
+HIP -> file, on the same command line -- instead of front-end -> oracle; output of the round's run: profiles/r04_ref_task_fuzz_cli.log.
 
 A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
 exits with status 1 there too).  A case in which a satellite in view runs out of ephemeris is the reference's undefined behaviour
@@ -40,6 +43,36 @@ def make_case(rng, c):
                 iono=bool(rng.integers(0, 2)), tovr=bool(rng.random() < 0.15))
 
 
+CLI = os.path.join(ROOT, "galileo-sdr-sim_amd", "galileo-sdr-sim")
+USE_CLI = "--cli" in sys.argv[1:]
+
+
+def md5_file(path):
+    h = hashlib.md5()
+    n = 0
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+            n += len(blk)
+    return h.hexdigest(), n
+
+
+def run_case_cli(k, args, ref_md5, ref_n, rc):
+    """The product's side of a case: the CLI on the reference's command line (-P 0: no position listener)."""
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        out = os.path.join(d, "o.bin")
+        r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True)
+        if r.returncode != 0:
+            if "Invalid start time" in r.stderr:
+                return dict(k=k, args=args, status="skipped", why=r.stderr.strip().splitlines()[-1], ref_n=ref_n, ref_rc=rc)
+            return dict(k=k, args=args, status="DIFFERENT", ours="exit %d: %s" % (r.returncode, r.stderr[-200:]), ref=ref_md5, n=0, ref_n=ref_n)
+        ours, n = md5_file(out)
+    if "no ephemeris within an hour" in r.stderr:
+        return dict(k=k, args=args, status="undefined", ref=ref_md5, ref_n=ref_n, gaps=r.stderr.count("no ephemeris within an hour"))
+    return dict(k=k, args=args, status="equal" if (ours == ref_md5 and n == ref_n) else "DIFFERENT", ours=ours, ref=ref_md5, n=n, ref_n=ref_n,
+                n_sv=-1, samples=n // 4)
+
+
 def run_case(k):
     from ref_task_goldens import run_ref_task
     from __graft_entry__ import load_pkg
@@ -52,6 +85,8 @@ def run_case(k):
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         out = os.path.join(d, "r.bin")
         ref_md5, ref_n, dt, rc = run_ref_task(BIN, args, out, port=20000 + k["c"] % 20000, timeout=120 + 5 * k["dur"])
+    if USE_CLI:
+        return run_case_cli(k, args, ref_md5, ref_n, rc)
     try:
         sc = pkg.Scenario(NAV, llh=llh, start=k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
         rows = sc.all()
@@ -70,9 +105,10 @@ def run_case(k):
 
 
 def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    jobs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n_cases = int(argv[0]) if len(argv) > 0 else 40
+    seed = int(argv[1]) if len(argv) > 1 else 1
+    jobs = int(argv[2]) if len(argv) > 2 else 6
     if not os.path.exists(BIN):
         sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
     rng = np.random.default_rng(seed)
@@ -98,9 +134,9 @@ def main():
             if r["status"] != "equal":
                 bad += 1
                 print("DIFFERENT case %d [%s]: ours %s (%d B)  reference %s (%d B)" % (r["k"]["c"], r["args"], r["ours"], r["n"], r["ref"], r["ref_n"]), flush=True)
-    print("ref_task fuzz (seed %d): %d cases, %d compared (%.1f M samples), %d different, %d skipped (both reject the start time), %d where "
+    print("ref_task fuzz%s (seed %d): %d cases, %d compared (%.1f M samples), %d different, %d skipped (both reject the start time), %d where "
           "the reference's behaviour is undefined (ephemeris gap), SV counts %s, %.0f s" % (
-              seed, n_cases, n_cases - skipped - undefined, samples / 1e6, bad, skipped, undefined, dict(sorted(svs.items())), time.time() - t0))
+              " against the product CLI (front-end -> HIP -> file)" if USE_CLI else " against front-end -> oracle", seed, n_cases, n_cases - skipped - undefined, samples / 1e6, bad, skipped, undefined, dict(sorted(svs.items())), time.time() - t0))
     sys.exit(1 if bad else 0)
 
 
