@@ -69,7 +69,24 @@ def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
     dtp = time.perf_counter() - t0
     all_cores = cores * reps * n_par * n_samp / dtp / 1e6
     n_act = int((params["prn"][0] > 0).sum())
+    # the reference's OWN loop: oracle/_ref/libref_loop.so = src/galileo-sdr.cpp:481-539 compiled from the reference's text with
+    # the reference's flags (-g -DDEBUG, no -O; oracle/ref_loop_harness.cpp), where it was built (this needs /root/reference at
+    # build time; the .so travels to the GPU box).  Its per-sample get_nanos() is the harness's no-op, so this is an upper bound.
+    ref_own = None
+    try:
+        from ref_loop_binding import ref_loop_available, ref_loop_run
+        if ref_loop_available() and rate == 2.6e6 and params.shape[1] <= 16:
+            n_rl = max(2, min(params.shape[0], n_ep // 8))
+            t0 = time.perf_counter()
+            ref_loop_run(params[:n_rl], n_samp)
+            dtr = time.perf_counter() - t0
+            ref_own = {"value": round(n_rl * n_samp / dtr / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+                       "sample": "first %d epochs, %.1f s of CPU: the reference's loop text (src/galileo-sdr.cpp:481-539) compiled with "
+                                 "its own flags (-g -DDEBUG, no -O), clock read stubbed" % (n_rl, dtr)}
+    except Exception as e:  # a baseline, not the product: report and go on
+        ref_own = {"error": str(e)[:200]}
     return {
+        **({"reference_loop": ref_own} if ref_own else {}),
         "value": round(plain, 3),
         "unit": "Msamples/s",
         "cores": 1,

@@ -10,6 +10,8 @@ the reference directly -- no recorded md5 in between.  CPU only; needs /root/ref
 
 --cli (on the GPU box; the binary travels there with oracle/_ref/): the other side is the PRODUCT -- the galileo-sdr-sim CLI, front-end ->
 HIP -> file, on the same command line -- instead of front-end -> oracle; output of the round's run: profiles/r04_ref_task_fuzz_cli.log.
+--odd: the corners of the command line too -- -t or -l left out, fractional durations and seconds, the ends of the coordinate ranges,
+starts at the edges of the file's span (profiles/r04_ref_task_fuzz_odd.log).
 
 A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
 exits with status 1 there too).  A case in which a satellite in view runs out of ephemeris is the reference's undefined behaviour
@@ -33,14 +35,38 @@ NAV = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
 BIN = os.path.join(ROOT, "oracle", "_ref", "ref_task")
 
 
-def make_case(rng, c):
+def make_case(rng, c, odd=False):
     lat, lon, h = rng.uniform(-89, 89), rng.uniform(-180, 180), rng.uniform(0, 4000)
     if rng.random() < 0.15:  # round numbers: the defaults people type
         lat, lon, h = float(round(lat)), float(round(lon)), 100.0
     hh, mm, ss = int(rng.integers(0, 24)), int(rng.integers(0, 60)), int(rng.integers(0, 60))
     dur = float(rng.choice([2, 3, 5, 8, 12, 20, 31, 45], p=[.15, .15, .2, .15, .15, .1, .05, .05]))
-    return dict(c=c, llh=(lat, lon, h), start="2022/02/20,%02d:%02d:%02d" % (hh, mm, ss), dur=dur,
-                iono=bool(rng.integers(0, 2)), tovr=bool(rng.random() < 0.15))
+    k = dict(c=c, llh=(lat, lon, h), start="2022/02/20,%02d:%02d:%02d" % (hh, mm, ss), dur=dur,
+             iono=bool(rng.integers(0, 2)), tovr=bool(rng.random() < 0.15), no_t=False, no_l=False)
+    if odd:  # --odd: the corners of the command line -- options left out, fractions, the ends of the coordinate ranges
+        r = rng.random()
+        if r < 0.12:
+            k["no_t"], k["tovr"] = True, False  # start = the file's first TOC (src/gnss-time.cpp:159-165)
+        elif r < 0.24:
+            k["no_l"] = True  # the default site (src/main.cpp:187-189)
+        elif r < 0.44:
+            k["dur"] = float(round(rng.uniform(1.2, 9.0), int(rng.integers(1, 4))))  # (int)(d * 10 + 0.5) epochs (src/main.cpp:274-275)
+        elif r < 0.56:
+            k["start"] += ".%d" % rng.integers(1, 10)  # seconds are floored (src/main.cpp:269)
+        elif r < 0.70:
+            k["llh"] = (float(rng.choice([-90, 90, 0])), float(rng.choice([-180, 180, 0])), float(rng.choice([-400, 0, 9000, 2.0e7])))
+        elif r < 0.80:
+            k["start"] = "2022/02/19,%02d:%02d:%02d" % (22 + int(rng.integers(0, 2)), mm, ss)  # the file's first two hours
+        elif r < 0.90:
+            k["start"] = "2022/02/20,23:%02d:%02d" % (int(rng.integers(20, 31)), 0 if rng.random() < 0.5 else ss)  # around tmax
+            k["dur"] = float(rng.choice([2, 3, 5]))
+    return k
+
+
+def case_args(k):
+    return " ".join(([] if k["no_l"] else ["-l %.9g,%.9g,%.9g" % k["llh"]]) +
+                    ([] if k["no_t"] else ["-%s %s" % ("T" if k["tovr"] else "t", k["start"])]) +
+                    ["-d %g" % k["dur"]] + ([] if k["iono"] else ["-I 1"]))
 
 
 CLI = os.path.join(ROOT, "galileo-sdr-sim_amd", "galileo-sdr-sim")
@@ -78,17 +104,16 @@ def run_case(k):
     from __graft_entry__ import load_pkg
     from oracle_binding import oracle_run
     pkg = load_pkg()
-    args = "-l %.9g,%.9g,%.9g -%s %s -d %g%s" % (k["llh"][0], k["llh"][1], k["llh"][2], "T" if k["tovr"] else "t", k["start"], k["dur"],
-                                              "" if k["iono"] else " -I 1")
+    args = case_args(k)
     # the front-end reads -l through the same text (sscanf %lf of what the command line says)
-    llh = tuple(float(v) for v in args.split()[1].split(","))
+    llh = (42.3601, -71.0589, 2.0) if k["no_l"] else tuple(float(v) for v in args.split()[1].split(","))
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         out = os.path.join(d, "r.bin")
         ref_md5, ref_n, dt, rc = run_ref_task(BIN, args, out, port=20000 + k["c"] % 20000, timeout=120 + 5 * k["dur"])
     if USE_CLI:
         return run_case_cli(k, args, ref_md5, ref_n, rc)
     try:
-        sc = pkg.Scenario(NAV, llh=llh, start=k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
+        sc = pkg.Scenario(NAV, llh=llh, start=None if k["no_t"] else k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
         rows = sc.all()
         gaps = sc.eph_gaps
     except pkg.GalScenError as e:
@@ -112,7 +137,7 @@ def main():
     if not os.path.exists(BIN):
         sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
     rng = np.random.default_rng(seed)
-    cases = [make_case(rng, c) for c in range(n_cases)]
+    cases = [make_case(rng, c, odd="--odd" in sys.argv[1:]) for c in range(n_cases)]
     t0 = time.time()
     bad = skipped = undefined = 0
     samples = 0
