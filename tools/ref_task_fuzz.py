@@ -12,6 +12,7 @@ the reference directly -- no recorded md5 in between.  CPU only; needs /root/ref
 HIP -> file, on the same command line -- instead of front-end -> oracle; output of the round's run: profiles/r04_ref_task_fuzz_cli.log.
 --odd: the corners of the command line too -- -t or -l left out, fractional durations and seconds, the ends of the coordinate ranges,
 starts at the edges of the file's span (profiles/r04_ref_task_fuzz_odd.log).
+--toc: long cases (65-130 s) that run across a 10-minute mark of the records' TOC grid and several 30 s refreshes (r04_ref_task_fuzz_toc.log).
 
 A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
 exits with status 1 there too).  A case in which a satellite in view runs out of ephemeris is the reference's undefined behaviour
@@ -60,6 +61,11 @@ def make_case(rng, c, odd=False):
         elif r < 0.90:
             k["start"] = "2022/02/20,23:%02d:%02d" % (int(rng.integers(20, 31)), 0 if rng.random() < 0.5 else ss)  # around tmax
             k["dur"] = float(rng.choice([2, 3, 5]))
+    if "--toc" in sys.argv[1:]:  # --toc: every case runs across a 10-minute mark (the records' TOC grid: epoch_matcher moves on at a
+        # 30 s refresh behind it, src/galileo-sdr.cpp:545-562) and across two to four refreshes
+        k["start"] = "2022/02/20,%02d:%d9:%02d" % (hh, int(rng.integers(0, 6)), int(rng.integers(0, 50)))
+        k["dur"] = float(rng.choice([65, 80, 100, 130]))
+        k["tovr"] = False
     return k
 
 
