@@ -259,3 +259,12 @@ def test_cli_exact_replay_flag_gives_the_same_bytes(tmp_path):
                         "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert hashlib.md5(out.read_bytes()).hexdigest() == REF["G1"]["md5"]
+
+
+def test_cli_duration_too_short_leaves_an_empty_file(tmp_path):
+    """(int)(10 d + 0.5) < 2 epochs: the reference opens its sink and has nothing to generate (src/galileo-sdr.cpp:438; seen with
+    oracle/_ref/ref_task: an empty file); the CLI does the same before it touches the device."""
+    out = tmp_path / "e.ishort"
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "0.14", "-P", "0", "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and out.exists() and out.stat().st_size == 0, r.stderr
