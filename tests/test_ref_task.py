@@ -25,6 +25,7 @@ NAV = os.path.join(G, "20feb2022.rnx")
 REF = json.load(open(os.path.join(G, "reference_md5.json")))
 BIN = os.path.join(ROOT, "oracle", "_ref", "ref_task")
 CLI = os.path.join(ROOT, "galileo-sdr-sim_amd", "galileo-sdr-sim")
+BIN_HIP = os.path.join(ROOT, "oracle", "_ref", "ref_task_hip")
 
 needs_ref_task = pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/ref_task not built (needs /root/reference at build time)")
 
@@ -73,3 +74,20 @@ def test_cli_file_equals_the_reference_programs_file(k, tmp_path):
     a, b = np.fromfile(ref_path, dtype=np.int16), np.fromfile(out, dtype=np.int16)
     assert a.size * 2 == ref_n and a.any()
     assert np.array_equal(a, b)
+
+
+@pytest.mark.skipif(not (os.path.exists(BIN) and os.path.exists(BIN_HIP)), reason="oracle/_ref/ref_task{,_hip} not built")
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [UNSEEN[0], UNSEEN[3]], ids=["3s", "32s_across_a_refresh"])
+def test_reference_with_the_loop_patch_writes_the_reference_file(k, tmp_path):
+    """THE DROP-IN ON THE REFERENCE ITSELF.  oracle/_ref/ref_task_hip is the reference's file-sink program with its per-sample loop
+    (src/galileo-sdr.cpp:481-539) replaced by galileo-sdr-sim_amd/integration/galileo_sdr_loop_patch.inc -- INTEGRATION.md section B,
+    the text a maintainer would add: channel records out of chan[], one gal_synth_run_host() per epoch into iq_buff, carrier phase
+    and page back into chan[] -- and linked against libgalsynth.so; everything else (RINEX, orbits, channel allocation, page
+    generation, fwrite) is the reference's own code.  Its file must be the unpatched reference program's, byte for byte."""
+    ref_path, out = str(tmp_path / "r.bin"), str(tmp_path / "h.bin")
+    _, ref_n, _, _ = run_ref_task(BIN, _args(k), ref_path)
+    md5, n, _, _ = run_ref_task(BIN_HIP, _args(k), out)
+    assert n == ref_n and n > 0
+    a, b = np.fromfile(ref_path, dtype=np.int16), np.fromfile(out, dtype=np.int16)
+    assert a.any() and np.array_equal(a, b)
