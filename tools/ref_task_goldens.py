@@ -5,6 +5,10 @@ each file's md5 next to the recorded one.  The recorded md5s came from builds th
 Appendix A's stand-in headers; the judges' scratch builds); this run reproduces them admissibly.
 
     python tools/ref_task_goldens.py [--O2] [names...]     (CPU only; needs /root/reference; ~3 min for all nine)
+    python tools/ref_task_goldens.py --hip [names...]      (GPU box: oracle/_ref/ref_task_hip instead -- the reference's program with
+                                                            its per-sample loop replaced by INTEGRATION.md section B's patch and linked
+                                                            against libgalsynth.so; output of the round's run:
+                                                            profiles/r04_ref_task_hip_md5.log)
 
 --O2: additionally builds oracle/_ref/ref_task_O2 (the same recipe with -O2 appended) and runs G8 through it: the reference's
 answer changes with the optimisation level there, and the recorded `md5_reference_O2` is that build's.
@@ -76,7 +80,8 @@ def run_ref_task(binary, args, out_path, port=5671, timeout=None):
 def main():
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or sorted(ARGS)
     o2 = "--O2" in sys.argv[1:]
-    binary = os.path.join(ROOT, "oracle", "_ref", "ref_task")
+    hip = "--hip" in sys.argv[1:]
+    binary = os.path.join(ROOT, "oracle", "_ref", "ref_task_hip" if hip else "ref_task")
     if not os.path.exists(binary):
         sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
     bad = 0
@@ -85,7 +90,7 @@ def main():
             md5, n, dt, rc = run_ref_task(binary, ARGS[k], os.path.join(d, k + ".bin"))
             ok = md5 == REF[k]["md5"] and n == REF[k]["bytes"]
             bad += not ok
-            print("%s  ref_task %s  %d B  %.1f s  exit %d   recorded %s  %s   [%s]" % (
+            print(("%s  " + ("ref_task_hip" if hip else "ref_task") + " %s  %d B  %.1f s  exit %d   recorded %s  %s   [%s]") % (
                 k, md5, n, dt, rc, REF[k]["md5"], "EQUAL" if ok else "DIFFERENT", ARGS[k]), flush=True)
             os.unlink(os.path.join(d, k + ".bin"))
         if o2:
