@@ -575,8 +575,11 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     if (R < 4) R = 4;
     const int nchunks = (N + R - 1) / R;
     const int tiles = (nchunks + 63) / 64;
-    // carrier-walk legs: ~8 per epoch so that (legs x channels) fills the chip
+    // carrier-walk legs: ~8 per epoch so that (legs x channels) fills the chip.  A batch of a few epochs (one-epoch calls:
+    // INTEGRATION.md option B) is latency, not throughput: its walk and its verification are as long as ONE leg, so it gets
+    // up to 32 shorter ones (one-epoch call: k_walk_carr / k_verify_carr 124 / 121 -> 38 / 36 us, tools/trace_epoch.sh)
     int legs = 8;
+    if (E * 8 < 256) legs = std::min(32, 256 / E);
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_LEGS")) legs = atoi(env) > 0 ? atoi(env) : legs;
 #endif
