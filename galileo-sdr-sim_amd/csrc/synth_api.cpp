@@ -119,6 +119,7 @@ void init_tables()
 }
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
+constexpr size_t kRunHostStagedBytes = 32u << 20;  // gal_synth_run_host: batches up to here land in pinned memory of the handle
 constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block per slot stitches the carrier legs
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
 constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = chunk length of its batches (synth_group.hip: SG_CHUNK)
@@ -171,6 +172,8 @@ struct gal_synth {
     int range_e0 = 0, range_ne = 0;  // epoch range of the last execute
     void *own_iq = nullptr;
     size_t own_iq_bytes = 0;
+    void *own_pin = nullptr;  // gal_synth_run_host, small batches: pinned landing buffer of the device->host copy
+    size_t own_pin_bytes = 0;
     int *h_ctr = nullptr;  // pinned: [CTR_COUNT] counters, [CTR_COUNT] spare, then the completion flag (k_publish)
     uint32_t *h_flag = nullptr;  // = (uint32_t *)(h_ctr + 2 * CTR_COUNT): sequence number of the last batch whose record is complete
     uint32_t seq = 0;            // sequence number of the batch in flight
@@ -385,6 +388,7 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->arena) hipFree(h->arena);
     if (h->own_iq) hipFree(h->own_iq);
+    if (h->own_pin) hipHostFree(h->own_pin);
     if (h->d_lut) hipFree(h->d_lut);
     if (h->d_str) hipFree(h->d_str);
     if (h->h_up) hipHostFree(h->h_up);
@@ -886,6 +890,15 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     // wait here, so several handles can be kept in flight (the latency-bound walk of one batch then runs beside the
     // issue-bound synthesis of another).  gal_synth_finish() looks at the counters; in the rare case that the chain was
     // not verified by then it iterates further and repeats the synthesis.
+    // (a batch of a few epochs: the code chain of ONE epoch -- 550 dependent closed-form steps, 115 us -- is the longer of the two
+    // since the carrier legs are short there, so it goes first)
+    const bool code_first = h->Pw.E * 8 < 256 && h->aux_stream && h->aux_stream != ws;
+    if (code_first) {
+        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
+        galk_launch_walk_code(P, h->aux_stream);
+        galk_launch_pages(P, h->aux_stream);
+        HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
+    }
     galk_launch_carr_guess(P, ws);
     int n_passes = h->enq_passes;
 #ifdef GAL_TEST_HOOKS
@@ -898,10 +911,12 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the carrier chain:
     // they run on a second stream beside it and join before k_synth.  (Enqueued after the carrier passes: every launch
     // call in front of those delays the critical path by the 5-8 us the call takes.)
-    HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
-    galk_launch_walk_code(P, h->aux_stream);
-    galk_launch_pages(P, h->aux_stream);
-    HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
+    if (!code_first) {
+        HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_prep, 0));
+        galk_launch_walk_code(P, h->aux_stream);
+        galk_launch_pages(P, h->aux_stream);
+        HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
+    }
     // k_synth_g batches: the carrier checkpoints are verified by a kernel of their own (k_verify_carr), on the walker stream
     // behind the chain and beside the synthesis; the completion record waits for both
     bool verify_beside = h->P.fam == 1 && ws != st && h->nact_max != 0;
@@ -1135,11 +1150,33 @@ int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n
         if (hipMalloc(&h->own_iq, bytes) != hipSuccess) return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", bytes);
         h->own_iq_bytes = bytes;
     }
+    // Small batches (one-epoch calls, INTEGRATION.md option B) are latency: their copy is enqueued behind the batch at once, into
+    // pinned memory of the handle, so that it runs while gal_synth_finish is still on its way back; what is left behind finish is
+    // one memcpy into the caller's (pageable) buffer.  (hipMemcpy into pageable memory, issued only after finish, cost such a
+    // call 100 us between the completion record and the start of its copy.)
+    const bool staged = bytes <= (size_t)kRunHostStagedBytes;
+    if (staged && bytes > h->own_pin_bytes) {
+        if (h->own_pin) hipHostFree(h->own_pin);
+        h->own_pin = nullptr;
+        h->own_pin_bytes = 0;
+        if (hipHostMalloc(&h->own_pin, bytes, hipHostMallocDefault) != hipSuccess)
+            return fail(GAL_E_NOMEM, "hipHostMalloc of %zu bytes failed", bytes);
+        h->own_pin_bytes = bytes;
+    }
     rc = gal_synth_execute(h, (int16_t *)h->own_iq);
     if (rc) return rc;
+    hipStream_t st = handle_stream(h);
+    if (staged) HIP_TRY(hipMemcpyAsync(h->own_pin, h->own_iq, bytes, hipMemcpyDeviceToHost, st));
     rc = gal_synth_finish(h, state_out, stats);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(iq_host, h->own_iq, bytes, hipMemcpyDeviceToHost));
+    if (!staged) {
+        HIP_TRY(hipMemcpy(iq_host, h->own_iq, bytes, hipMemcpyDeviceToHost));
+        return GAL_OK;
+    }
+    // finish() repeats the synthesis when the speculative chain was not verified in time (rare): the copy then has to be repeated too
+    if (h->stats.synth_runs != 1) HIP_TRY(hipMemcpyAsync(h->own_pin, h->own_iq, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(iq_host, h->own_pin, bytes);
     return GAL_OK;
 }
 
