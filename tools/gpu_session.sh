@@ -13,7 +13,9 @@ timeout 600 python bench.py --no-extras --no-cpu-baseline --channels 9 > gpurun_
 timeout 300 python tools/per_epoch_latency.py > gpurun_out/${tag}_latency.log 2>&1
 timeout 300 python tools/per_epoch_breakdown.py >> gpurun_out/${tag}_latency.log 2>&1
 timeout 300 tools/trace_step.sh $tag > gpurun_out/${tag}_trace.log 2>&1
-tail -3 gpurun_out/${tag}_pytest.log; tail -8 gpurun_out/${tag}_profile.log | cut -c1-300; cat gpurun_out/${tag}_latency.log; tail -9 gpurun_out/${tag}_trace.log
+timeout 300 tools/trace_epoch.sh $tag > gpurun_out/${tag}_trace_epoch.log 2>&1
+[ -x oracle/_ref/ref_task_hip ] && timeout 300 python tools/ref_task_goldens.py --hip > gpurun_out/${tag}_ref_task_hip_md5.log 2>&1
+tail -3 gpurun_out/${tag}_pytest.log; tail -8 gpurun_out/${tag}_profile.log | cut -c1-300; cat gpurun_out/${tag}_latency.log; tail -9 gpurun_out/${tag}_trace.log; tail -14 gpurun_out/${tag}_trace_epoch.log; cut -c1-110 gpurun_out/${tag}_ref_task_hip_md5.log
 python - $tag <<'PY'
 import json,sys
 tag=sys.argv[1]
