@@ -91,3 +91,47 @@ def test_reference_with_the_loop_patch_writes_the_reference_file(k, tmp_path):
     assert n == ref_n and n > 0
     a, b = np.fromfile(ref_path, dtype=np.int16), np.fromfile(out, dtype=np.int16)
     assert a.any() and np.array_equal(a, b)
+
+
+# ---- answers the reference program gave HERE, kept as a fixture: tests/golden/ref_task_recorded.json (tools/ref_task_fuzz.py --record:
+# every random case with the md5 and the byte count of the reference's file).  Needs neither /root/reference nor the binary at test time.
+RECORDED = os.path.join(G, "ref_task_recorded.json")
+
+
+def _recorded(max_dur, count):
+    if not os.path.exists(RECORDED):
+        return []
+    cases = [k for k in json.load(open(RECORDED)) if k["recorded"][0] not in (None, "timeout") and k["dur"] <= max_dur]
+    step = max(1, len(cases) // count)
+    return cases[::step][:count]
+
+
+def _case_args(k):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from ref_task_fuzz import case_args
+    return case_args(dict(k, llh=tuple(k["llh"])))
+
+
+@pytest.mark.parametrize("k", _recorded(3.0, 8), ids=lambda k: "case%d" % k["c"])
+def test_front_end_and_oracle_reproduce_recorded_reference_answers(pkg, k):
+    args = _case_args(k)
+    llh = (42.3601, -71.0589, 2.0) if k["no_l"] else tuple(float(v) for v in args.split()[1].split(","))
+    sc = pkg.Scenario(NAV, llh=llh, start=None if k["no_t"] else k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
+    rows = sc.all()
+    if sc.eph_gaps:
+        pytest.skip("ephemeris gap: the reference's behaviour is undefined there")
+    iq, _ = oracle_run(rows, 260000, 2.6e6)
+    assert [hashlib.md5(iq.tobytes()).hexdigest(), iq.nbytes] == k["recorded"][:2], args
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", _recorded(5.0, 32), ids=lambda k: "case%d" % k["c"])
+def test_cli_reproduces_recorded_reference_answers(k, tmp_path):
+    args = _case_args(k)
+    out = str(tmp_path / "o.bin")
+    r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if "no ephemeris within an hour" in r.stderr:
+        pytest.skip("ephemeris gap: the reference's behaviour is undefined there")
+    data = open(out, "rb").read()
+    assert [hashlib.md5(data).hexdigest(), len(data)] == k["recorded"][:2], args

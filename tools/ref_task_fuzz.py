@@ -12,6 +12,9 @@ the reference directly -- no recorded md5 in between.  CPU only; needs /root/ref
 HIP -> file, on the same command line -- instead of front-end -> oracle; output of the round's run: profiles/r04_ref_task_fuzz_cli.log.
 --odd: the corners of the command line too -- -t or -l left out, fractional durations and seconds, the ends of the coordinate ranges,
 starts at the edges of the file's span (profiles/r04_ref_task_fuzz_odd.log).
+--record F: besides comparing, write every case with the reference's md5 / byte count to the JSON file F (made HERE, where the reference
+runs in parallel); --replay F --cli: on the GPU box, take the reference's answers from F instead of running the reference there (it binds
+a fixed UDP port, so it runs one instance at a time without network namespaces): only the product runs (r04_ref_task_replay_cli.log).
 --toc: long cases (65-130 s) that run across a 10-minute mark of the records' TOC grid and several 30 s refreshes (r04_ref_task_fuzz_toc.log).
 
 A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
@@ -105,8 +108,16 @@ def run_case_cli(k, args, ref_md5, ref_n, rc):
                 n_sv=-1, samples=n // 4)
 
 
+def _flag_value(name):
+    a = sys.argv[1:]
+    return a[a.index(name) + 1] if name in a and a.index(name) + 1 < len(a) else None
+
+
 def run_case(k):
     from ref_task_goldens import run_ref_task
+    if "recorded" in k:  # --replay: the reference's answer comes from the file
+        ref_md5, ref_n, rc = k["recorded"]
+        return run_case_cli(k, case_args(k), ref_md5, ref_n, rc)
     from __graft_entry__ import load_pkg
     from oracle_binding import oracle_run
     pkg = load_pkg()
@@ -136,20 +147,31 @@ def run_case(k):
 
 
 def main():
-    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rec_path, rep_path = _flag_value("--record"), _flag_value("--replay")
+    argv = [a for a in sys.argv[1:] if not a.startswith("--") and a not in (rec_path, rep_path)]
     n_cases = int(argv[0]) if len(argv) > 0 else 40
     seed = int(argv[1]) if len(argv) > 1 else 1
     jobs = int(argv[2]) if len(argv) > 2 else 6
-    if not os.path.exists(BIN):
-        sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
-    rng = np.random.default_rng(seed)
-    cases = [make_case(rng, c, odd="--odd" in sys.argv[1:]) for c in range(n_cases)]
+    if rep_path:
+        import json
+        cases = json.load(open(rep_path))
+        for k in cases:
+            k["llh"] = tuple(k["llh"])
+        n_cases = len(cases)
+    else:
+        if not os.path.exists(BIN):
+            sys.exit("oracle/_ref/ref_task is not built (make -C oracle ref, with /root/reference present)")
+        rng = np.random.default_rng(seed)
+        cases = [make_case(rng, c, odd="--odd" in sys.argv[1:]) for c in range(n_cases)]
+    recorded = []
     t0 = time.time()
     bad = skipped = undefined = 0
     samples = 0
     svs = {}
     with mp.get_context("spawn").Pool(jobs) as pool:
         for r in pool.imap_unordered(run_case, cases):
+            if rec_path and r.get("ref") not in ("timeout",) and "ref_n" in r:
+                recorded.append(dict(r["k"], recorded=[r.get("ref"), r["ref_n"], r.get("ref_rc", -6)]))
             if r["status"] == "skipped":
                 skipped += 1
                 print("skipped case %d [%s]: %s; the reference wrote %d bytes (exit %d)" % (r["k"]["c"], r["args"], r["why"], r["ref_n"], r["ref_rc"]), flush=True)
@@ -168,6 +190,11 @@ def main():
     print("ref_task fuzz%s (seed %d): %d cases, %d compared (%.1f M samples), %d different, %d skipped (both reject the start time), %d where "
           "the reference's behaviour is undefined (ephemeris gap), SV counts %s, %.0f s" % (
               " against the product CLI (front-end -> HIP -> file)" if USE_CLI else " against front-end -> oracle", seed, n_cases, n_cases - skipped - undefined, samples / 1e6, bad, skipped, undefined, dict(sorted(svs.items())), time.time() - t0))
+    if rec_path:
+        import json
+        recorded.sort(key=lambda k: k["c"])
+        json.dump(recorded, open(rec_path, "w"), indent=0)
+        print("recorded %d cases with the reference's md5 in %s" % (len(recorded), rec_path))
     sys.exit(1 if bad else 0)
 
 
