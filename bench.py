@@ -30,10 +30,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 METRIC = "IQ Msamples/s (×real-time @2.6MS/s), 12-SV static E1B/C, 1/2/4/8 GPU"
 
 
-def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
+def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0, gpu_out=None):
     """Time the CPU restatement of the reference loop (oracle/galsyn_oracle.c, 1 thread, -O2
     -ffp-contract=off) on a bounded prefix of the same workload.  Checker code used ONLY as the
-    reported baseline, never in the product path."""
+    reported baseline, never in the product path.
+    gpu_out: the int16 output of the timed steps (device tensor): the oracle's samples over the epochs it ran -- all of them
+    on the GPU box's host -- are compared with it int16 by int16; the verdict goes into the line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import oracle_run
 
@@ -43,9 +45,21 @@ def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
     dt = time.perf_counter() - t0
     n_ep = int(max(probe, min(params.shape[0], target_seconds / max(dt / probe, 1e-6))))
     t0 = time.perf_counter()
-    oracle_run(params[:n_ep], n_samp, rate)
+    ref_iq, _ = oracle_run(params[:n_ep], n_samp, rate)
     dt = time.perf_counter() - t0
     plain = n_ep * n_samp / dt / 1e6
+    verdict = None
+    if gpu_out is not None:
+        # the timed output against the checker, every int16 of the epochs the checker produced (in pieces of 64 epochs)
+        bad, piece = 0, 64 * n_samp * 2
+        chk = 0
+        for a in range(0, n_ep * n_samp * 2, piece):
+            b = min(a + piece, n_ep * n_samp * 2)
+            bad += int(np.count_nonzero(gpu_out[a:b].cpu().numpy() != ref_iq[a:b]))
+            chk = (chk + int(ref_iq[a:b].view(np.int32).astype(np.int64).sum())) & 0xFFFFFFFF
+        verdict = {"equal": bad == 0, "epochs_compared": int(n_ep), "of_epochs": int(params.shape[0]), "int16_different": bad,
+                   "oracle_checksum": "%08x" % chk}
+    del ref_iq
     # with the reference's per-sample clock read (src/galileo-sdr.cpp:485), on a shorter prefix
     n_ck = max(probe, n_ep // 4)
     t0 = time.perf_counter()
@@ -87,6 +101,7 @@ def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0):
         ref_own = {"error": str(e)[:200]}
     return {
         **({"reference_loop": ref_own} if ref_own else {}),
+        **({"output_vs_oracle": verdict} if verdict else {}),
         "value": round(plain, 3),
         "unit": "Msamples/s",
         "cores": 1,
@@ -640,6 +655,17 @@ def main():
         if args.signal == "cboc":
             line["config"]["signal"] = "CBOC(6,1,1/11), opt-in mode (not the reference's signal, not the headline)"
             args.no_cpu_baseline = True
+        if world == 1 and not args.no_cpu_baseline:
+            # (in front of the extras, which free the timed outputs: the checker's samples are compared with them)
+            line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate, gpu_out=out)  # (world 1: the whole scenario)
+            v = line["cpu_baseline"].pop("output_vs_oracle", None)
+            if v is not None:
+                line["config"]["output_equals_oracle"] = v["equal"]
+                line["config"]["output_vs_oracle"] = v
+                if not v["equal"]:
+                    print(json.dumps(line))
+                    raise SystemExit("bench: the timed output differs from the oracle in %d int16 values of the first %d epochs"
+                                     % (v["int16_different"], v["epochs_compared"]))
         if default_run and not args.no_extras:
             # untimed-for-headline legs (kernel-only above, kernel + D2H and the file sink here; configs 3/4)
             line["e2e"] = {"kernel_plus_d2h": leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp)}
@@ -655,8 +681,6 @@ def main():
                                "syn24_full": leg_config(torch, pkg, "syn24_full", 5999, 3, local_rank, streams),
                                # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
                                "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank, streams)}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate)
         line["x_realtime"] = round(value * 1e6 / rate, 2)
         print(json.dumps(line))
     if dist is not None:

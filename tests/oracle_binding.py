@@ -63,6 +63,21 @@ def oracle_run(params, samples_per_epoch, sample_rate, state_in=None, clock_read
     return iq, st_out
 
 
+def oracle_matches_device(out_dev, params, samples_per_epoch, sample_rate, piece=200, state_in=None, cboc=False):
+    """EVERY epoch of a device output (torch int16 tensor, [n_epochs * N * 2]) against the oracle, int16 by int16: the oracle
+    runs the batch in pieces of `piece` epochs with the channel state carried (host memory stays at one piece), each piece is
+    compared with the matching slice of the device buffer.  Returns (int16 values that differ, the oracle's end state)."""
+    n_epochs = params.shape[0]
+    per = samples_per_epoch * 2
+    assert out_dev.numel() == n_epochs * per, (out_dev.numel(), n_epochs, per)
+    st, bad = state_in, 0
+    for a in range(0, n_epochs, piece):
+        b = min(a + piece, n_epochs)
+        ref, st = oracle_run(params[a:b], samples_per_epoch, sample_rate, state_in=st, cboc=cboc)
+        bad += int(np.count_nonzero(out_dev[a * per:b * per].cpu().numpy() != ref))
+    return bad, st
+
+
 def oracle_tables():
     cos = np.zeros(512, dtype=np.int32)
     sin = np.zeros(512, dtype=np.int32)

@@ -24,6 +24,10 @@ def test_bench_json_line():
     assert d["preroll_steps"] > 0  # the device wake-up in front of the warm-up steps is reported, never timed
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["chain_mismatch"] == 0
+    # the oracle's verdict on the timed output is part of the record (every epoch of this small batch)
+    assert d["config"]["output_equals_oracle"] is True
+    v = d["config"]["output_vs_oracle"]
+    assert v["epochs_compared"] == 24 and v["int16_different"] == 0 and v["oracle_checksum"] == d["config"]["output_checksum"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k

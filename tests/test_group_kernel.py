@@ -6,7 +6,7 @@ GAL_CFG_EXACT_REPLAY); gal_synth_stats_t.kernel_family says which ran, .repaired
 import numpy as np
 import pytest
 
-from oracle_binding import oracle_run
+from oracle_binding import oracle_matches_device, oracle_run
 from test_parity_gpu import _compare
 
 pytestmark = pytest.mark.gpu
@@ -204,7 +204,8 @@ def test_group_kernel_randomised_soak_slice(pkg):
 
 def test_group_kernel_full_size_equals_exact_replay(pkg):
     """M-SYN12 at BASELINE's size (1199 epochs x 260000 samples x 12 SVs = 3.7e9 channel-samples): about two thousand of the
-    19.5 million groups are listed and replayed; both kernels equal word for word, first and last epochs equal to the oracle."""
+    19.5 million groups are listed and replayed; both kernels equal word for word, and EVERY epoch equals the oracle int16 by
+    int16 (8 s of CPU on the GPU box's host)."""
     import torch
 
     p = pkg.workloads.m_syn12()
@@ -220,8 +221,8 @@ def test_group_kernel_full_size_equals_exact_replay(pkg):
                 assert 200 <= stats["repaired_groups"] <= 20000, stats
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
-    ref_iq, _ = oracle_run(p[:2], 260000, 2.6e6)
-    assert np.array_equal(outs[0][: ref_iq.size].cpu().numpy(), ref_iq)
+    bad, _ = oracle_matches_device(outs[0], p, 260000, 2.6e6)
+    assert bad == 0, "%d int16 values differ from the oracle" % bad
 
 
 def test_group_kernel_epoch_ranges_of_one_plan(pkg):
