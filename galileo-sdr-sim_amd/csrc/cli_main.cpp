@@ -63,9 +63,10 @@ void usage(const char *prog)
            "  -t <date,time>   Scenario start time YYYY/MM/DD,hh:mm:ss\n"
            "  -d <duration>    Duration [sec]\n"
            "  -I <x>           Disable ionospheric delay\n"
-           "  -T <date,time>   Start time as -t without its range check, and the UTC reference time overwritten (use `now` for the\n"
-           "                   current time) -- what the reference's -T does; with --shift-toe also TOC and TOE of every record\n"
-           "                   are moved to the start time, which is what the option is meant to do (include/galscen.h)\n"
+           "  -T <date,time>   Overwrite TOC and TOE of every record to the start time (use `now` for the current time): the\n"
+           "                   navigation file becomes valid at any start, as the option is meant to (include/galscen.h)\n"
+           "  --ref-T          with -T: what the reference, built with its own flags, does instead -- -t without its range check\n"
+           "                   and the UTC reference time overwritten, NO record shifted (an empty sky outside the file's span)\n"
            "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (0 = off; default: 7533 on\n"
            "                   the loopback interface; a port given here is bound on all interfaces, as the reference's)\n"
            "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
@@ -295,6 +296,10 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
         fprintf(stderr, "ERROR: no site (lat,lon,hgt) in %s\n", sites_file);
         return 1;
     }
+    if (udp_base > 0 && (size_t)udp_base + sites.size() - 1 > 65535) {  // site k listens on port + k
+        fprintf(stderr, "ERROR: -P %d with %zu sites runs past port 65535\n", udp_base, sites.size());
+        return 1;
+    }
     if (n_gpus <= 0) n_gpus = gal_synth_device_count();
     if (n_gpus <= 0) {
         fprintf(stderr, "ERROR: no usable gfx950 device (there is no CPU fallback)\n");
@@ -404,15 +409,16 @@ int main(int argc, char *argv[])
     sc.duration_s = 300.0;
     sc.iono_enable = 1;
     sc.n_slots = GAL_MAX_CHAN;
-    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false, exact_replay = false, shift_toe = false;
+    bool verbose = false, have_batch = false, udp_given = false, realtime = false, cboc = false, exact_replay = false, shift_toe = false, ref_T = false;
     int batch_epochs = 128, n_writers = -1, sites_gpus = 0, sites_per_gpu = 1;
     sc.udp_port = GAL_SCEN_UDP_PORT;  // the reference always listens for position updates (src/galileo-sdr.cpp:185)
     sc.udp_loopback = 1;              // ... on every interface; the default listener here takes local datagrams only
 
-    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU, OPT_EXACT, OPT_SHIFT_TOE };
+    enum { OPT_STRICT = 1000, OPT_SITES, OPT_WRITERS, OPT_GPUS, OPT_PER_GPU, OPT_EXACT, OPT_SHIFT_TOE, OPT_REF_T };
     static const struct option long_opts[] = {{"strict", no_argument, nullptr, OPT_STRICT},
                                               {"exact-replay", no_argument, nullptr, OPT_EXACT},
                                               {"shift-toe", no_argument, nullptr, OPT_SHIFT_TOE},
+                                             {"ref-T", no_argument, nullptr, OPT_REF_T},
                                               {"sites", required_argument, nullptr, OPT_SITES},
                                               {"writers", required_argument, nullptr, OPT_WRITERS},
                                               {"gpus", required_argument, nullptr, OPT_GPUS},
@@ -423,7 +429,7 @@ int main(int argc, char *argv[])
     while ((opt = getopt_long(argc, argv, "e:n:o:u:g:l:T:t:d:G:a:p:iI:U:b:vB:P:rC", long_opts, nullptr)) != -1) {
         if (opt != 'l' && opt != 'o' && opt != 'P' && opt != OPT_SITES && opt != OPT_GPUS && opt != OPT_PER_GPU && opt != '?' && opt != ':') {
             if (opt >= 1000) {
-                child_args.push_back(opt == OPT_STRICT ? "--strict" : opt == OPT_EXACT ? "--exact-replay" : opt == OPT_SHIFT_TOE ? "--shift-toe" : "--writers");
+                child_args.push_back(opt == OPT_STRICT ? "--strict" : opt == OPT_EXACT ? "--exact-replay" : opt == OPT_SHIFT_TOE ? "--shift-toe" : opt == OPT_REF_T ? "--ref-T" : "--writers");
             } else {
                 char name[3] = {'-', (char)opt, 0};
                 child_args.push_back(name);
@@ -470,6 +476,7 @@ int main(int argc, char *argv[])
         case OPT_STRICT: sc.strict_eph = 1; break;
         case OPT_EXACT: exact_replay = true; break;
         case OPT_SHIFT_TOE: shift_toe = true; break;
+        case OPT_REF_T: ref_T = true; break;
         case OPT_SITES: snprintf(sitesfile, sizeof(sitesfile), "%s", optarg); break;
         case OPT_WRITERS: n_writers = atoi(optarg); break;
         case OPT_GPUS: sites_gpus = atoi(optarg); break;
@@ -486,7 +493,16 @@ int main(int argc, char *argv[])
         printf("ERROR: Galileo ephemeris/nav_msg file is not specified.\n");
         exit(1);
     }
-    if (shift_toe && sc.time_overwrite) sc.time_overwrite = 2;
+    // plain -T shifts TOC / TOE (time_overwrite 2; --shift-toe says so explicitly); --ref-T asks for the reference as built (1)
+    if ((shift_toe || ref_T) && !sc.time_overwrite) {
+        printf("ERROR: %s needs -T <date,time>.\n", ref_T ? "--ref-T" : "--shift-toe");
+        exit(1);
+    }
+    if (shift_toe && ref_T) {
+        printf("ERROR: --shift-toe and --ref-T exclude each other.\n");
+        exit(1);
+    }
+    if (sc.time_overwrite) sc.time_overwrite = ref_T ? 1 : 2;
     if (sitesfile[0]) {
         // several listeners cannot share a port: the sites run without the position listener unless -P names a base port, in
         // which case site k (in file order) listens on port + k
@@ -516,7 +532,7 @@ int main(int argc, char *argv[])
     }
     if (orc != GAL_OK) {
         fprintf(stderr, "%s\n", gal_scen_last_error());
-        if (strstr(gal_scen_last_error(), "duration too short") && strcmp(outfile, "-") != 0) {
+        if (orc == GAL_E_EMPTY && strcmp(outfile, "-") != 0) {
             // (int)(10 d + 0.5) < 2: the reference opens its sink, finds no epoch to generate and closes it (src/galileo-sdr.cpp:438)
             FILE *f = fopen(outfile, "wb");
             if (f) fclose(f);

@@ -229,7 +229,7 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
     }
     if (s->numd < 2) {
         delete s;
-        return scen_fail(GAL_E_INVAL, "duration too short: nothing to generate");
+        return scen_fail(GAL_E_EMPTY, "duration too short: nothing to generate");
     }
 
     // earliest / latest usable start (src/galileo-sdr.cpp:230-270)
@@ -308,6 +308,15 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
     }
     s->grx.sec = s->grx.sec + kEpochDt;
     allocate_channels(s, s->grx, s->xyz0);
+    if (cfg->time_overwrite) {
+        // -T skips the range check of -t: say so when the start it let through leaves the sky empty
+        int in_view = 0;
+        for (int i = 0; i < cfg->n_slots; ++i) in_view += s->chan[i].prn > 0;
+        if (in_view == 0)
+            fprintf(stderr, "WARNING: no satellite in view at the start time -T let through%s: the IQ will be all zero\n",
+                    cfg->time_overwrite == 1 ? " (time_overwrite 1 = the reference as built: no ephemeris record is shifted; "
+                                               "2 / plain -T shifts TOC and TOE to the start time)" : "");
+    }
     s->grx.sec = s->grx.sec + kEpochDt;
     s->iumd = 1;
     if (cfg->udp_port > 0) {

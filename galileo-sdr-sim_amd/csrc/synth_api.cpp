@@ -15,6 +15,7 @@
 #include <time.h>
 #include <vector>
 
+#define GAL_SYNTH_NO_SIZED_MACROS 1
 #include "synth_dev.h"
 #include "e1_tables.inc"
 
@@ -48,6 +49,13 @@ static double rw_threshold_gap(double s)
     double g = 1.0;
     for (int i = 1; i < 15; ++i) g = std::min(g, T[i] - T[i - 1]);
     return g;
+}
+// Form of the resampled windows a code step of cs2 half chips per sample takes (k_synth<.., RW>, k_synth_g<.., MODE>): 1 = holds
+// (the reference's 2.6 MS/s), 2 = at most two advances per 16 samples (from 15.4 MS/s), 3 = at most four (from 7.7 MS/s), 0 = none.
+// ONE definition for gal_synth_plan's gate and for gal_synth_create's choice of the code objects to load up front.
+static int rw_mode_of(double cs2)
+{
+    return (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
 }
 static constexpr double kRwMinGap = 1.0 / 128.0 + 4e-6;
 // the CBOC mode keeps two bin tables per channel (chip holds, BOC(6,1) half-period parity) of 64 bins each
@@ -354,10 +362,16 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     // code-object load now, not inside the first batch (the families this configuration can launch)
     galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
     {
+        // k_synth_g's code object, if a batch of this configuration can take it: the plan's own gate (rw_mode_of; the CBOC mode
+        // exists in form 1 only) on the nominal code step and on the steps +-1e-4 around it (Doppler moves a channel's step by a
+        // few 1e-6 of itself)
         const double ratio = 2.0 * 1.023e6 / cfg->sample_rate;
-        if (!(cfg->flags & GAL_CFG_EXACT_REPLAY) && ((ratio >= 0.70 && ratio <= 1.02) || (ratio <= 0.28 && !(cfg->flags & GAL_CFG_CBOC))) &&
-            cfg->chunk_samples <= 0)
-            galk_warm_g(nullptr);
+        bool g_possible = false;
+        for (const double f : {1.0 - 1e-4, 1.0, 1.0 + 1e-4}) {
+            const int m = rw_mode_of(ratio * f);
+            g_possible = g_possible || (m != 0 && (m == 1 || !(cfg->flags & GAL_CFG_CBOC)));
+        }
+        if (g_possible && !(cfg->flags & GAL_CFG_EXACT_REPLAY) && cfg->chunk_samples <= 0) galk_warm_g(nullptr);
     }
     create_stage("warm launches enqueued");
     // First use of the handle's own streams: HIP creates a stream's hardware queue at its first use, and which queues
@@ -487,7 +501,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             if (rw_ok) {
                 const double cs2 = 2.0 * (r.f_code * delt);
                 cs2_max = std::max(cs2_max, cs2);
-                const int mode = (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
+                const int mode = rw_mode_of(cs2);
                 rw_ok = mode != 0 && (rw_mode == 0 || rw_mode == mode);
                 rw_mode = mode;
                 // (evaluated for every record: the distance is not a continuous function of the step -- when some u s
@@ -953,7 +967,20 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     return GAL_OK;
 }
 
+size_t gal_synth_stats_size(void) { return sizeof(gal_synth_stats_t); }
+
+// the caller's struct may be older (shorter) than the library's: never more than its own sizeof is written
+static void copy_stats(const gal_synth *h, void *stats, size_t stats_bytes)
+{
+    if (stats) memcpy(stats, &h->stats, std::min(stats_bytes, sizeof(gal_synth_stats_t)));
+}
+
 int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats)
+{
+    return gal_synth_finish_n(h, state_out, stats, sizeof(gal_synth_stats_t));
+}
+
+int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats, size_t stats_bytes)
 {
     if (!h) return fail(GAL_E_INVAL, "null handle");
     if (!h->executed) return fail(GAL_E_STATE, "gal_synth_finish before gal_synth_execute");
@@ -1114,7 +1141,7 @@ int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stat
     h->stats.window_mode = h->P.rw;
     h->legs_walked = ctr_end[CTR_WALKS];
     h->legs_translated = ctr_end[CTR_SHIFTS];
-    if (stats) *stats = h->stats;
+    copy_stats(h, stats, stats_bytes);
     if (state_out) {
         if (!h->state_fetched)
             HIP_TRY(hipMemcpy(h->h_state, P->state_out, sizeof(gal_chan_state_t) * P->S, hipMemcpyDeviceToHost));
@@ -1138,6 +1165,13 @@ int gal_synth_walk_counts(const gal_synth_t *h, int64_t *legs_walked, int64_t *l
 int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                        const gal_chan_state_t *state_in, int16_t *iq_host, gal_chan_state_t *state_out,
                        gal_synth_stats_t *stats)
+{
+    return gal_synth_run_host_n(h, params, n_epochs, state_in, iq_host, state_out, stats, sizeof(gal_synth_stats_t));
+}
+
+int gal_synth_run_host_n(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                         const gal_chan_state_t *state_in, int16_t *iq_host, gal_chan_state_t *state_out,
+                         void *stats, size_t stats_bytes)
 {
     if (!h || !iq_host) return fail(GAL_E_INVAL, "gal_synth_run_host: null argument");
     int rc = gal_synth_plan(h, params, n_epochs, state_in);
@@ -1167,7 +1201,7 @@ int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n
     if (rc) return rc;
     hipStream_t st = handle_stream(h);
     if (staged) HIP_TRY(hipMemcpyAsync(h->own_pin, h->own_iq, bytes, hipMemcpyDeviceToHost, st));
-    rc = gal_synth_finish(h, state_out, stats);
+    rc = gal_synth_finish_n(h, state_out, stats, stats_bytes);
     if (rc) return rc;
     if (!staged) {
         HIP_TRY(hipMemcpy(iq_host, h->own_iq, bytes, hipMemcpyDeviceToHost));

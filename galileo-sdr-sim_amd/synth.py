@@ -99,7 +99,10 @@ EXPORTED_SYMBOLS = (
     "gal_synth_execute",
     "gal_synth_execute_range",
     "gal_synth_finish",
+    "gal_synth_finish_n",
+    "gal_synth_stats_size",
     "gal_synth_run_host",
+    "gal_synth_run_host_n",
     "gal_tables_e1b",
     "gal_tables_e1c",
     "gal_tables_cos512",
@@ -144,6 +147,10 @@ def load_library(hooks=False):
     lib.gal_synth_execute_range.restype = ctypes.c_int
     lib.gal_synth_finish.argtypes = [vp, vp, ctypes.POINTER(_Stats)]
     lib.gal_synth_run_host.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.POINTER(_Stats)]
+    # the sized entry points (what the header's macros call): the library copies min(our sizeof, its own) bytes of statistics
+    lib.gal_synth_finish_n.argtypes = [vp, vp, ctypes.POINTER(_Stats), ctypes.c_size_t]
+    lib.gal_synth_run_host_n.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.POINTER(_Stats), ctypes.c_size_t]
+    lib.gal_synth_stats_size.restype = ctypes.c_size_t
     for name in ("gal_tables_e1b", "gal_tables_e1c", "gal_tables_cos512", "gal_tables_sin512"):
         getattr(lib, name).restype = vp
     lib.gal_tables_cs25.restype = ctypes.c_uint32
@@ -271,7 +278,7 @@ class SynthEngine:
     def finish(self):
         st = np.zeros(self.n_slots, dtype=CHAN_STATE_DTYPE)
         stats = _Stats()
-        self._check(self._lib.gal_synth_finish(self._h, st.ctypes.data, ctypes.byref(stats)))
+        self._check(self._lib.gal_synth_finish_n(self._h, st.ctypes.data, ctypes.byref(stats), ctypes.sizeof(_Stats)))
         return st, {k: getattr(stats, k) for k, _ in _Stats._fields_}
 
     def run_host(self, params, state_in=None):
@@ -282,9 +289,9 @@ class SynthEngine:
         st = np.zeros(self.n_slots, dtype=CHAN_STATE_DTYPE)
         stats = _Stats()
         self._check(
-            self._lib.gal_synth_run_host(
+            self._lib.gal_synth_run_host_n(
                 self._h, p.ctypes.data, p.shape[0], s.ctypes.data if s is not None else None, iq.ctypes.data,
-                st.ctypes.data, ctypes.byref(stats)
+                st.ctypes.data, ctypes.byref(stats), ctypes.sizeof(_Stats)
             )
         )
         self.n_epochs = p.shape[0]

@@ -38,7 +38,9 @@ typedef enum gal_status {
     GAL_E_STATE = -4,     /* call sequence error (execute before plan, ...)                 */
     GAL_E_CHAIN = -5,     /* NCO chain self-check failed (see gal_synth_stats_t)            */
     GAL_E_IO = -6,
-    GAL_E_BUSY = -7       /* a resource another instance holds (galscen: the UDP position port)   */
+    GAL_E_BUSY = -7,      /* a resource another instance holds (galscen: the UDP position port)   */
+    GAL_E_EMPTY = -8      /* galscen: the duration holds no epoch, (int)(10 d + 0.5) < 2: nothing to generate (the reference
+                             opens its sink and closes it again, src/galileo-sdr.cpp:438)        */
 } gal_status_t;
 
 /* gal_chan_epoch_t.flags */
@@ -120,12 +122,18 @@ typedef struct gal_synth_stats {
                                    it (carrier chain not complete when the kernel was started, or the replay check failed) */
     int32_t kernel_family;      /* 0: exact replay, one chunk of ~1000 samples per lane (any rate, any signal); 1: one 16-sample
                                    group per lane, start states in closed form from the chunk's exact checkpoint, groups whose
-                                   chip pattern or table index hangs on the rounding history replayed exactly afterwards
-                                   (BOC(1,1), 0.74 <= 2 f_code / fs < 1 -- the reference's 2.6 MS/s; the default there)      */
+                                   chip pattern or table index hangs on the rounding history replayed exactly afterwards -- the
+                                   default wherever gal_synth_plan's gate admits the batch: automatic chunking, every code step
+                                   in one form of the resampled windows (window_mode 1, 2 or 3: the reference's 2.6 MS/s, and
+                                   from 7.7 MS/s up) with well separated thresholds, every carrier step in [2^-40, 0.0147]
+                                   cycles per sample; BOC(1,1) in all three forms, the CBOC mode in form 1                  */
     int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
     float   ms_repair;          /* family 1: device time of that replay (k_repair_g, behind the synthesis kernel; not in ms_synth) */
     int32_t reserved;
 } gal_synth_stats_t;
+/* The struct only ever GROWS AT ITS END (0.2: 40 bytes, up to chain_mismatch .. ms_synth; 0.3: 56).  gal_synth_finish and
+ * gal_synth_run_host are macros over the _n entry points below, which copy min(the caller's sizeof, the library's) bytes: a caller
+ * compiled against an older header never gets more than its own struct holds.  gal_synth_stats_size() = the library's sizeof. */
 
 typedef struct gal_synth gal_synth_t;
 
@@ -184,6 +192,8 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
  * (or the replay check disagreed) finish() repeats the synthesis into iq_dev.  Do not enqueue copies out of
  * iq_dev between execute() and finish(). */
 int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats);
+int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats, size_t stats_bytes);
+size_t gal_synth_stats_size(void);
 
 /* Diagnostics of the last gal_synth_finish(): carrier-chain legs evaluated by walking, legs accepted by
  * translation (csrc/nco_walk.h: binade_margin), and how often (since create) the replay check forced the
@@ -194,6 +204,14 @@ int gal_synth_walk_counts(const gal_synth_t *h, int64_t *legs_walked, int64_t *l
 int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                        const gal_chan_state_t *state_in, int16_t *iq_host,
                        gal_chan_state_t *state_out, gal_synth_stats_t *stats);
+int gal_synth_run_host_n(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                         const gal_chan_state_t *state_in, int16_t *iq_host,
+                         gal_chan_state_t *state_out, void *stats, size_t stats_bytes);
+#ifndef GAL_SYNTH_NO_SIZED_MACROS
+#define gal_synth_finish(h, state_out, stats) gal_synth_finish_n((h), (state_out), (stats), sizeof(gal_synth_stats_t))
+#define gal_synth_run_host(h, params, n_epochs, state_in, iq_host, state_out, stats) \
+    gal_synth_run_host_n((h), (params), (n_epochs), (state_in), (iq_host), (state_out), (stats), sizeof(gal_synth_stats_t))
+#endif
 
 /* Signal tables as the engine uses them (for tests and for the oracle to share DATA, not code). */
 const uint32_t *gal_tables_e1b(void);   /* [50][128] */

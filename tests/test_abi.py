@@ -34,6 +34,7 @@ def test_struct_layouts_match_header(pkg):
     import ctypes
 
     st = pkg.synth._Stats
+    assert ctypes.CDLL(pkg.synth.LIB_PATH).gal_synth_stats_size() == ctypes.sizeof(st)  # (c_int return: 56 fits)
     assert ctypes.sizeof(st) == 56 and st.ms_repair.offset == 48 and st.kernel_family.offset == 40 and st.repaired_groups.offset == 44 and st.ms_walk.offset == 24 and st.window_mode.offset == 32 and st.synth_runs.offset == 36
 
 
@@ -89,3 +90,23 @@ def test_headers_compile_as_c_and_link(pkg, tmp_path):
     assert "gfx950" in r.stdout and "active channels 9" in r.stdout
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_a_caller_with_an_older_stats_struct_is_not_overrun(pkg):
+    """gal_synth_stats_t only grows at its end; the header's gal_synth_finish / gal_synth_run_host are macros over the _n entry points,
+    which copy min(the caller's sizeof, the library's): a caller compiled against the 40-byte struct of 0.2 gets 40 bytes."""
+    lib = pkg.load_library()
+    n = 26000
+    p = pkg.workloads.make_synthetic(n_epochs=2, n_chan=3, n_slots=16, samples_per_epoch=n, seed=5)
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
+        iq = np.empty(2 * n * 2, dtype=np.int16)
+        st = np.zeros(16, dtype=pkg.CHAN_STATE_DTYPE)
+        buf = (ctypes.c_ubyte * 64)(*([0xAA] * 64))
+        pp = np.ascontiguousarray(p, dtype=pkg.CHAN_EPOCH_DTYPE)
+        rc = lib.gal_synth_run_host_n(eng._h, pp.ctypes.data, 2, None, iq.ctypes.data, st.ctypes.data,
+                                      ctypes.cast(buf, ctypes.POINTER(pkg.synth._Stats)), 40)
+        assert rc == 0
+    raw = bytes(buf)
+    assert raw[40:] == b"\xaa" * 24 and raw[:40] != b"\xaa" * 40
+    assert int.from_bytes(raw[8:12], "little") == 2  # n_epochs

@@ -56,7 +56,7 @@ def _args(k):
 def test_front_end_and_oracle_equal_the_reference_program(pkg, k, tmp_path):
     ref_md5, ref_n, _, _ = run_ref_task(BIN, _args(k), str(tmp_path / "r.bin"))
     rows = pkg.Scenario(NAV, llh=tuple(float(v) for v in k["llh"].split(",")), start=k["t"], duration_s=k["d"], iono_enable=k["iono"],
-                        time_overwrite=k["T"]).all()
+                        time_overwrite="ref" if k["T"] else False).all()
     assert (rows["prn"] > 0).any()
     iq, _ = oracle_run(rows, 260000, 2.6e6)
     assert (hashlib.md5(iq.tobytes()).hexdigest(), iq.nbytes) == (ref_md5, ref_n)
@@ -69,7 +69,8 @@ def test_cli_file_equals_the_reference_programs_file(k, tmp_path):
     """Same command line into the reference program and into the product CLI (front-end -> HIP -> file): the same bytes."""
     ref_path, out = str(tmp_path / "r.bin"), str(tmp_path / "o.bin")
     _, ref_n, _, _ = run_ref_task(BIN, _args(k), ref_path)
-    r = subprocess.run([CLI, "-e", NAV] + _args(k).split() + ["-P", "0", "-o", out], capture_output=True, text=True)
+    # (--ref-T: the reference's -T as built -- the CLI's plain -T shifts TOC / TOE, which is what the option is meant to do)
+    r = subprocess.run([CLI, "-e", NAV] + _args(k).split() + (["--ref-T"] if k["T"] else []) + ["-P", "0", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     a, b = np.fromfile(ref_path, dtype=np.int16), np.fromfile(out, dtype=np.int16)
     assert a.size * 2 == ref_n and a.any()
@@ -116,7 +117,7 @@ def _case_args(k):
 def test_front_end_and_oracle_reproduce_recorded_reference_answers(pkg, k):
     args = _case_args(k)
     llh = (42.3601, -71.0589, 2.0) if k["no_l"] else tuple(float(v) for v in args.split()[1].split(","))
-    sc = pkg.Scenario(NAV, llh=llh, start=None if k["no_t"] else k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
+    sc = pkg.Scenario(NAV, llh=llh, start=None if k["no_t"] else k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite="ref" if k["tovr"] else False)
     rows = sc.all()
     if sc.eph_gaps:
         pytest.skip("ephemeris gap: the reference's behaviour is undefined there")
@@ -129,7 +130,7 @@ def test_front_end_and_oracle_reproduce_recorded_reference_answers(pkg, k):
 def test_cli_reproduces_recorded_reference_answers(k, tmp_path):
     args = _case_args(k)
     out = str(tmp_path / "o.bin")
-    r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True)
+    r = subprocess.run([CLI, "-e", NAV] + args.split() + (["--ref-T"] if k["tovr"] else []) + ["-P", "0", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     if "no ephemeris within an hour" in r.stderr:
         pytest.skip("ephemeris gap: the reference's behaviour is undefined there")

@@ -96,7 +96,8 @@ def run_case_cli(k, args, ref_md5, ref_n, rc):
     """The product's side of a case: the CLI on the reference's command line (-P 0: no position listener)."""
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         out = os.path.join(d, "o.bin")
-        r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True)
+        # (--ref-T: the reference's -T as built; the CLI's plain -T shifts TOC / TOE)
+        r = subprocess.run([CLI, "-e", NAV] + args.split() + (["--ref-T"] if k.get("tovr") else []) + ["-P", "0", "-o", out], capture_output=True, text=True)
         if r.returncode != 0:
             if "Invalid start time" in r.stderr:
                 return dict(k=k, args=args, status="skipped", why=r.stderr.strip().splitlines()[-1], ref_n=ref_n, ref_rc=rc)
@@ -130,7 +131,7 @@ def run_case(k):
     if USE_CLI:
         return run_case_cli(k, args, ref_md5, ref_n, rc)
     try:
-        sc = pkg.Scenario(NAV, llh=llh, start=None if k["no_t"] else k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite=k["tovr"])
+        sc = pkg.Scenario(NAV, llh=llh, start=None if k["no_t"] else k["start"], duration_s=k["dur"], iono_enable=k["iono"], time_overwrite="ref" if k["tovr"] else False)
         rows = sc.all()
         gaps = sc.eph_gaps
     except pkg.GalScenError as e:
