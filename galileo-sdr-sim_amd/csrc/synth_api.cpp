@@ -134,6 +134,10 @@ constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = c
 constexpr int kGroupSyms = 64;      // ... symbol masks per channel and epoch (SG_SYMS)
 constexpr int kGroupListMin = 1 << 16;  // ... least capacity of the undecided-group list (a 120 s batch lists ~2000 of 19.5 M groups);
                                         // a plan's list holds 0.5 % of its groups + this
+constexpr int kVerifyRotation = 8;  // k_verify_carr re-walks every eighth leg position per batch (GAL_CFG_VERIFY_ALL: all of them).  Same box,
+                                    // M-SYN12, pipelined step / one handle / k_synth_g beside it (profiles/r05f_verify_ab.log): none 0.974 /
+                                    // 1.230 / 0.842 ms; every leg 1.010 / 1.297 / 0.890; every 4th 0.985 / 1.258 / 0.865; 8th 0.979 / 1.238 /
+                                    // 0.846; 16th 0.976 / 1.234 / 0.845
 constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + stitch (which translates on the spot), one spare --
                                     // no-op launches in front of k_synth when the chain is complete after one, as it normally
                                     // is; a handle whose last batch got by with one enqueues one (gal_synth_finish iterates and
@@ -144,6 +148,7 @@ constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + 
 struct gal_synth {
     gal_synth_cfg_t cfg{};
     int device = 0;
+    int n_cu = 256;  // compute units of the device (MI355X: 256)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // code-chain walk + page resolution run beside the carrier passes
@@ -173,6 +178,9 @@ struct gal_synth {
     bool in_flight = false;  // execute() enqueued, finish() not yet called
     int n_groups = 0;  // channel groups (each <= kKernelMaxChan) -> synth launches per execute
     std::vector<int> group_nch;
+    std::vector<int> group_kind;     // 1: k_synth_g, 0: k_synth (k_synth_g batches: the records that are not fit for it, accumulating)
+    int all_first = 0, all_count = 0;  // k_synth_g batches with records of kind 0: the groups that hold ALL records (list-overflow path)
+    int n_exact_records = 0;         // records of the batch that take the exact-replay launch behind k_synth_g
     uint8_t *d_act = nullptr;  // [groups][E][kActRow]
     int *d_nact = nullptr;     // [groups][E]
     int nact_max = 0;
@@ -279,6 +287,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     if (!h) return fail(GAL_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
     h->device = dev;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     auto bail = [&](int code) {
         gal_synth_destroy(h);
         return code;
@@ -453,17 +462,21 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     int nact_max = 0;
     std::vector<int> cur_prn(S, 0);
     for (int s = 0; s < S; ++s) cur_prn[s] = (state_in && state_in[s].prn > 0) ? state_in[s].prn : 0;
-    // k_synth's resampled-window fast path: at most 4 holds per 16 samples on every channel, thresholds a bin apart
-    bool rw_ok = true;
+    // What every RECORD (channel-epoch) could run on, decided per record since round 5 (rounds 2-4: per batch -- one still
+    // carrier sent all twelve channels to the exact-replay kernel; the reference treats channels independently,
+    // src/galileo-sdr.cpp:487-534):
+    //   rec_mode  the form of the resampled windows its code step takes (rw_mode_of) if its pattern thresholds are more than a bin
+    //             apart from each other (k_synth's fast body needs that), else 0
+    //   rec_g     ... and k_synth_g in that form: thresholds also a bin away from 0 and 1 (its group-start phase is approximate), and
+    //             a carrier step in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries per group (the table's
+    //             extension behind a wrap), and a phase that moves: a carrier that stands still ON an index boundary would have
+    //             every one of its groups listed for the exact replay
+    std::vector<uint8_t> rec_mode((size_t)E * S, 0), rec_g((size_t)E * S, 0);
     double cs2_max = 0.0;  // largest code step of the batch, half chips per sample
-    bool g_ok = true;   // k_synth_g: every carrier step in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries
-                        // per group (the table's extension behind a wrap), and a phase that moves: a carrier that stands still
-                        // ON an index boundary would have every one of its groups listed for the exact replay
-    int rw_mode = 0;  // 1: holds (code step 0.74 .. 1 half chips per sample), 2: <= 2 advances (<= 0.133), 3: <= 4 advances
-                      // (<= 0.266); one form per batch
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); h->rw_e0.assign(S, 0.0); }
     const double delt = 1.0 / h->cfg.sample_rate;
     const bool cboc = (h->cfg.flags & GAL_CFG_CBOC) != 0;
+    const double min_gap = cboc ? kRwMinGapCboc : kRwMinGap;
     for (int e = 0; e < E; ++e) {
         int n = 0;
         for (int s = 0; s < S; ++s) {
@@ -494,28 +507,27 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
-            if (g_ok) {
-                const double ad = std::fabs(r.f_carr * delt);
-                g_ok = ad >= 9.094947017729282e-13 && 511.0 * ad * 16.0 <= 120.0;
-            }
-            if (rw_ok) {
-                const double cs2 = 2.0 * (r.f_code * delt);
-                cs2_max = std::max(cs2_max, cs2);
-                const int mode = rw_mode_of(cs2);
-                rw_ok = mode != 0 && (rw_mode == 0 || rw_mode == mode);
-                rw_mode = mode;
-                // (evaluated for every record: the distance is not a continuous function of the step -- when some u s
+            const double ad = std::fabs(r.f_carr * delt);
+            const bool carr_ok = ad >= 9.094947017729282e-13 && 511.0 * ad * 16.0 <= 120.0;
+            const double cs2 = 2.0 * (r.f_code * delt);
+            cs2_max = std::max(cs2_max, cs2);
+            const int mode = rw_mode_of(cs2);
+            if (mode != 0 && !(cboc && mode != 1)) {  // (CBOC: the half-period parity pattern exists in the hold form only)
+                // (evaluated for every new step: the distance is not a continuous function of the step -- when some u s
                 // crosses an integer its threshold jumps from 0 to 1 -- so a cached value cannot be extrapolated)
-                if (rw_ok && cs2 != h->rw_s0[s]) {
+                if (cs2 != h->rw_s0[s]) {
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
                     h->rw_e0[s] = rw_threshold_edge(cs2);
-                    if (cboc) h->rw_e0[s] = mode == 1 ? std::min(h->rw_e0[s], rw_threshold_edge(6.0 * cs2)) : 0.0;
-                    // CBOC: the half-period parity pattern steps by 6 s per sample; only the hold form (1) exists there
-                    if (cboc) h->rw_g0[s] = mode == 1 ? std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2)) : 0.0;
+                    if (cboc) {  // ... and the pattern of the BOC(6,1) half periods: 6 s per sample
+                        h->rw_e0[s] = std::min(h->rw_e0[s], rw_threshold_edge(6.0 * cs2));
+                        h->rw_g0[s] = std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2));
+                    }
                 }
-                if (rw_ok) rw_ok = h->rw_g0[s] > (cboc ? kRwMinGapCboc : kRwMinGap);
-                if (rw_ok && g_ok) g_ok = h->rw_e0[s] > (cboc ? kRwMinGapCboc : kRwMinGap);
+                if (h->rw_g0[s] > min_gap) {
+                    rec_mode[(size_t)e * S + s] = (uint8_t)mode;
+                    rec_g[(size_t)e * S + s] = (carr_ok && h->rw_e0[s] > min_gap) ? 1 : 0;
+                }
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
             ++n;
@@ -523,6 +535,23 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         nact_all[e] = n;
         if (n > nact_max) nact_max = n;
     }
+    // the batch: k_synth's fast body needs ONE window form on every record (P.rw); k_synth_g takes the records that are fit for it
+    // in the form most of them have, the others go to an accumulating exact-replay launch behind it (classic windows)
+    int rw_mode = 0;
+    bool rw_ok = nact_max > 0;
+    long long g_count[4] = {0, 0, 0, 0}, n_records = 0;
+    for (int e = 0; e < E; ++e)
+        for (int k = 0; k < nact_all[e]; ++k) {
+            const size_t i = (size_t)e * S + act_all[(size_t)e * S + k];
+            ++n_records;
+            if (rec_mode[i] == 0 || (rw_mode != 0 && rec_mode[i] != rw_mode)) rw_ok = false;
+            if (rw_mode == 0) rw_mode = rec_mode[i];
+            if (rec_g[i]) g_count[rec_mode[i]] += 1;
+        }
+    int g_mode = 1;
+    for (int m = 2; m <= 3; ++m)
+        if (g_count[m] > g_count[g_mode]) g_mode = m;
+    const long long n_grec = g_count[g_mode];
     if (state_in) {
         for (int s = 0; s < S; ++s)
             if (state_in[s].prn > 0 && !(std::fabs(state_in[s].carr_phase) < 1.0))
@@ -537,7 +566,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     // Doppler with the phase on the 1 / 1300 lattice of 2 x 1.023 / 2.6, a synthetic input -- lists a percent of its groups, and
     // k_repair_g then costs more than the exact-replay kernel; the next 8 batches of the handle take that one)
     if (h->g_holdoff > 0) h->g_holdoff -= 1;
-    bool fam_g = rw_ok && rw_mode >= 1 && rw_mode <= (cboc ? 1 : 3) && g_ok && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
+    // (the majority of the records must be fit for it: every exact launch behind it reads and writes the whole output once more)
+    bool fam_g = n_grec > 0 && 2 * n_grec >= n_records && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
                  nact_max > 0 && h->g_holdoff == 0 &&
                  (double)N * cs2_max / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
                  (double)E * (double)((N + kGroupChunk - 1) / kGroupChunk) * 64.0 < 4294967296.0;
@@ -606,27 +636,62 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const int W = (nchunks + Lc - 1) / Lc;
     const size_t LEGS = (size_t)E * W;
 
-    // ---- channel groups (one synth launch each; later groups accumulate onto the first)
-    const int n_groups = nact_max == 0 ? 1 : (nact_max + kKernelMaxChan - 1) / kKernelMaxChan;
-    h->n_groups = n_groups;
-    h->group_nch.assign(n_groups, 0);
-    // per channel group: one 16-byte row per epoch (<= kKernelMaxChan positions, zero-padded; k_synth reads it as one word quad)
-    std::vector<uint8_t> act_g((size_t)n_groups * E * kActRow, 0);
-    std::vector<int> nact_g((size_t)n_groups * E, 0);
-    for (int e = 0; e < E; ++e) {
-        const int n = nact_all[e];
-        // split evenly so every launch replays about the same number of channels
-        const int per = (n + n_groups - 1) / n_groups;
-        int k = 0;
-        for (int g = 0; g < n_groups; ++g) {
-            int m = n - k < per ? n - k : per;
-            if (m < 0) m = 0;
-            for (int j = 0; j < m; ++j) act_g[((size_t)g * E + e) * kActRow + j] = act_all[(size_t)e * S + k + j];
-            nact_g[(size_t)g * E + e] = m;
-            if (m > h->group_nch[g]) h->group_nch[g] = m;
-            k += m;
+    // ---- channel groups (one synth launch each; later groups accumulate onto the first).  Per group: one 16-byte row per epoch
+    // (<= kKernelMaxChan positions, zero-padded; the kernels read it as one word quad).  k_synth_g batches: first the groups of the
+    // records that are fit for it (kind 1), then -- if the batch has any -- the groups of the others (kind 0: k_synth on classic
+    // windows, accumulating), then ONCE MORE all records in groups of kind 0: what gal_synth_finish's list-overflow path launches.
+    std::vector<int> grp_nch, grp_kind;
+    std::vector<uint8_t> act_g;
+    std::vector<int> nact_g;
+    auto add_groups = [&](const int kind, auto &&take_record) {
+        // positions of every epoch that take_record() accepts, split evenly over the launches
+        std::vector<uint8_t> pos((size_t)E * S, 0);
+        std::vector<int> cnt(E, 0);
+        int most = 0;
+        for (int e = 0; e < E; ++e) {
+            for (int k = 0; k < nact_all[e]; ++k) {
+                const uint8_t s = act_all[(size_t)e * S + k];
+                if (take_record((size_t)e * S + s)) pos[(size_t)e * S + cnt[e]++] = s;
+            }
+            most = std::max(most, cnt[e]);
         }
+        const int ng = most == 0 ? (kind == 1 || grp_nch.empty() ? 1 : 0) : (most + kKernelMaxChan - 1) / kKernelMaxChan;
+        const size_t g0 = grp_nch.size();
+        grp_nch.resize(g0 + ng, 0);
+        grp_kind.resize(g0 + ng, kind);
+        act_g.resize((g0 + ng) * (size_t)E * kActRow, 0);
+        nact_g.resize((g0 + ng) * (size_t)E, 0);
+        for (int e = 0; e < E && ng > 0; ++e) {
+            const int n = cnt[e];
+            const int per = (n + ng - 1) / ng;  // about the same number of channels in every launch
+            int k = 0;
+            for (int g = 0; g < ng; ++g) {
+                int m = n - k < per ? n - k : per;
+                if (m < 0) m = 0;
+                for (int j = 0; j < m; ++j) act_g[((g0 + g) * (size_t)E + e) * kActRow + j] = pos[(size_t)e * S + k + j];
+                nact_g[(g0 + g) * (size_t)E + e] = m;
+                grp_nch[g0 + g] = std::max(grp_nch[g0 + g], m);
+                k += m;
+            }
+        }
+        return ng;
+    };
+    int n_exact_records = 0;
+    if (fam_g) {
+        h->n_groups = add_groups(1, [&](size_t i) { return rec_g[i] && rec_mode[i] == g_mode; });
+        h->n_groups += add_groups(0, [&](size_t i) { return !(rec_g[i] && rec_mode[i] == g_mode); });
+        n_exact_records = (int)(n_records - n_grec);
+        h->all_first = h->n_groups;
+        h->all_count = n_exact_records ? add_groups(0, [](size_t) { return true; }) : 0;  // (no exact records: the kind-1 groups ARE all)
+    } else {
+        h->n_groups = add_groups(0, [](size_t) { return true; });
+        h->all_first = 0;
+        h->all_count = 0;
     }
+    h->group_nch = grp_nch;
+    h->group_kind = grp_kind;
+    h->n_exact_records = n_exact_records;
+    const int n_groups = (int)grp_nch.size();  // (rows in the upload, not launches per execute)
 
     // ---- arena layout
     const size_t ES = (size_t)E * S;
@@ -652,7 +717,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_pguess = take(ES * 8);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmr = take(LEGS * S * 8);
-    const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S);
+    const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S), o_risk = take(LEGS * S);
     const size_t zero_end = off;
     const size_t o_clmw = take(LEGS * S * 8);  // "no claim" = -1
     const size_t o_state_out = take(sizeof(gal_chan_state_t) * S);
@@ -720,7 +785,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.anc_w = (long long *)(base + o_ancw); P.anc_r = (double *)(base + o_ancr);
     P.clm_w = (long long *)(base + o_clmw); P.clm_r = (double *)(base + o_clmr);
     P.pend = (double *)(base + o_pend);
-    P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty);
+    P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty); P.risk = (uint8_t *)(base + o_risk);
+    P.ver_mod = 1; P.ver_rem = 0;
     P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
     P.scanm = multi_scan ? (void *)(base + o_scanm) : nullptr;
@@ -741,27 +807,24 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     if (const char *env = getenv("GAL_G_LIST_CAP")) P.gflist_cap = std::max(1, std::min((int)g_cap, atoi(env)));  // overflow path
 #endif
     {
-        // k_synth_g: a block takes an epoch's chunks (or 1 / bpe of them), its waves one chunk at a time
-        // measured (M-SYN12, kernel alone): 512 threads x 1 / 2 / 4 blocks per epoch 0.908 / 0.943 / 0.938 ms, 1024 threads x 1 / 2
-        // 1.055 / 1.107 -- blocks do not run in rounds (the last ones run on a half-empty device, faster), so the cut only has to
-        // give every CU its two blocks: the smallest power of two with E x bpe >= 512, as long as every wave still gets a chunk
-        // -- and, where an epoch is long enough that a block's tables are cheap beside its samples (16 chunks per wave and more:
-        // BASELINE config 4's 2442-chunk epochs, not the reference's 254), on until the batch is 4096 blocks: 600 such epochs as
-        // 600 blocks ran as one full round and a second one of 88 (5.7 ms per launch; cut in 8: see DESIGN.md 5.1)
-        int best_thr = 512, best_bpe = 1;
-        while (E * best_bpe < 512 && best_bpe * 2 * (best_thr / 64) <= nchunks) best_bpe *= 2;
-        while (E * best_bpe < 4096 && nchunks / (best_bpe * 2 * (best_thr / 64)) >= 16) best_bpe *= 2;
-        P.gthreads = best_thr;
-        P.gbpe = best_bpe;
+        // k_synth_g: every block takes a contiguous run of the launch's chunks, cut on epoch boundaries (synth_group.hip: sg_grid)
+        P.gthreads = 512;
+        P.gbpe = 0;
+        P.gslots = 2 * h->n_cu;
+        P.grounds = 0;
 #ifdef GAL_TEST_HOOKS
         if (const char *env = getenv("GAL_G_THREADS")) P.gthreads = atoi(env);
-        if (const char *env = getenv("GAL_G_BPE")) P.gbpe = atoi(env) > 0 ? atoi(env) : P.gbpe;
+        if (const char *env = getenv("GAL_G_BPE")) P.gbpe = atoi(env) > 0 ? atoi(env) : 0;
+        if (const char *env = getenv("GAL_G_ROUNDS")) P.grounds = atoi(env) > 0 ? atoi(env) : P.grounds;
+        if (const char *env = getenv("GAL_G_SLOTS")) P.gslots = atoi(env) > 0 ? atoi(env) : P.gslots;
 #endif
     }
 
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
-    P.rw = rw_ok ? rw_mode : 0;  // (CBOC: form 1 only -- the gate above leaves rw_ok false for the others)
+    // k_synth_g: the form its records have; k_synth alone: its fast body if EVERY record has the same form (CBOC: form 1 only --
+    // rec_mode is 0 for the others), else classic windows
+    P.rw = fam_g ? g_mode : (rw_ok ? rw_mode : 0);
 #ifdef GAL_TEST_HOOKS
     // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)
@@ -830,17 +893,31 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 // on the walker stream instead, beside the synthesis (gal_synth_execute_range)
 static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
 {
-    if (verify_here && h->P.fam == 1 && h->nact_max != 0) galk_launch_verify_carr(&h->Pw, h->stream);
+    if (verify_here && h->P.fam == 1 && h->nact_max != 0) {
+        // (in front of the synthesis on its own stream: gal_synth_finish's repair paths and handles without a walker stream --
+        // nothing to hide it behind, and the repair paths have reason to look at every leg)
+        DevPlan Pv = h->Pw;
+        if (h->stats.synth_runs > 1) Pv.ver_mod = 1, Pv.ver_rem = 0;
+        galk_launch_verify_carr(&Pv, h->stream);
+    }
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
         HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
         return GAL_OK;
     }
-    for (int g = 0; g < h->n_groups; ++g) {
+    // k_synth_g batches: its groups, then the accumulating exact-replay groups of the records it cannot take (classic windows); after
+    // a list overflow (P.fam set to 0 by gal_synth_finish) and in k_synth batches: every record on k_synth
+    const bool overflow_set = h->P.fam == 0 && h->all_count > 0;
+    const int g_first = overflow_set ? h->all_first : 0, g_count = overflow_set ? h->all_count : h->n_groups;
+    DevPlan Px = h->P;  // what an exact-replay launch of a k_synth_g batch sees
+    if (h->P.fam == 1 || overflow_set) Px.rw = 0;
+    for (int k = 0; k < g_count; ++k) {
+        const int g = g_first + k;
         const uint8_t *act = h->d_act + (size_t)g * h->P.E * kActRow;
         const int *nact = h->d_nact + (size_t)g * h->P.E;
-        const int rc = h->P.fam == 1
-                           ? galk_launch_synth_g(&h->P, h->d_plan, h->group_nch[g], g > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream)
-                           : galk_launch_synth(&h->P, h->d_plan, h->group_nch[g], g > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream);
+        const bool on_g = h->P.fam == 1 && h->group_kind[g] == 1;
+        const int rc = on_g ? galk_launch_synth_g(&h->P, h->d_plan, h->group_nch[g], k > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream)
+                            : galk_launch_synth(h->P.fam == 1 || overflow_set ? &Px : &h->P, h->d_plan, h->group_nch[g], k > 0, act, nact, iq,
+                                                h->range_e0, h->range_ne, h->stream);
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
     }
     // the groups k_synth_g could not decide (chip pattern or table index within the rounding drift of a boundary), exactly
@@ -888,6 +965,13 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->Pw.tr_e0 = first_epoch;
     h->Pw.tr_e1 = first_epoch + n_epochs;
     h->Pw.cp_e0 = first_epoch;
+    // k_verify_carr (k_synth_g batches): an eighth of the leg positions per batch, rotating with the handle's batch count, plus the
+    // legs whose translation was not overwhelmingly inside its margin; GAL_CFG_VERIFY_ALL: every leg (synth_kernels.hip)
+    h->Pw.ver_mod = (h->cfg.flags & GAL_CFG_VERIFY_ALL) ? 1 : kVerifyRotation;
+#ifdef GAL_TEST_HOOKS
+    if (const char *env = getenv("GAL_VERIFY_MOD")) h->Pw.ver_mod = atoi(env) > 0 ? atoi(env) : h->Pw.ver_mod;  // timing experiments
+#endif
+    h->Pw.ver_rem = (int)((h->seq + 1u) % (uint32_t)h->Pw.ver_mod);
     hipStream_t st = handle_stream(h);
     if (!st) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
     const DevPlan *P = &h->Pw;
@@ -1129,6 +1213,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
     }
     h->stats.kernel_family = h->P.fam;
     h->stats.repaired_groups = h->P.fam == 1 ? ctr_end[CTR_GFLAGS] : 0;
+    h->stats.exact_records = h->P.fam == 1 ? h->n_exact_records : 0;
     if (h->P.fam == 1 && (double)ctr_end[CTR_GFLAGS] > 0.004 * (double)h->range_ne * (double)((h->P.N + 15) / 16) + 4096.0)
         h->g_holdoff = 9;  // (this batch is exact like any other; the handle's next 8 go to the exact-replay kernel)
     h->stats.walk_passes = ctr_end[CTR_PASSES];

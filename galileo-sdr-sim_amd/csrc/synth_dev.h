@@ -62,6 +62,9 @@ struct DevPlan {
     int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
     long long *tpos;     // global sample index right after that tie step
     double *shift;       // pending translation (new anchor residual - walked anchor residual)
+    uint8_t *risk;       // 1: the leg was accepted by a translation that used more than 1/256 of its binade margin: k_verify_carr
+                         // re-walks such a leg in every batch, whatever the rotation says
+    int ver_mod, ver_rem;  // k_verify_carr re-walks the legs i = ver_rem (mod ver_mod) of the executed epochs (1, 0: every leg)
     void *scanm;         // scratch of the multi-block stitch (long batches), null: single-block k_carr_scan
     int translate;       // 1 normal; 0: always re-walk (the all-walked fallback); 2: GAL_TEST_HOOKS builds only
     int tr_e0, tr_e1;    // legs of epochs outside [tr_e0, tr_e1) are never translated (gal_synth_execute_range)
@@ -82,8 +85,10 @@ struct DevPlan {
                           // 2 / 3 every code step has 2 f_code / fs <= 0.133 / 0.266 (<= 2 / 4 advances), 0 classic per-sample window index
     int fam;              // synthesis kernel family: 0 k_synth (one chunk per lane, exact replay), 1 k_synth_g (one 16-sample group per
                           // lane from the chunk's checkpoint in closed form + k_repair_g for the undecided groups; synth_group.hip)
-    int gbpe;             // k_synth_g: blocks per epoch
-    int gthreads;         // k_synth_g: threads per block (512 or 1024)
+    int gbpe;             // k_synth_g: 0 (product): contiguous chunk ranges, see gslots / grounds; > 0 (GAL_TEST_HOOKS): blocks per epoch
+    int gthreads;         // k_synth_g: threads per block (512)
+    int gslots;           // k_synth_g: blocks the device holds at a time (2 per CU)
+    int grounds;          // k_synth_g: a big launch is gslots x grounds blocks
     uint32_t *gflist;     // k_synth_g -> k_repair_g: the undecided groups, (epoch in range * nchunks + chunk) * 64 + group
     int gflist_cap;
     const uint32_t *str;  // [50][512] half-chip streams: bit 2h = E1B^E1C chip, bit 2h+1 = E1C chip ^ (h & 1)
@@ -95,6 +100,7 @@ struct SynGeom {
     int S, N, R, nchunks, CP1, blocks_per_epoch;
     int cls, per;  // lane order: position L of the epoch replays chunk (L % per) * cls + L / per, per = nchunks / cls
     int e0;  // first epoch of the executed range (the output buffer starts there)
+    int ne;  // epochs of the launch (k_synth_g: its blocks cut ne x nchunks chunks among themselves)
 };
 
 #endif

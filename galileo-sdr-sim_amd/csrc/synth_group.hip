@@ -287,14 +287,29 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     __shared__ uint32_t s_sya[(SG_THREADS / 64) * 2 * SG_MAXCH];  // ... LDS byte address of the sign mask of the chunk's first symbol
     __shared__ int s_rwbad;
 
-    const int bpe = G.blocks_per_epoch;
-    const int er = blockIdx.x / bpe;  // epoch relative to the executed range
-    const int tg = blockIdx.x - er * bpe;
-    const int e = G.e0 + er;
+    // (s_setprio 1 / 2 here, to keep the verification kernel that runs beside this one out of its issue slots: the kernel ALONE gets
+    // slower, 0.895 -> 0.960 ms, profiles/r05d_prio_ab.log)
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-
-    // ---- phase 0 (scalar): plan pointers, the epoch's active list, slot indices
+    // ---- the block's share of the launch: a CONTIGUOUS range of its chunks in (epoch, chunk) order, cut evenly (round 5; rounds
+    // 1-4: one block per epoch -- 1199 blocks on 512 resident slots, the third round a third full).  A range that crosses an epoch
+    // boundary is worked off segment by segment: the block rebuilds its per-epoch tables in between.  Consecutive ranges go to the
+    // same XCD (hardware: block b -> XCD b % 8): they share an epoch's checkpoints in that XCD's L2
+    // (product launches: ne x bpe blocks, block boundaries on epoch boundaries -- 32-bit arithmetic; the 64-bit form serves the
+    // GAL_TEST_HOOKS layouts that ignore them)
+    const int nb = (int)gridDim.x;
+    long long uq, u_end;
+    if (G.blocks_per_epoch > 0) {
+        const int bpe = G.blocks_per_epoch;
+        const int erb = (int)blockIdx.x / bpe, tg = (int)blockIdx.x - erb * bpe;
+        uq = (long long)erb * G.nchunks + G.nchunks * tg / bpe;
+        u_end = (long long)erb * G.nchunks + G.nchunks * (tg + 1) / bpe;
+    } else {
+        const int xb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        const long long U = (long long)G.ne * G.nchunks;
+        uq = U * xb / nb;
+        u_end = U * (xb + 1) / nb;
+    }
     const int *const p_lut = Pd->lut;
     const int *const p_prn = Pd->prn;
     const int *const p_ib0 = Pd->ib0;
@@ -305,33 +320,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     const uint32_t *const p_pcur = Pd->page_cur, *const p_pnext = Pd->page_next;
     const uint32_t cs25 = Pd->cs25;
     int *const p_ctr = Pd->ctr;
-    const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
-    const uint4 aw = *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW);
-    const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};
-    int ixs[SG_MAXCH];
-#pragma unroll
-    for (int j = 0; j < SG_MAXCH; ++j) {
-        // slot index e * S + act[j] of position j (idle positions alias slot act[0]: loads stay in bounds, results unused)
-        ixs[j] = __builtin_amdgcn_readfirstlane(e * G.S + (int)((awv[j >> 2] >> (8 * (j & 3))) & 0xffu));
-    }
-
-    // ---- phase 1: the epoch's tables in LDS
-    if (tid == 0) s_rwbad = 0;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        int prn = p_prn[ixs[j]];
-        prn = prn < 1 ? 1 : prn;  // idle position: any valid row, zeroed below
-        const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
-        const bool on = j < nact;
-        // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window at or
-        // across the code wrap is one contiguous read: a plain copy of words 0 .. 510, then the 69 spliced ones
-        for (int t = tid; t < STR_WORDS - 1; t += nthr) s_str[j * SG_STR_PITCH + t] = on ? src[t] : 0u;
-        if (tid < SG_STR_PITCH - (STR_WORDS - 1)) {
-            const int t = tid;  // row word 511 + t
-            const uint32_t w = t == 0 ? ((src[STR_WORDS - 1] & 0xffffu) | (src[0] << 16)) : ((src[t - 1] >> 16) | (src[t] << 16));
-            s_str[j * SG_STR_PITCH + STR_WORDS - 1 + t] = on ? w : 0u;
-        }
-    }
+    // ---- tables that do not depend on the epoch
     for (int i = tid; i < 16 * SG_MPOS; i += nthr) {
         const int pair = i / SG_MPOS, pos = i - pair * SG_MPOS;
         const uint32_t mc = (uint32_t)(pair >> 2) * 0x55555555u, mn = (uint32_t)(pair & 3) * 0x55555555u;
@@ -355,6 +344,50 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         k = k >= 511 ? k - 511 : k;
         k = k >= 511 ? k - 511 : k;
         s_lut[i] = p_lut[(tab ? -k : k) & 511];
+    }
+    int row_prn[NCH];  // PRN whose stream row position j holds (0: none yet, -1: the all-zero row of an idle position)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) row_prn[j] = 0;
+    bool first_seg = true;
+    while (uq < u_end) {
+    const int er = G.blocks_per_epoch > 0 ? (int)blockIdx.x / G.blocks_per_epoch : (int)(uq / G.nchunks);  // epoch relative to the executed range
+    const int c_begin = (int)(uq - (long long)er * G.nchunks);
+    const int c_end = (long long)(G.nchunks - c_begin) < u_end - uq ? G.nchunks : c_begin + (int)(u_end - uq);
+    uq += c_end - c_begin;
+    const int e = G.e0 + er;
+    if (!first_seg) __syncthreads();  // every wave is through with the tables of the segment before
+    first_seg = false;
+
+    // ---- phase 0 (scalar): the epoch's active list, slot indices
+    const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
+    const uint4 aw = *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW);
+    const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};
+    int ixs[SG_MAXCH];
+#pragma unroll
+    for (int j = 0; j < SG_MAXCH; ++j) {
+        // slot index e * S + act[j] of position j (idle positions alias slot act[0]: loads stay in bounds, results unused)
+        ixs[j] = __builtin_amdgcn_readfirstlane(e * G.S + (int)((awv[j >> 2] >> (8 * (j & 3))) & 0xffu));
+    }
+
+    // ---- phase 1: the epoch's tables in LDS
+    if (tid == 0) s_rwbad = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        int prn = __builtin_amdgcn_readfirstlane(p_prn[ixs[j]]);
+        prn = prn < 1 ? 1 : prn;  // idle position: any valid row, zeroed below
+        const bool on = j < nact;
+        const int want = on ? prn : -1;
+        if (want == row_prn[j]) continue;  // the row of the segment before (same satellite in this position) stays
+        row_prn[j] = want;
+        const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
+        // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window at or
+        // across the code wrap is one contiguous read: a plain copy of words 0 .. 510, then the 69 spliced ones
+        for (int t = tid; t < STR_WORDS - 1; t += nthr) s_str[j * SG_STR_PITCH + t] = on ? src[t] : 0u;
+        if (tid < SG_STR_PITCH - (STR_WORDS - 1)) {
+            const int t = tid;  // row word 511 + t
+            const uint32_t w = t == 0 ? ((src[STR_WORDS - 1] & 0xffffu) | (src[0] << 16)) : ((src[t - 1] >> 16) | (src[t] << 16));
+            s_str[j * SG_STR_PITCH + STR_WORDS - 1 + t] = on ? w : 0u;
+        }
     }
     // symbol sign pairs: entry k = sg = (data ^ secondary) | secondary << 1 of the k-th symbol after the one in force at the
     // epoch start (the XOR mask of a symbol on its half chips is sg x 0x55555555); data symbol = page bit, secondary =
@@ -500,7 +533,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     __syncthreads();
     const bool rw_off = __builtin_amdgcn_readfirstlane(s_rwbad) != 0;
 
-    // ---- the block's chunks: wave w of the block takes chunks tg * nw + w, + bpe * nw, ...
+    // ---- the segment's chunks: wave w of the block takes chunks c_begin + w, + nw, ...
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int nw = nthr >> 6;
@@ -521,8 +554,8 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     const uint32_t mtab0 = (uint32_t)(uintptr_t)(sg_lds_u32)s_mtab;
     SgRec *const recw = s_rec + wv * 2 * SG_MAXCH;
     uint32_t *const syaw = s_sya + wv * 2 * SG_MAXCH;
-    const int cstep_w = bpe * nw;
-    int c = __builtin_amdgcn_readfirstlane(tg * nw + wv);
+    const int cstep_w = nw;
+    int c = __builtin_amdgcn_readfirstlane(c_begin + wv);
     // checkpoint of chunk cc: x (pre-check code phase, chips), p (carrier phase), ibit | flipped << 16
     double lx = 0.0, lp = 0.0;
     uint32_t lib = 0u;
@@ -533,7 +566,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     const sg_gbl_f64 g_cpx = (sg_gbl_f64)(uintptr_t)p_cpx + cpl, g_cpp = (sg_gbl_f64)(uintptr_t)p_cpp + cpl;
     const sg_gbl_u32 g_cpi = (sg_gbl_u32)(uintptr_t)p_cpi + cpl;
     auto fetch = [&](const int cc) {
-        const int ce = cc < G.nchunks ? cc : G.nchunks - 1;
+        const int ce = cc < c_end ? cc : c_end - 1;
         lx = g_cpx[ce];
         lp = g_cpp[ce];
         lib = g_cpi[ce];
@@ -557,9 +590,9 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
             syaw[buf * SG_MAXCH + lane] = mtab0 + pair * (SG_MPOS * 4u);
         }
     };
-    fetch(c);
+    if (c < c_end) fetch(c);
     int buf = 0;
-    for (; c < G.nchunks; c += cstep_w, buf ^= 1) {
+    for (; c < c_end; c += cstep_w, buf ^= 1) {
         stage(buf);
         fetch(c + cstep_w);  // in flight while this chunk is synthesised
         const int n0 = c * SG_CHUNK;
@@ -619,6 +652,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         }
         }
     }
+    }  // segments
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -661,6 +695,22 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
             const CodeEnd ce = code_walk(P.cp_x[cp], (int)(cib & 0xffffu), cst, 1.0 / cst, 16 * g, 1 << 30, [](int, double, int, int) {});
             double x = ce.x;
             double p = carr_walk_track(P.cp_p[cp], d, 1.0 / __builtin_fabs(d), 16 * g, 16 * g + 1, 16 * g + 1, [](int, double) {}).p;
+            {
+                // ... and both chains walked on to the END of the chunk: they must arrive at the next checkpoint, bit for bit (the
+                // end-of-epoch state behind the last chunk).  The listed groups are scattered over the batch by the bits of the
+                // phases, so this is a random sample of ~20 000 (chunk, channel) pairs per 120 s batch -- the only check the CODE
+                // checkpoints get on this kernel family (k_synth's replay checks every one), and one more on the carrier's beside
+                // k_verify_carr's rotation.  A mismatch ends the batch in gal_synth_finish's repair path.
+                int nR = G.N - c * G.R;
+                nR = nR > G.R ? G.R : nR;
+                const int rem = nR - 16 * g;
+                const CodeEnd ce2 = code_walk(ce.x, ce.ibit, cst, 1.0 / cst, rem, 1 << 30, [](int, double, int, int) {});
+                const uint32_t fl_end = (cib >> 16) | (uint32_t)ce.flipped | (uint32_t)ce2.flipped;
+                const double p2 = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), rem, rem + 1, rem + 1, [](int, double) {}).p;
+                const bool bad = d2u(ce2.x) != d2u(P.cp_x[cp + 1]) || ((uint32_t)ce2.ibit | (fl_end << 16)) != P.cp_ib[cp + 1] ||
+                                 d2u(p2) != d2u(P.cp_p[cp + 1]);
+                if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], 1);
+            }
             // Everything the 16 samples read from memory, fetched in one go (a load per sample and table would make this a
             // chain of ~50 dependent memory round trips): the symbol in force and its successor (:497-506: at most one code wrap
             // inside 16 samples), the two stream words the half chips in front of the wrap can fall into and the two behind it
@@ -741,14 +791,49 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Blocks of a launch over `ne` epochs: every block takes a contiguous, equally long run of the launch's chunks (k_synth_g), cut so
+// that block boundaries fall on epoch boundaries: ne x bpe blocks.  One block per epoch where that fills the device (M-SYN12: 1199
+// blocks on 512 resident slots -- 2 blocks of 512 threads per CU: 61 KB of LDS, 128 VGPRs); a batch of fewer epochs is cut into the
+// smallest bpe with ne x bpe >= slots that leaves every wave two chunks; epochs long enough that a block's tables are cheap beside
+// its samples (16 chunks per wave and more: BASELINE config 4's 2442-chunk epochs) on until the launch is 4096 blocks.
+// Measured and NOT taken (round 5; profiles/r05b_rounds_ab.log, same box, M-SYN12, kernel alone / pipelined step):
+// a PERSISTENT grid of balanced ranges that ignore the epoch boundaries -- 512 blocks (one round of the slots) 0.939 / 1.103 ms,
+// 1024 blocks 0.909 / 1.064, 1536 0.932 / 1.065, 2048 0.969 / 1.09, 3072 0.98 / 1.158 -- against one block per epoch 0.894 / 1.025:
+// the partly empty third round costs less than it looks (the blocks left run on emptier SIMDs, faster), a block that crosses an
+// epoch boundary pays a barrier and a second set of tables, and 512 blocks that live as long as the launch leave the next batch's
+// walker kernels no SIMD to start on.  (GAL_TEST_HOOKS: GAL_G_ROUNDS / GAL_G_BPE select those layouts.)
+static int sg_grid(const DevPlan *P, int ne)
+{
+    const long long U = (long long)ne * P->nchunks;
+    const int slots = P->gslots > 0 ? P->gslots : 512;
+    if (P->grounds > 0 && U >= (long long)slots * P->grounds * 32) return slots * P->grounds;  // (hooks: balanced persistent ranges)
+    int bpe = P->gbpe > 0 ? P->gbpe : 1;                                                        // (hooks: fixed blocks per epoch)
+    if (P->gbpe <= 0) {
+        const int nw = 8;  // waves per block
+        bpe = (slots + ne - 1) / ne;
+        const int most = P->nchunks / (2 * nw) > 1 ? P->nchunks / (2 * nw) : 1;
+        bpe = bpe > most ? most : bpe;
+        while ((long long)ne * bpe < 4096 && P->nchunks / (bpe * 2 * nw) >= 16) bpe *= 2;
+    }
+    return ne * bpe;
+}
+// ... and the blocks per epoch of that grid (0: a hooks layout that ignores the epoch boundaries)
+static int sg_bpe(const DevPlan *P, int ne)
+{
+    const long long U = (long long)ne * P->nchunks;
+    const int slots = P->gslots > 0 ? P->gslots : 512;
+    if (P->grounds > 0 && U >= (long long)slots * P->grounds * 32) return 0;
+    return sg_grid(P, ne) / ne;
+}
+
 template <bool ACC, int MODE, int SIG>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
 #ifdef SG_FORCE_THREADS  // A/B builds (tools/build_variant_g.sh)
-    const dim3 grid(ne * G.blocks_per_epoch), block(SG_FORCE_THREADS);
+    const dim3 grid(sg_grid(P, ne)), block(SG_FORCE_THREADS);
 #else
-    const dim3 grid(ne * G.blocks_per_epoch), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
+    const dim3 grid(sg_grid(P, ne)), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
 #endif
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
     if constexpr (SIG == 1) {
@@ -769,12 +854,13 @@ static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const 
     return 0;
 }
 
-static SynGeom sg_geom(const DevPlan *P, int e0)
+static SynGeom sg_geom(const DevPlan *P, int e0, int ne)
 {
     SynGeom G;
     G.e0 = e0;
+    G.ne = ne;
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1;
-    G.blocks_per_epoch = P->gbpe > 0 ? P->gbpe : 1;
+    G.blocks_per_epoch = ne > 0 ? sg_bpe(P, ne) : 1;
     G.cls = 1;
     G.per = P->nchunks;
     return G;
@@ -787,7 +873,7 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
                                    uint32_t *iq, int e0, int ne, hipStream_t st)
 {
     if (P->R != SG_CHUNK) return -2;
-    const SynGeom G = sg_geom(P, e0);
+    const SynGeom G = sg_geom(P, e0, ne);
     if (P->signal == 1) {
         if (P->rw != 1) return -3;
         return accumulate ? launch_synth_g_t<true, 1, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G)
@@ -805,7 +891,7 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
 // behind the last synthesis launch of the batch, same stream
 extern "C" void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hipStream_t st)
 {
-    const SynGeom G = sg_geom(P, e0);
+    const SynGeom G = sg_geom(P, e0, 0);
     // (512 blocks x 16 rows: a batch of the reference geometry lists ~2000 groups, one of BASELINE config 4's ~16 000 per 600 epochs;
     // blocks without a group leave at once)
     hipLaunchKernelGGL(k_repair_g, dim3(512), dim3(256), 0, st, *P, G, iq, P->gflist, P->gflist_cap);

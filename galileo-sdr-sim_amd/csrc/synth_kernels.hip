@@ -285,6 +285,7 @@ __device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, con
         }
     }
     if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
+    if (__builtin_fabs(dl) * 256.0 > P.marg[li]) P.risk[li] = 1;  // not overwhelmingly inside the margin: verified in every batch
     P.pend[li] += dl2;
     if (P.clm_w[li] >= 0) P.clm_r[li] += (P.clm_w[li] >= tp) ? dl2 : dl;
     P.marg[li] -= __builtin_fabs(dl) + 2.220446049250313e-16;
@@ -383,22 +384,49 @@ __global__ void k_walk_carr(DevPlan P, int first)
     P.tdir[li] = (int8_t)tdir;
     P.tpos[li] = tpos;
     P.dirty[li] = 0;
+    P.risk[li] = 0;  // walked, not translated
     const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
 }
 
-// k_verify_carr: every leg of the executed epochs walked once more, genuinely and in closed form, from its own first
-// checkpoint: each checkpoint of the leg and the state it hands to the next leg must come out bit for bit (CTR_MISMATCH
-// otherwise, which sends gal_synth_finish into the all-walked fallback).  This is what k_synth's exact replay establishes on
-// its way; k_synth_g (synth_group.hip) never forms the exact phase, so batches that run it get this kernel on the walker
-// stream, beside the synthesis.  Same lane order as k_walk_carr (a wave = 64 legs of one slot).
+// k_verify_carr: legs of the executed epochs walked once more, genuinely and in closed form, from their own first checkpoint:
+// each checkpoint of the leg and the state it hands to the next leg must come out bit for bit (CTR_MISMATCH otherwise, which sends
+// gal_synth_finish into the all-walked fallback).  This is what k_synth's exact replay establishes on its way; k_synth_g
+// (synth_group.hip) never forms the exact phase, so batches that run it get this kernel on the walker stream, beside the synthesis.
+// WHICH legs (round 5): nearly every leg is accepted by TRANSLATION (a proof, with the leg's binade margin as
+// its hypothesis), and re-walking all of them in every batch cost a single handle 5.5 % of its step and the pipelined step 3.7 %
+// (k_synth_g 0.05 ms slower beside it, 25 M instructions; profiles/r05f_verify_ab.log).  Now: (a) the legs i = ver_rem (mod
+// ver_mod) -- an eighth per batch, rotating with the handle's batch count, so every leg position is re-walked every eighth batch
+// (at 8 legs per epoch: one leg of every epoch per batch); (b) in EVERY batch the legs whose translation used
+// more than 1/256 of their margin (P.risk; typical: 2^-26 of it); (c) GAL_CFG_VERIFY_ALL: every leg, as before.  Beside it,
+// k_repair_g walks ~20 000 randomly placed chunks of BOTH chains to their ends (code and carrier) and compares them with the next
+// checkpoint.  First nsel threads: the rotation's legs (compact: a wave = 64 selected legs of one slot); the threads behind them:
+// one per leg, for (b).
 __global__ void k_verify_carr(DevPlan P)
 {
     if (P.ctr[CTR_UNVERIFIED] != 0) return;  // chain not complete: gal_synth_finish iterates and launches this again
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.LEGS * P.S) return;
-    const int s = t / P.LEGS;
-    const int i = t - s * P.LEGS;
+    const int mod = P.ver_mod > 1 ? P.ver_mod : 1;
+    const int per_slot = (P.LEGS + mod - 1) / mod;
+    const int nsel = per_slot * P.S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int s, i;
+    if (t < nsel) {
+        s = t / per_slot;
+        i = (t - s * per_slot) * mod + P.ver_rem;
+        if (i >= P.LEGS) return;
+    } else {
+        // (b): eight legs' flags per thread; a set one is next to never seen (the thread then re-walks its first: a batch in
+        // which several of eight neighbours are risky is not a case the rotation is for -- GAL_CFG_VERIFY_ALL)
+        t -= nsel;
+        const int total = P.LEGS * P.S;
+        if (mod == 1 || t * 8 >= total) return;
+        int hit = -1;
+        for (int q = 0; q < 8 && t * 8 + q < total; ++q)
+            if (hit < 0 && P.risk[(size_t)t * 8 + q] && (t * 8 + q) % P.LEGS % mod != P.ver_rem) hit = t * 8 + q;
+        if (hit < 0) return;
+        s = hit / P.LEGS;
+        i = hit - s * P.LEGS;
+    }
     const int e = i / P.W, w = i - e * P.W;
     if (e < P.cp_e0) return;  // walked silently: no checkpoints
     const int idx = e * P.S + s;
@@ -1712,6 +1740,7 @@ __global__ __launch_bounds__(SYN_BLOCK) __attribute__((amdgpu_waves_per_eu(SYN_W
     const uint32_t *const p_pcur = Pd->page_cur, *const p_pnext = Pd->page_next;
     const uint32_t cs25 = Pd->cs25;
     const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
+    if (ACC && nact == 0) return;  // nothing to add in this epoch (an accumulating launch behind k_synth_g: most epochs of most batches)
     const uint4 aw = *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW);
     const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};
     // slot index e * S + act[j] of position j (idle positions alias slot act[0]: loads stay in bounds, results unused)
@@ -2353,8 +2382,10 @@ extern "C" void galk_launch_carr_guess(const DevPlan *P, hipStream_t st)
 
 extern "C" void galk_launch_verify_carr(const DevPlan *P, hipStream_t st)
 {
-    const int n = P->LEGS * P->S;
-    hipLaunchKernelGGL(k_verify_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P);
+    const int mod = P->ver_mod > 1 ? P->ver_mod : 1;
+    const int nsel = (P->LEGS + mod - 1) / mod * P->S;  // the rotation's legs, then (mod > 1) one thread per eight legs for the risky ones
+    const int n = nsel + (mod > 1 ? (P->LEGS * P->S + 7) / 8 : 0);
+    hipLaunchKernelGGL(k_verify_carr, dim3((n + 255) / 256), dim3(256), 0, st, *P);
 }
 
 extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st)

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libgalsynth.so")
 HOOKS_LIB_PATH = os.path.join(PKG_DIR, "libgalsynth_hooks.so")
 GAL_CFG_SINGLE_STREAM = 1
 GAL_CFG_EXACT_REPLAY = 4  # always the exact-replay kernel (k_synth), also where k_synth_g could run
+GAL_CFG_VERIFY_ALL = 8  # k_synth_g batches: re-walk every translated carrier leg in every batch (default: a rotating eighth)
 GAL_CFG_CBOC = 2  # opt-in CBOC(6,1,1/11) sub-carrier (not in the reference; defined by the oracle's CBOC mode)
 
 GAL_CH_RESTART = 1
@@ -75,7 +76,7 @@ class _Stats(ctypes.Structure):
         ("kernel_family", ctypes.c_int32),
         ("repaired_groups", ctypes.c_int32),
         ("ms_repair", ctypes.c_float),
-        ("reserved", ctypes.c_int32),
+        ("exact_records", ctypes.c_int32),
     ]
 
 

@@ -101,6 +101,11 @@ typedef struct gal_synth_cfg {
                                     the default kernel of the reference geometry -- 16-sample groups from closed-form start
                                     states, undecided groups replayed exactly -- could run.  Same bits either way; this one is
                                     slower and carries the replay self-check (gal_synth_stats_t.kernel_family says which ran) */
+#define GAL_CFG_VERIFY_ALL 8u    /* batches of the default kernel (kernel_family 1): re-walk EVERY translated carrier leg in every batch
+                                    (round 4's behaviour; a single handle's step is 5 % longer for it).  Default: an eighth of the
+                                    leg positions per batch, rotating with the handle's batch count, plus every leg whose
+                                    translation used more than 1/256 of its margin, plus ~20 000 randomly placed chunks of both
+                                    chains walked to their ends by the repair kernel                       */
 #define GAL_CFG_SINGLE_STREAM 1u /* enqueue every kernel on the handle's stream (no internal high-priority walker
                                     streams): for callers that capture or serialise the stream themselves       */
 
@@ -129,7 +134,10 @@ typedef struct gal_synth_stats {
                                    cycles per sample; BOC(1,1) in all three forms, the CBOC mode in form 1                  */
     int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
     float   ms_repair;          /* family 1: device time of that replay (k_repair_g, behind the synthesis kernel; not in ms_synth) */
-    int32_t reserved;
+    int32_t exact_records;      /* family 1: records (channel-epochs) of the batch that are not fit for the group kernel -- a carrier
+                                   that stands still or is faster than 120 table entries per 16 samples, pattern thresholds that
+                                   crowd, another window form than the batch's -- and took an accumulating exact-replay launch
+                                   behind it (0 in every scenario of the reference's geometry seen so far)                      */
 } gal_synth_stats_t;
 /* The struct only ever GROWS AT ITS END (0.2: 40 bytes, up to chain_mismatch .. ms_synth; 0.3: 56).  gal_synth_finish and
  * gal_synth_run_host are macros over the _n entry points below, which copy min(the caller's sizeof, the library's) bytes: a caller

@@ -467,20 +467,37 @@ def test_m_syn24_full_size_properties(pkg):
 
 
 def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
-    """Safety net of the translated acceptance: a leg shifted by the wrong amount (test hook) must be caught by
-    k_synth's replay check; gal_synth_finish then redoes the chain with every leg walked and repeats the
-    synthesis -- the caller still gets bit-exact IQ, and the fallback is counted."""
+    """Safety net of the translated acceptance: a leg shifted by the wrong amount (test hook) must be caught -- by
+    k_verify_carr's re-walk on the default kernel (GAL_CFG_VERIFY_ALL: every leg in every batch; default: the leg's
+    turn in the rotation comes within eight batches of the handle), by k_synth's replay check with GAL_CFG_EXACT_REPLAY;
+    gal_synth_finish then redoes the chain with every leg walked and repeats the synthesis -- the caller still gets
+    bit-exact IQ, and the fallback is counted."""
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=4, n_slots=8, samples_per_epoch=260000, seed=99)
     monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")  # honoured by the GAL_TEST_HOOKS build only
-    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0, test_hooks=True) as eng:
-        assert b"testhooks" in eng._lib.gal_synth_version()
-        iq, st, stats = eng.run_host(p)
-        walked, translated, fallbacks = eng.walk_counts()
     ref_iq, ref_st = oracle_run(p, 260000, 2.6e6)
-    assert fallbacks == 1 and stats["chain_mismatch"] == 0
-    assert np.array_equal(iq, ref_iq)
     act = ref_st["prn"] > 0
-    assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+    for flags in (pkg.synth.GAL_CFG_VERIFY_ALL, pkg.synth.GAL_CFG_EXACT_REPLAY):
+        with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0, test_hooks=True, flags=flags) as eng:
+            assert b"testhooks" in eng._lib.gal_synth_version()
+            iq, st, stats = eng.run_host(p)
+            walked, translated, fallbacks = eng.walk_counts()
+        assert fallbacks == 1 and stats["chain_mismatch"] == 0, flags
+        assert np.array_equal(iq, ref_iq)
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+    # the default: an eighth of the leg positions per batch, rotating -- the bad leg is caught when its turn comes, the output of
+    # the batches before that is wrong in the leg's 32 chunks (which is what the rotation trades for 5 % of a single handle's step;
+    # the translation it guards is a proof, and no leg has ever failed it outside this hook)
+    with pkg.SynthEngine(samples_per_epoch=260000, n_slots=8, device=0, test_hooks=True) as eng:
+        n_caught = 0
+        for _ in range(8):
+            before = eng.walk_counts()[2]
+            iq, st, stats = eng.run_host(p)
+            assert stats["chain_mismatch"] == 0
+            if eng.walk_counts()[2] > before:  # this batch's rotation looked at the leg: repaired, exact
+                n_caught += 1
+                assert np.array_equal(iq, ref_iq)
+                assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+        assert n_caught in (1, 2)  # (the leg's own turn, and its predecessor's, whose hand-over lands on its first checkpoint)
     monkeypatch.setenv("GAL_WALK_TRANSLATE", "0")  # and the all-walked mode on its own
     _compare(pkg, p, 260000, test_hooks=True)
     # the product library has no such hook: the same environment leaves it on the normal path
@@ -503,7 +520,7 @@ def test_range_execute_never_rests_on_an_unreplayed_translation(pkg, monkeypatch
     p = pkg.workloads.make_synthetic(n_epochs=6, n_chan=4, n_slots=8, samples_per_epoch=n, seed=99)
     ref_iq, ref_st = oracle_run(p, n, 2.6e6)
     monkeypatch.setenv("GAL_WALK_TRANSLATE", "2")
-    with pkg.SynthEngine(samples_per_epoch=n, n_slots=8, device=0, test_hooks=True) as eng:
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=8, device=0, test_hooks=True, flags=pkg.synth.GAL_CFG_VERIFY_ALL) as eng:
         eng.plan(p)
         for e0, ne in ((2, 3), (1, 5), (5, 1)):
             out = torch.empty(ne * n * 2, dtype=torch.int16, device="cuda")

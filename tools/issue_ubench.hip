@@ -63,7 +63,28 @@
     X(45, "ds_read_b32 + 4 x v_add_f64 (5)", 5, 1, "ds_read_b32 v[\\r-10], v44\n v_add_f64 v[\\r:\\r+1], v[\\r:\\r+1], v[42:43]\n v_add_f64 v[\\r:\\r+1], v[\\r:\\r+1], v[42:43]\n v_add_f64 v[\\r:\\r+1], v[\\r:\\r+1], v[42:43]\n v_add_f64 v[\\r:\\r+1], v[\\r:\\r+1], v[42:43]") \
     X(46, "ds_read_b32 + 4 x v_add_u32 (5)", 5, 1, "ds_read_b32 v[\\r-10], v44\n v_add_u32 v\\r, v\\r, v40\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_add_u32 v\\r, v\\r, v40\n v_add_u32 v[\\r+1], v[\\r+1], v40") \
     X(47, "s_nop 0", 1, 0, "s_nop 0")                                                     \
-    X(48, "v_add_u32 + s_nop 0 (2)", 2, 0, "v_add_u32 v\\r, v\\r, v40\n s_nop 0")
+    X(48, "v_add_u32 + s_nop 0 (2)", 2, 0, "v_add_u32 v\\r, v\\r, v40\n s_nop 0")   \
+    X(49, "v_fma_f32 distinct regs", 1, 1, "v_fma_f32 v\\r, v\\r, v[\\r+1], v41")             \
+    X(50, "N,P,P: pk_mad, add_u32, and_b32 (3)", 3, 1, "v_pk_mad_u16 v\\r, v40, v\\r, v\\r op_sel_hi:[1,0,1]\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_and_b32 v[\\r-10], v[\\r-10], v40") \
+    X(51, "N,N,P,P: pk_mad, bfe, add_u32, and_b32 (4)", 4, 1, "v_pk_mad_u16 v\\r, v40, v\\r, v\\r op_sel_hi:[1,0,1]\n v_bfe_i32 v[\\r-9], v[\\r-9], 4, 2\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_and_b32 v[\\r-10], v[\\r-10], v40") \
+    X(52, "N,P,P,P,P: add_f64 + 4 simple (5)", 5, 1, "v_add_f64 v[\\r:\\r+1], v[\\r:\\r+1], v[42:43]\n v_add_u32 v[\\r-10], v[\\r-10], v40\n v_and_b32 v[\\r-9], v[\\r-9], v40\n v_lshrrev_b32 v[\\r-10], 1, v[\\r-10]\n v_xor_b32 v[\\r-9], v[\\r-9], v40") \
+    X(53, "v_add_co_u32 (vcc)", 1, 0, "v_add_co_u32 v\\r, vcc, v\\r, v40")                   \
+    X(54, "v_addc_co_u32 (vcc)", 1, 0, "v_addc_co_u32 v\\r, vcc, v\\r, v40, vcc")            \
+    X(55, "add_co + addc pair (2)", 2, 1, "v_add_co_u32 v\\r, vcc, v\\r, v40\n v_addc_co_u32 v[\\r+1], vcc, v[\\r+1], v40, vcc") \
+    X(56, "v_lshlrev_b32 by vgpr", 1, 0, "v_lshlrev_b32 v\\r, v40, v\\r")                    \
+    X(57, "v_lshrrev_b32 by vgpr", 1, 0, "v_lshrrev_b32 v\\r, v40, v\\r")                    \
+    X(58, "v_ashrrev_i32", 1, 0, "v_ashrrev_i32 v\\r, 1, v\\r")                              \
+    X(59, "v_cvt_f32_i32", 1, 0, "v_cvt_f32_i32 v\\r, v\\r")                                 \
+    X(60, "v_cvt_f32_ubyte0", 1, 0, "v_cvt_f32_ubyte0 v\\r, v\\r")                           \
+    X(61, "v_mac_f32 / v_fmac_f32", 1, 0, "v_fmac_f32 v\\r, v40, v41")                       \
+    X(62, "v_fmac_f32 + v_add_u32 (2)", 2, 1, "v_fmac_f32 v\\r, v40, v41\n v_add_u32 v[\\r+1], v[\\r+1], v40") \
+    X(63, "v_fmac_f32 x2 + add_u32 + lshrrev (4)", 4, 1, "v_fmac_f32 v\\r, v40, v41\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_fmac_f32 v[\\r-10], v40, v41\n v_lshrrev_b32 v[\\r-9], 1, v[\\r-9]") \
+    X(64, "v_mul_u32_u24", 1, 0, "v_mul_u32_u24 v\\r, v\\r, v40")                            \
+    X(65, "v_subrev_u32", 1, 0, "v_subrev_u32 v\\r, v40, v\\r")                              \
+    X(66, "v_sub_f32", 1, 0, "v_sub_f32 v\\r, v\\r, v41")                                    \
+    X(67, "v_mul_f32 x v_add_f32 alternating (2)", 2, 1, "v_mul_f32 v\\r, v\\r, v41\n v_add_f32 v[\\r+1], v[\\r+1], v41") \
+    X(68, "v_pk_mad_u16 x2 + 4 simple (6)", 6, 1, "v_pk_mad_u16 v\\r, v40, v\\r, v\\r op_sel_hi:[1,0,1]\n v_pk_mad_u16 v[\\r+1], v40, v[\\r+1], v[\\r+1] op_sel_hi:[1,0,1]\n v_add_u32 v[\\r-10], v[\\r-10], v40\n v_and_b32 v[\\r-9], v[\\r-9], v40\n v_lshrrev_b32 v[\\r-10], 1, v[\\r-10]\n v_xor_b32 v[\\r-9], v[\\r-9], v40") \
+    X(69, "ds_read_b32 + 8 x v_add_u32 (9)", 9, 1, "ds_read_b32 v[\\r-10], v44\n v_add_u32 v\\r, v\\r, v40\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_add_u32 v\\r, v\\r, v40\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_add_u32 v\\r, v\\r, v40\n v_add_u32 v[\\r+1], v[\\r+1], v40\n v_add_u32 v\\r, v\\r, v40\n v_add_u32 v[\\r+1], v[\\r+1], v40")
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t *out, unsigned long long *cyc, float seed, int trips)
