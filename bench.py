@@ -341,6 +341,8 @@ def main():
                     "25 MS/s); dyn = config 3 (12 SVs, Doppler from a 10 Hz circular track); locations = config 5 "
                     "literally: rank r simulates static site r of 8 for 300 s from tests/golden/20feb2022.rnx through "
                     "the real host front-end (7-10 SVs per site, so the ranks' work differs)")
+    ap.add_argument("--site", type=int, default=None, help="--workload locations: the site (0..7 of shard.LOCATIONS) this process "
+                    "simulates instead of site `rank` -- the per-site 1-GPU baseline of config 5 (tools/config5_sites.sh)")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4],
                     help="engine handles in flight: 2 = software pipeline, the NCO walk of step k+1 (latency "
                     "bound, on the handle's high-priority stream) runs beside the synthesis kernel of step k (issue "
@@ -427,7 +429,7 @@ def main():
     site = None
     if args.workload == "locations":
         nav = os.path.join(ROOT, "tests", "golden", "20feb2022.rnx")
-        params, site = pkg.shard.rank_location_scenario(pkg.Scenario, nav, 0 if strong else rank)
+        params, site = pkg.shard.rank_location_scenario(pkg.Scenario, nav, args.site if args.site is not None else (0 if strong else rank))
         args.epochs = params.shape[0]
         args.channels = int((params["prn"] > 0).sum(axis=1).max())
     else:
@@ -592,8 +594,8 @@ def main():
             "config": {
                 "workload": {"syn12": "M-SYN12: static-geometry 12-SV E1B/C", "syn24": "M-SYN24: 24-SV E1B/C",
                              "dyn": "M-DYN: 12-SV E1B/C, 10 Hz circular user motion",
-                             "locations": "config 5: static site per rank from 20feb2022.rnx (rank 0: %s, %d SVs), 300 s"
-                             % (site, args.channels)}[args.workload]
+                             "locations": "config 5: static site per rank from 20feb2022.rnx (%s: %s, %d SVs), 300 s"
+                             % ("site %d" % args.site if args.site is not None else "rank 0", site, args.channels)}[args.workload]
                 + (", ONE scenario of %d epochs x %d samples @%.1f MS/s cut into epoch ranges over the ranks" if strong
                    else ", %d epochs x %d samples @%.1f MS/s per GPU (one independent scenario per rank)") % (
                     args.epochs, n_samp, rate / 1e6),

@@ -219,6 +219,66 @@ def test_cli_sites_one_process_per_site(pkg, tmp_path):
     assert r.returncode == 1 and "failed = 3" in r.stderr
 
 
+def _oracle_md5(pkg, rows, piece=200):
+    """md5 of the oracle's ishort stream on these rows, produced in pieces with the channel state carried (host memory: one piece)."""
+    from oracle_binding import oracle_run
+
+    h, st, n = hashlib.md5(), None, 0
+    for a in range(0, rows.shape[0], piece):
+        iq, st = oracle_run(rows[a:a + piece], 260000, 2.6e6, state_in=st)
+        h.update(iq.tobytes())
+        n += iq.nbytes
+    return h.hexdigest(), n
+
+
+@pytest.mark.gpu
+def test_cli_config5_all_eight_sites(pkg, tmp_path):
+    """BASELINE config 5 LITERALLY on the one GPU there is: `--sites` with the eight receiver sites of shard.LOCATIONS, 300 s each
+    (2999 epochs, 3 118 960 000 bytes per site), two processes at a time on GPU 0.  Every file's md5 must be (a) the md5 of the
+    oracle's stream on the front-end's rows for that site and (b) the md5 THE REFERENCE PROGRAM gave for the same command line
+    (tests/golden/ref_task_config5.json, recorded by tools/ref_task_config5.py from oracle/_ref/ref_task where /root/reference
+    exists).  Eight files are 25 GB: where the temporary directory has less room the sites run in two launches of four."""
+    import shutil
+    from concurrent.futures import ThreadPoolExecutor
+
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_task_config5.json")))
+    sites = list(pkg.shard.LOCATIONS)
+    assert len(sites) == 8 and [tuple(s["llh"]) for s in rec["sites"]] == [tuple(x) for x in sites]
+    start, dur = rec["start"], rec["duration_s"]
+
+    def front_end_oracle(llh):
+        rows = pkg.Scenario(NAV, llh=llh, start=start, duration_s=dur, iono_enable=True).all()
+        return _oracle_md5(pkg, rows), int((rows["prn"] > 0).sum(axis=1).max())
+
+    with ThreadPoolExecutor(8) as ex:  # (ctypes releases the GIL inside the oracle: the eight sites beside the CLI runs)
+        want = [ex.submit(front_end_oracle, llh) for llh in sites]
+        free = shutil.disk_usage(str(tmp_path)).free
+        halves = [list(range(8))] if free > 40e9 else [[0, 1, 2, 3], [4, 5, 6, 7]]
+        got = {}
+        for part in halves:
+            lst = tmp_path / "sites.txt"
+            lst.write_text("".join("%.10g,%.10g,%.10g\n" % sites[k] for k in part))
+            stem = tmp_path / "c5.ishort"
+            r = subprocess.run([CLI, "-e", NAV, "--sites", str(lst), "-t", start, "-d", str(dur), "-o", str(stem), "--gpus", "1",
+                                "--per-gpu", "2"], capture_output=True, text=True, timeout=1500)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert "Sites = %d  failed = 0" % len(part) in r.stderr
+            for j, k in enumerate(part):
+                f = tmp_path / ("c5.site%d.ishort" % j)
+                h, n = hashlib.md5(), 0
+                with open(f, "rb") as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b""):
+                        h.update(blk)
+                        n += len(blk)
+                got[k] = (h.hexdigest(), n)
+                f.unlink()
+        want = [w.result() for w in want]
+    for k in range(8):
+        (md5, n), n_sv = want[k]
+        assert n == 2999 * 260000 * 4 and got[k] == (md5, n), (k, sites[k], n_sv)
+        assert (rec["sites"][k]["md5"], rec["sites"][k]["bytes"]) == got[k], (k, sites[k], "reference program")
+
+
 @pytest.mark.gpu
 def test_cli_file_sink_variants_agree(tmp_path):
     """The mapped multi-writer sink (regular files), the sequential sink (GAL_SINK=stream) and stdout give the same bytes;
