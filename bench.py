@@ -290,6 +290,36 @@ def measured_traffic():
         return None, None
 
 
+def measured_issue(kernel_ms):
+    """What actually bounds k_synth_g: instruction issue, not HBM.  From the newest committed PMC summary
+    (profiles/*_pmc_k_synth_all.json: SQ_INSTS_VALU, SQ_LDS_IDX_ACTIVE per launch): VALU wave-instructions x 4 cycles over the
+    chip's 1024 SIMDs at the 2.4 GHz the device reports, and LDS array cycles over its 256 LDS units, against the LIVE kernel time.
+    (tools/issue_ubench: every VALU instruction of this path costs 4.1-4.3 cycles of that clock back to back, i.e. the device
+    runs a pure VALU stream at ~2.25 GHz; at that clock the fractions are 7 % higher.)"""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_k_synth_all.json")))
+    if not files or not kernel_ms:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        valu = float(d["SQ_INSTS_VALU"])
+        out = {"bound": "valu issue", "valu_wave_instructions": int(valu), "cycles_per_instruction": 4, "simds": 1024, "clock_ghz": 2.4,
+               "valu_ms": round(valu * 4 / 1024 / 2.4e9 * 1e3, 4), "kernel_ms": round(kernel_ms, 4),
+               "frac": round(valu * 4 / 1024 / 2.4e9 * 1e3 / kernel_ms, 4),
+               "per_channel_sample": round(valu * 64 / (311.74e6 * 12), 3),
+               "source": os.path.basename(files[-1]), "is_live": False}
+        if "SQ_LDS_IDX_ACTIVE" in d:
+            lds = float(d["SQ_LDS_IDX_ACTIVE"])
+            out["lds_array_cycles"] = int(lds)
+            out["lds_frac"] = round(lds / 256 / 2.4e9 * 1e3 / kernel_ms, 4)
+            if "SQ_LDS_BANK_CONFLICT" in d:
+                out["lds_bank_conflict_cycles"] = int(float(d["SQ_LDS_BANK_CONFLICT"]))
+        return out
+    except Exception:
+        return None
+
+
 # A/B experiments only (tools/): GAL_BENCH_HOOKS=1 runs the GAL_TEST_HOOKS build of the library, whose environment
 # switches (GAL_SYNTH_RW=0 ...) select code paths; such a line carries "hooks_build": true and is never a result.
 HOOKS_BUILD = bool(os.environ.get("GAL_BENCH_HOOKS"))
@@ -650,6 +680,8 @@ def main():
                                "what": "per-launch HIP-event intervals INSIDE the timed region (%d handles in flight)" % depth},
                 "avg_walk_ms": round(ms_walk / args.steps, 4),
                 "algorithmic_bytes_per_launch": 4 * samples_per_step,
+                # the bound that binds: issue slots (north_star's HBM-write fraction above stays the headline `frac`)
+                **({"issue": measured_issue(solo_ms)} if traffic is not None and measured_issue(solo_ms) else {}),
             },
         }
         default_run = (world == 1 and args.workload == "syn12" and args.epochs == 1199 and args.channels == 12 and not strong

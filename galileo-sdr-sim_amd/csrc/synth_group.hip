@@ -291,25 +291,22 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     // slower, 0.895 -> 0.960 ms, profiles/r05d_prio_ab.log)
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    // ---- the block's share of the launch: a CONTIGUOUS range of its chunks in (epoch, chunk) order, cut evenly (round 5; rounds
-    // 1-4: one block per epoch -- 1199 blocks on 512 resident slots, the third round a third full).  A range that crosses an epoch
-    // boundary is worked off segment by segment: the block rebuilds its per-epoch tables in between.  Consecutive ranges go to the
-    // same XCD (hardware: block b -> XCD b % 8): they share an epoch's checkpoints in that XCD's L2
-    // (product launches: ne x bpe blocks, block boundaries on epoch boundaries -- 32-bit arithmetic; the 64-bit form serves the
-    // GAL_TEST_HOOKS layouts that ignore them)
+    // ---- the block's share of the launch: a CONTIGUOUS run of its chunks in (epoch, chunk) order.  ne x bpe blocks, block boundaries
+    // on epoch boundaries: a block's run lies inside ONE epoch -- one set of tables (sg_grid).  The balanced layouts that ignore the
+    // epoch boundaries (a range that crosses one is worked off segment by segment, the block rebuilds its per-epoch tables in
+    // between; consecutive ranges on the same XCD), measured slower, are in variant builds only: -DSG_BALANCED_RANGES,
+    // tools/build_variant_g.sh
+#ifdef SG_BALANCED_RANGES
     const int nb = (int)gridDim.x;
-    long long uq, u_end;
-    if (G.blocks_per_epoch > 0) {
-        const int bpe = G.blocks_per_epoch;
-        const int erb = (int)blockIdx.x / bpe, tg = (int)blockIdx.x - erb * bpe;
-        uq = (long long)erb * G.nchunks + G.nchunks * tg / bpe;
-        u_end = (long long)erb * G.nchunks + G.nchunks * (tg + 1) / bpe;
-    } else {
-        const int xb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-        const long long U = (long long)G.ne * G.nchunks;
-        uq = U * xb / nb;
-        u_end = U * (xb + 1) / nb;
-    }
+    const int xb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const long long U = (long long)G.ne * G.nchunks;
+    long long uq = U * xb / nb;
+    const long long u_end = U * (xb + 1) / nb;
+#else
+    const int bpe = G.blocks_per_epoch;
+    const int er = (int)blockIdx.x / bpe, tg = (int)blockIdx.x - er * bpe;  // epoch relative to the executed range, part of it
+    const int c_begin = G.nchunks * tg / bpe, c_end = G.nchunks * (tg + 1) / bpe;
+#endif
     const int *const p_lut = Pd->lut;
     const int *const p_prn = Pd->prn;
     const int *const p_ib0 = Pd->ib0;
@@ -345,18 +342,24 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         k = k >= 511 ? k - 511 : k;
         s_lut[i] = p_lut[(tab ? -k : k) & 511];
     }
+#ifdef SG_BALANCED_RANGES
     int row_prn[NCH];  // PRN whose stream row position j holds (0: none yet, -1: the all-zero row of an idle position)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) row_prn[j] = 0;
+#endif
+#ifdef SG_BALANCED_RANGES
     bool first_seg = true;
     while (uq < u_end) {
-    const int er = G.blocks_per_epoch > 0 ? (int)blockIdx.x / G.blocks_per_epoch : (int)(uq / G.nchunks);  // epoch relative to the executed range
+    const int er = (int)(uq / G.nchunks);  // epoch relative to the executed range
     const int c_begin = (int)(uq - (long long)er * G.nchunks);
     const int c_end = (long long)(G.nchunks - c_begin) < u_end - uq ? G.nchunks : c_begin + (int)(u_end - uq);
     uq += c_end - c_begin;
-    const int e = G.e0 + er;
     if (!first_seg) __syncthreads();  // every wave is through with the tables of the segment before
     first_seg = false;
+#else
+    {
+#endif
+    const int e = G.e0 + er;
 
     // ---- phase 0 (scalar): the epoch's active list, slot indices
     const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
@@ -376,9 +379,11 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         int prn = __builtin_amdgcn_readfirstlane(p_prn[ixs[j]]);
         prn = prn < 1 ? 1 : prn;  // idle position: any valid row, zeroed below
         const bool on = j < nact;
+#ifdef SG_BALANCED_RANGES
         const int want = on ? prn : -1;
         if (want == row_prn[j]) continue;  // the row of the segment before (same satellite in this position) stays
         row_prn[j] = want;
+#endif
         const uint32_t *src = p_str + (size_t)(prn - 1) * STR_WORDS;
         // the row continues behind half chip 8183 (the middle of word 511) with the start of the period, so that a window at or
         // across the code wrap is one contiguous read: a plain copy of words 0 .. 510, then the 69 spliced ones
@@ -623,9 +628,16 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         // balanced parts: 5, 6, 7, 9, 10, 11 positions are cut 3+2, 3+3, 4+3, 3+3+3, 4+3+3, 4+4+3
 #define SG_PART(J0, CNT) sg_part<J0, CNT, MODE, SIG, BINS, BPITCH>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat, s_bin6, s_pat6, nact); \
                          __builtin_amdgcn_sched_barrier(0);
-        // (CBOC: parts of three -- a part's group start keeps 17 values per position alive, 13 in the BOC(1,1) form)
-        if constexpr (SIG == 1 && NCH == 4) { SG_PART(0, 2) SG_PART(2, 2) }
+        // (CBOC: parts of at most three -- a part's group start keeps 17 values per position alive, 13 in the BOC(1,1) form)
+        if constexpr (SIG == 1 && NCH <= 3) { SG_PART(0, NCH) }
+        else if constexpr (SIG == 1 && NCH == 4) { SG_PART(0, 2) SG_PART(2, 2) }
+        else if constexpr (SIG == 1 && NCH == 5) { SG_PART(0, 3) SG_PART(3, 2) }
+        else if constexpr (SIG == 1 && NCH == 6) { SG_PART(0, 3) SG_PART(3, 3) }
+        else if constexpr (SIG == 1 && NCH == 7) { SG_PART(0, 3) SG_PART(3, 2) SG_PART(5, 2) }
         else if constexpr (SIG == 1 && NCH == 8) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 2) }
+        else if constexpr (SIG == 1 && NCH == 9) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 3) }
+        else if constexpr (SIG == 1 && NCH == 10) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 2) SG_PART(8, 2) }
+        else if constexpr (SIG == 1 && NCH == 11) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 3) SG_PART(9, 2) }
         else if constexpr (SIG == 1 && NCH == 12) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 3) SG_PART(9, 3) }
         else if constexpr (NCH <= 4) { SG_PART(0, NCH) }
         else if constexpr (NCH == 5) { SG_PART(0, 3) SG_PART(3, 2) }
@@ -806,7 +818,11 @@ static int sg_grid(const DevPlan *P, int ne)
 {
     const long long U = (long long)ne * P->nchunks;
     const int slots = P->gslots > 0 ? P->gslots : 512;
-    if (P->grounds > 0 && U >= (long long)slots * P->grounds * 32) return slots * P->grounds;  // (hooks: balanced persistent ranges)
+#ifdef SG_BALANCED_RANGES
+    if (P->grounds > 0 && U >= (long long)slots * P->grounds * 32) return slots * P->grounds;  // balanced persistent ranges
+#else
+    (void)U;
+#endif
     int bpe = P->gbpe > 0 ? P->gbpe : 1;                                                        // (hooks: fixed blocks per epoch)
     if (P->gbpe <= 0) {
         const int nw = 8;  // waves per block
@@ -820,9 +836,6 @@ static int sg_grid(const DevPlan *P, int ne)
 // ... and the blocks per epoch of that grid (0: a hooks layout that ignores the epoch boundaries)
 static int sg_bpe(const DevPlan *P, int ne)
 {
-    const long long U = (long long)ne * P->nchunks;
-    const int slots = P->gslots > 0 ? P->gslots : 512;
-    if (P->grounds > 0 && U >= (long long)slots * P->grounds * 32) return 0;
     return sg_grid(P, ne) / ne;
 }
 
@@ -836,14 +849,7 @@ static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const 
     const dim3 grid(sg_grid(P, ne)), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
 #endif
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
-    if constexpr (SIG == 1) {
-        // the opt-in CBOC mode is built for 4, 8 and 12 positions only, like k_synth's (positions beyond the active count are idle)
-        if (nch < 1 || nch > 12) return -1;
-        switch ((nch + 3) / 4 * 4) {
-            GAL_CASE(4) GAL_CASE(8) GAL_CASE(12)
-        default: return -1;
-        }
-    } else {
+    {  // one instance per channel count, in the CBOC mode too (round 4: 4 / 8 / 12 positions, a 9-SV batch paid for 12)
         switch (nch) {
             GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
             GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)

@@ -136,3 +136,20 @@ def test_cli_reproduces_recorded_reference_answers(k, tmp_path):
         pytest.skip("ephemeris gap: the reference's behaviour is undefined there")
     data = open(out, "rb").read()
     assert [hashlib.md5(data).hexdigest(), len(data)] == k["recorded"][:2], args
+
+
+def test_front_end_and_oracle_reproduce_a_config5_unit_of_the_reference_program(pkg):
+    """BASELINE config 5's per-rank unit, 300 s at one of its eight sites (tests/golden/ref_task_config5.json: the reference program's
+    md5 and byte count for every site, recorded by tools/ref_task_config5.py): front-end -> oracle on the CPU gives the reference's
+    file for the site with the fewest satellites (5 SVs, 35 s of CPU); all eight go through the product on the GPU box
+    (tests/test_cli.py::test_cli_config5_all_eight_sites)."""
+    rec = json.load(open(os.path.join(G, "ref_task_config5.json")))
+    k = 4
+    assert tuple(rec["sites"][k]["llh"]) == tuple(pkg.shard.LOCATIONS[k])
+    rows = pkg.Scenario(NAV, llh=pkg.shard.LOCATIONS[k], start=rec["start"], duration_s=rec["duration_s"], iono_enable=True).all()
+    h, st, n = hashlib.md5(), None, 0
+    for a in range(0, rows.shape[0], 200):
+        iq, st = oracle_run(rows[a:a + 200], 260000, 2.6e6, state_in=st)
+        h.update(iq.tobytes())
+        n += iq.nbytes
+    assert (h.hexdigest(), n) == (rec["sites"][k]["md5"], rec["sites"][k]["bytes"])

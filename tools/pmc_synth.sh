@@ -10,7 +10,7 @@ mkdir -p $out
 cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1"
 i=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
-            "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" "WRITE_SIZE" "FETCH_SIZE"; do
+            "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_IDX_ACTIVE" "WRITE_SIZE" "FETCH_SIZE"; do
     i=$((i+1))
     # (WRITE_SIZE and FETCH_SIZE do not fit one pass on gfx950: rocprofv3 aborts and then hangs -> own passes,
     # and every pass under its own timeout)
