@@ -8,6 +8,7 @@ import json,sys
 for ln in sys.stdin:
     if ln.startswith("{"):
         d=json.loads(ln); c=d["config"]
-        print("site %s  SVs(max) %2d  epochs 2999  ms per 300 s scenario %.3f  = %.1f G samples/s  kernel alone %.3f ms  family %s  checksum %s  %s" % (
-            sys.argv[1], c["channels"], d["ms_per_step"], d["value"]/1e3, d["roofline"]["avg_kernel_ms"], c["kernel_family"], c["output_checksum"], c["workload"][:90]))' $k
+        print("site %s  SVs(max) %2d  epochs 2999  ms per 300 s scenario %.3f  = %.1f G samples/s  kernel alone %.3f ms  walker chain %.3f ms  passes %s  synth runs %s  family %s  checksum %s  %s" % (
+            sys.argv[1], c["channels"], d["ms_per_step"], d["value"]/1e3, d["roofline"]["avg_kernel_ms"], d["roofline"]["avg_walk_ms"], c["walk_passes"], c["synth_runs_max"],
+            c["kernel_family"], c["output_checksum"], c["workload"][44:90]))' $k
 done
