@@ -369,6 +369,220 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
 
 
 // ---------------------------------------------------------------------------------------------
+// The code chain of ONE epoch in LEGS (round 5; rounds 1-4: one lane walked the epoch's 351 dependent closed-form steps, the long
+// pole of a one-epoch call and of a lone handle's walker chain).  Leg 0 starts from the epoch's own start state, which the
+// caller supplies; leg k > 0 is walked from an ANCHOR -- the last wrap (:491-507) strictly in front of its first sample, "after the
+// check at the top of sample w the phase is r and the symbol counter ib" -- guessed in ideal arithmetic.  A post-wrap phase
+// x - 4092 is a multiple of 2^-41 (the ulp of [2048, 4096), where every wrap happens), and every binade below 4096 has a grid that
+// 2^-41 is a multiple of: a trajectory shifted by delta = true residual - guessed residual therefore produces every state shifted
+// by delta, bit for bit, as long as (a) every state stays in its binade and on its side of the wrap threshold -- code_walk_track
+// records the MARGIN, the smallest distance of a visited state to a binade boundary or to 4092 -- and (b) no rounding is a tie
+// whose resolution depends on the parity of x / ulp, which delta can flip only in [2048, 4096) and only if the step is a
+// multiple of 2^-42 (code_tie_prone: such epochs -- one in ~4000 -- are not translated, their legs are walked one after the other).
+// The stitch (code_leg_accept) is the carrier chain's (synth_kernels.hip: k_carr_scan) in small: the legs of an epoch sit in
+// neighbouring lanes, leg k looks at the VERIFIED claim of leg k - 1.
+struct CodeTrack {
+    double x;        // pre-check state after the last sample
+    int ibit;
+    int flipped;     // the symbol counter passed 500 during this walk
+    int last_w;      // local index of the last sample at whose top a wrap fired, -1: none
+    double last_r;   // post-check state there (x - 4092)
+    int last_ib;     // symbol counter behind that wrap
+    int last_fl;     // `flipped` behind that wrap
+    double margin;   // smallest distance of a visited state to a boundary of its binade or to the wrap threshold
+};
+
+GAL_HD bool code_tie_prone(double cstep)
+{
+    const double t42 = cstep * 4398046511104.0;  // * 2^42, exact
+    return !(cstep < 4.0) || t42 == (double)(long long)t42;
+}
+
+// code_walk with the bookkeeping of a speculative leg.  Same states as code_walk (the batches are the same closed forms), bit for
+// bit; checkpoints at local samples cp0, cp0 + R, ... (cp0 >= N: none).  Steps outside [2^-20, 4) chips: margin 0 (never translated).
+template <class Emit>
+GAL_HD CodeTrack code_walk_track(double x, int ibit, double cstep, double inv_c, int N, int R, int cp0, Emit emit)
+{
+    int i = 0;
+    int next_cp = cp0, c = 0;
+    CodeTrack o;
+    o.flipped = 0;
+    o.last_w = -1;
+    o.last_r = 0.0;
+    o.last_ib = 0;
+    o.last_fl = 0;
+    const uint64_t cb = d2u(cstep);
+    const uint32_t ed = (uint32_t)(cb >> 52);
+    const bool lean = (cstep >= 9.5367431640625e-07) && (cstep < 4.0) && (x >= 0.0);
+    const uint32_t e_tie = ed + 1u + (uint32_t)__builtin_ctzll(cb | (1ull << 52));
+    double mg = lean ? 8192.0 : 0.0;
+    while (i < N) {
+        if (next_cp == i) {
+            emit(c, x, ibit, o.flipped);
+            ++c;
+            next_cp += R;
+        }
+        const bool ge = x >= 4092.0;
+        x = x - (ge ? 4092.0 : 0.0);
+        ibit += ge ? 1 : 0;
+        const bool flip = ibit >= 500;
+        ibit = flip ? 0 : ibit;
+        o.flipped |= flip ? 1 : 0;
+        o.last_w = ge ? i : o.last_w;
+        o.last_r = ge ? x : o.last_r;
+        o.last_ib = ge ? ibit : o.last_ib;
+        o.last_fl = ge ? o.flipped : o.last_fl;
+        // (a wrapped state sits x above the threshold it has just passed: a shift below -x would not have wrapped here)
+        mg = (ge && x < mg) ? x : mg;
+        int n;
+        double inc;
+        if (lean) {
+            const uint64_t xb = d2u(x);
+            const uint32_t ea = (uint32_t)(xb >> 52);
+            const bool can = ea > ed;
+            const uint64_t pkb = (uint64_t)ea << 52;
+            const double pk = u2d(pkb);
+            const double top = ea == 1034u ? 4091.9999999999995 : u2d(pkb | 0x000fffffffffffffull);
+            const double dk = (cstep + pk) - pk;
+            const bool odd_tie = (ea == e_tie) & ((uint32_t)xb & 1u);
+            const double t = top - x;
+            double q = t * inv_c;
+            const double qmax = (double)(N - i);
+            q = q > qmax ? qmax : q;
+            n = (int)q;
+            n -= (fma_exact(-(double)n, dk, t) < 0.0) ? 1 : 0;
+            n = n < 0 ? 0 : n;
+            n = (can & !odd_tie & (t >= 0.0)) ? n : 0;
+            inc = dk;
+            // the batch's first state above its binade's floor, its last one below the ceiling (or the wrap threshold); a state at or
+            // below the step's own binade (no batch) is within one step of zero: it is the residual of a wrap, counted above
+            const double m1 = x - pk;
+            const double room = fma_exact(-(double)n, dk, t);
+            mg = (can && m1 < mg) ? m1 : mg;
+            mg = (can && room < mg) ? room : mg;
+        } else if (cstep >= 9.5367431640625e-07) {
+            const Batch b = nco_batch(x, cstep, N - i, 4092.0, inv_c);
+            n = b.n;
+            inc = b.inc;
+        } else {
+            n = 0;
+            inc = 0.0;
+        }
+        while (next_cp <= i + n && next_cp < N) {
+            emit(c, fma_exact((double)(next_cp - i), inc, x), ibit, o.flipped);
+            ++c;
+            next_cp += R;
+        }
+        x = fma_exact((double)n, inc, x);
+        i += n;
+        if (i < N) {
+            x = x + cstep;
+            ++i;
+            if (lean) {  // the state a genuine step lands on: above its binade's floor, below its ceiling
+                const uint64_t ub = d2u(x) & 0x7ff0000000000000ull;
+                const double fl_ = u2d(ub), m1 = x - fl_, m2 = (fl_ + fl_) - x;
+                const double m = m1 < m2 ? m1 : m2;
+                const double m4 = x < 4092.0 ? 4092.0 - x : x - 4092.0;
+                mg = m < mg ? m : mg;
+                mg = m4 < mg ? m4 : mg;
+            }
+        }
+    }
+    o.x = x;
+    o.ibit = ibit;
+    o.margin = mg;
+    return o;
+}
+
+// An anchor / a claim of the code chain: the wrap at the top of local sample w (w = -1: the epoch's start state, PRE-check) left the
+// phase r, the symbol counter ib and the flip flag fl.
+struct CodeEvent {
+    int w;
+    double r;
+    int ib, fl;
+};
+
+// Ideal-arithmetic guess of the last wrap strictly in front of local sample n (n >= 1): y(m) = x0 + m c is the unwrapped pre-check
+// phase before sample m, wrap j fires at the top of the first sample with y >= 4092 j.  Residual snapped to the 2^-41 grid every
+// true residual lives on.  Returns the epoch's start when there is none.
+GAL_HD CodeEvent code_ideal_anchor(double x0, int ib0, double cstep, int n)
+{
+    CodeEvent a;
+    a.w = -1;
+    a.r = x0;
+    a.ib = ib0;
+    a.fl = 0;
+    const double yl = x0 + (double)(n - 1) * cstep;
+    const double j = __builtin_floor(yl * (1.0 / 4092.0));
+    if (!(j >= 1.0) || !(cstep > 0.0)) return a;
+    double w = __builtin_ceil((4092.0 * j - x0) / cstep);
+    w = w < 0.0 ? 0.0 : w;
+    w = w > (double)(n - 1) ? (double)(n - 1) : w;
+    const double res = (x0 + w * cstep) - 4092.0 * j;
+    a.w = (int)w;
+    a.r = (res + 3072.0) - 3072.0;
+    const int ib = ib0 + (int)j;
+    a.fl = ib >= 500 ? 1 : 0;
+    a.ib = ib >= 500 ? ib - 500 : ib;
+    return a;
+}
+
+// What the stitch does with leg k once the claim `prev` of the legs in front of it is TRUE: 0 = the leg was walked from that very
+// anchor (exact as it stands), 1 = same wrap, residual off by *delta, and the walk's margin covers it: every state of the leg is
+// the walked one + *delta, 2 = walk it again from `prev`.
+GAL_HD int code_leg_accept(const CodeEvent &anchor, const CodeEvent &prev, double margin, bool tie_prone, double *delta)
+{
+    *delta = 0.0;
+    if (anchor.w != prev.w || anchor.ib != prev.ib || anchor.fl != prev.fl) return 2;
+    if (d2u(anchor.r) == d2u(prev.r)) return 0;
+    if (anchor.w < 0) return 2;  // (two different start states: cannot happen, the start is given)
+    const double dl = prev.r - anchor.r;  // both multiples of 2^-41 below one step: exact
+    const double adl = dl < 0.0 ? -dl : dl;
+    if (tie_prone || !(adl + 9.094947017729282e-13 /* 2^-40 */ < margin)) return 2;
+    *delta = dl;
+    return 1;
+}
+
+// One leg of the code chain, walked from `anchor`: silently up to the leg's first sample n0 (no checkpoints), then through its nl
+// samples, emitting the pre-check state of every chunk start (emit(chunk within the leg, x, ibit, flipped since the epoch start)).
+struct CodeLeg {
+    CodeEvent claim;  // the last wrap seen (the anchor itself if none): what the next leg must be anchored at
+    double x;         // pre-check state after the leg's last sample
+    int ibit, fl;
+    double margin;
+};
+
+template <class Emit>
+GAL_HD CodeLeg code_leg_walk(const CodeEvent &anchor, double cstep, double inv_c, int n0, int nl, int R, Emit emit)
+{
+    const int start = anchor.w < 0 ? 0 : anchor.w;
+    const int ns = n0 - start;
+    const CodeTrack t1 = code_walk_track(anchor.r, anchor.ib, cstep, inv_c, ns, R, ns, [](int, double, int, int) {});
+    const int fl1 = anchor.fl | t1.flipped;
+    const CodeTrack t2 = code_walk_track(t1.x, t1.ibit, cstep, inv_c, nl, R, 0,
+                                         [&](int c, double x, int ib, int fl) { emit(c, x, ib, fl1 | fl); });
+    CodeLeg o;
+    o.claim = anchor;
+    if (t1.last_w >= 0) {
+        o.claim.w = start + t1.last_w;
+        o.claim.r = t1.last_r;
+        o.claim.ib = t1.last_ib;
+        o.claim.fl = anchor.fl | t1.last_fl;
+    }
+    if (t2.last_w >= 0) {
+        o.claim.w = n0 + t2.last_w;
+        o.claim.r = t2.last_r;
+        o.claim.ib = t2.last_ib;
+        o.claim.fl = fl1 | t2.last_fl;
+    }
+    o.x = t2.x;
+    o.ibit = t2.ibit;
+    o.fl = fl1 | t2.flipped;
+    o.margin = t1.margin < t2.margin ? t1.margin : t2.margin;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Mean advance per sample of the ROUNDED carrier chain: inside the binade [2^-j, 2^-j+1) every step adds
 // RN_g(d) (g the binade's ulp) rather than d, and a phase sweeping (0,1) spends the fraction 2^-j of its
 // steps there.  Used only for the first-pass GUESSES of the speculative stitcher: with the systematic part of

@@ -16,6 +16,7 @@
 #include <vector>
 
 #define GAL_SYNTH_NO_SIZED_MACROS 1
+#include "nco_walk.h"
 #include "synth_dev.h"
 #include "e1_tables.inc"
 
@@ -74,7 +75,6 @@ int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch, int accumu
 void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hipStream_t st);
 void galk_touch(hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
-void galk_launch_carr_guess(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_verify_carr(const DevPlan *P, hipStream_t st);
@@ -145,6 +145,66 @@ constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + 
 
 }  // namespace
 
+// First guesses of the speculative carrier walk (synth_kernels.hip: k_walk_carr, first pass): per slot and epoch the IDEAL-arithmetic
+// phase at the epoch start (mean advance of the rounded chain, nco_walk.h: eff_step) and the ideal last wrap event -- global sample
+// index and residual -- at or before that epoch start, or the chain root.  Nothing here has to be exact: the stitcher accepts a leg
+// only through bitwise equality with the verified chain; the guesses decide how many legs can be accepted by translation.  Epoch-major
+// [E][S] (a prefix computation: a range execute's cut plan sees the same values).  Rounds 1-4 ran this as a kernel (k_carr_guess, a
+// block scan per slot: 22 us at the head of the chain every batch waits for); on the host it is ~100 flops per record at plan time.
+static double guess_reduce(double x, double d)
+{
+    // the reference keeps the phase in (-1, 1) with the sign of the step it was last wrapped with (src/galileo-sdr.cpp:531-532)
+    x = x - std::trunc(x);
+    if (x != 0.0 && d != 0.0 && ((x < 0.0) != (d < 0.0))) x += d < 0.0 ? -1.0 : 1.0;
+    return x;
+}
+
+static void carrier_guesses(int E, int S, int N, const int *prn, const uint32_t *flags, const double *p0, const double *dstep,
+                            const gal_chan_state_t *state_in, double *pguess, long long *gss_w, double *gss_r)
+{
+    for (int s = 0; s < S; ++s) {
+        double run = 0.0;        // unreduced phase (fraction) after the epoch before, counted from the last restart
+        int kind = 0;            // last event before this epoch: 0 nothing yet, 1 defined (a wrap or a root), 2 chain broken (idle epoch)
+        long long ev_w = 0;
+        double ev_r = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const size_t i = (size_t)e * S + s;
+            const bool on = prn[i] > 0;
+            const bool restart = (flags[i] & GAL_CH_RESTART) != 0;
+            const bool reset = on && (restart || e == 0);
+            const double start = restart ? p0[i] : state_in[s].carr_phase;
+            const double d = galnco::eff_step(dstep[i]);
+            double adv = on ? (double)N * d : 0.0;  // idle epochs leave the phase alone
+            adv = adv - std::trunc(adv);
+            const double mine = reset ? start : guess_reduce(run, d);
+            run = reset ? start + adv : run + adv;
+            run = run - std::trunc(run);  // (only the fraction matters; keeps the sums small)
+            if (on) {
+                const bool use_root = reset || kind != 1;  // (a chain without a root is rejected by gal_synth_plan)
+                pguess[i] = mine;
+                gss_w[i] = use_root ? (long long)e * N : ev_w;
+                gss_r[i] = use_root ? mine : ev_r;
+            }
+            // the last event up to the END of this epoch: a wrap inside it, else its root, else what came before
+            if (!on) {
+                kind = 2;
+            } else {
+                int om;
+                double rr;
+                if (galnco::ideal_last_wrap(mine, d, N, &om, &rr)) {
+                    kind = 1;
+                    ev_w = (long long)e * N + om;
+                    ev_r = rr;
+                } else if (reset) {
+                    kind = 1;
+                    ev_w = (long long)e * N;
+                    ev_r = mine;
+                }
+            }
+        }
+    }
+}
+
 struct gal_synth {
     gal_synth_cfg_t cfg{};
     int device = 0;
@@ -194,6 +254,8 @@ struct gal_synth {
     uint32_t *h_flag = nullptr;  // = (uint32_t *)(h_ctr + 2 * CTR_COUNT): sequence number of the last batch whose record is complete
     uint32_t seq = 0;            // sequence number of the batch in flight
     int64_t legs_walked = 0, legs_translated = 0, n_fallbacks = 0;  // last finish(): carrier legs walked / translated
+    std::vector<int64_t> act_prefix;  // [E + 1] active records in the epochs before e (a first walker pass walks W legs of each)
+    int64_t first_pass_legs = 0;      // legs walked by the first passes of the batch in flight (every active leg; not counted on the device)
     gal_chan_state_t *h_state = nullptr;  // pinned [S]
     bool state_fetched = false;           // h_state holds the state of the batch in flight
     gal_synth_stats_t stats{};
@@ -712,10 +774,11 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
     const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
     const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4);
+    // first guesses of the speculative carrier walk (carrier_guesses below: host, O(E * S); rounds 1-4: a kernel in front of the chain)
+    const size_t o_pguess = take(ES * 8), o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t up_bytes = off;
     // zeroed region (ONE memset): checkpoints, first guesses, leg records that are read before they are written
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
-    const size_t o_pguess = take(ES * 8);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmr = take(LEGS * S * 8);
     const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S), o_risk = take(LEGS * S);
     const size_t zero_end = off;
@@ -723,7 +786,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_state_out = take(sizeof(gal_chan_state_t) * S);
     const size_t o_pcur = take(ES * GAL_PAGE_WORDS * 4);
     const size_t o_flip = take(ES);
-    const size_t o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t o_marg = take(LEGS * S * 8), o_shift = take(LEGS * S * 8), o_tpos = take(LEGS * S * 8),
                  o_tdir = take(LEGS * S);
     const size_t o_ctr = take(CTR_COUNT * 4);
@@ -869,6 +931,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         if (state_in) memcpy(st, state_in, sizeof(gal_chan_state_t) * S);
         for (int i = 0; i < S; ++i)
             if (st[i].carr_phase == 0.0) st[i].carr_phase = 0.0;
+        carrier_guesses(E, S, N, (const int *)(up + o_prn), (const uint32_t *)(up + o_flags), (const double *)(up + o_p0),
+                        (const double *)(up + o_dstep), st, (double *)(up + o_pguess), (long long *)(up + o_gssw), (double *)(up + o_gssr));
         memcpy(up + o_act, act_g.data(), act_g.size());
         memcpy(up + o_nact, nact_g.data(), nact_g.size() * sizeof(int));
         hipStream_t st_up = handle_stream(h);
@@ -879,6 +943,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         HIP_TRY(hipStreamSynchronize(st_up));
     }
     h->nact_max = nact_max;
+    h->act_prefix.assign((size_t)E + 1, 0);
+    for (int e = 0; e < E; ++e) h->act_prefix[e + 1] = h->act_prefix[e] + nact_all[e];
     memset(&h->stats, 0, sizeof(h->stats));
     h->stats.n_epochs = E;
     h->stats.n_active_max = nact_max;
@@ -997,13 +1063,13 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
         galk_launch_pages(P, h->aux_stream);
         HIP_TRY(hipEventRecord(h->ev_aux, h->aux_stream));
     }
-    galk_launch_carr_guess(P, ws);
     int n_passes = h->enq_passes;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;
 #endif
+    h->first_pass_legs = h->act_prefix[h->Pw.E] * h->P.W;
     for (int pass = 0; pass < n_passes; ++pass) {
-        galk_launch_walk_carr(P, pass == 0, ws);
+        galk_launch_walk_carr(P, pass == 0, ws);  // (the first one also resets the batch's counters)
         galk_launch_carr_scan(P, ws);
     }
     // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the carrier chain:
@@ -1166,14 +1232,14 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
         DevPlan Pw = *P;
         Pw.translate = 0;
         const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
-        galk_launch_carr_guess(&Pw, st);  // (resets the counters)
-        int first = 1;
+        int first = 1;  // (the first walk of a chain resets the batch's counters)
         do {
             if (!first && ctr_walk[CTR_PASSES] >= max_passes)
                 return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes", ctr_walk[CTR_PASSES]);
             for (int k = 0; k < 2; ++k) {
                 galk_launch_walk_carr(&Pw, first, st);
                 galk_launch_carr_scan(&Pw, st);
+                if (first) h->first_pass_legs += h->act_prefix[h->Pw.E] * h->P.W;
                 first = 0;
             }
             HIP_TRY(hipMemcpyAsync(ctr_walk, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1224,7 +1290,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
     h->stats.ms_synth = ms_synth;
     h->stats.ms_repair = h->stats.synth_runs == 1 ? ms_repair : 0.0f;
     h->stats.window_mode = h->P.rw;
-    h->legs_walked = ctr_end[CTR_WALKS];
+    h->legs_walked = h->first_pass_legs + ctr_end[CTR_WALKS];  // (a first pass walks every active leg: counted here, not on the device)
     h->legs_translated = ctr_end[CTR_SHIFTS];
     copy_stats(h, stats, stats_bytes);
     if (state_out) {

@@ -48,9 +48,9 @@ struct DevPlan {
     uint8_t *flip_in;     // [E][S] symbol counter wrapped inside this epoch
 
     // carrier speculation (leg arrays are slot-major, [S][LEGS])
-    double *pguess;      // [S][E] ideal-arithmetic phase at epoch start
-    long long *gss_w;    // [S][E] ideal last wrap (or root) at or before the epoch start: global sample index
-    double *gss_r;       // [S][E] ... and its residual
+    double *pguess;      // [E][S] ideal-arithmetic phase at epoch start (host: synth_api.cpp, carrier_guesses)
+    long long *gss_w;    // [E][S] ideal last wrap (or root) at or before the epoch start: global sample index
+    double *gss_r;       // [E][S] ... and its residual
     long long *anc_w;    // anchor of the leg: global sample index ...
     double *anc_r;       // ... and the phase before that sample (a wrap residual, or the chain root)
     long long *clm_w;    // claim: last wrap seen by the leg's last walk (-1: none)

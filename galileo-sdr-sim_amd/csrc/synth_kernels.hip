@@ -51,6 +51,16 @@ using namespace galdev;
 #define GAL_TU_FAMILY(k) (GAL_TU == (k))
 #endif
 
+// the walker kernels raise their waves' issue priority (A/B: -DGAL_WALK_PRIO=0 leaves it alone)
+#ifndef GAL_WALK_PRIO
+#define GAL_WALK_PRIO 3
+#endif
+#if GAL_WALK_PRIO > 0
+#define GAL_WALK_SETPRIO() __builtin_amdgcn_s_setprio(GAL_WALK_PRIO)
+#else
+#define GAL_WALK_SETPRIO() ((void)0)
+#endif
+
 #ifdef GAL_TEST_HOOKS
 #define GAL_HOOK_BAD_LEG 5  // (slot 0, epoch 0, leg 5) receives a wrong translation when P.translate == 2
 #endif
@@ -61,7 +71,7 @@ using namespace galdev;
 // ------------------------------------------------------------------------------------------------
 __global__ void k_walk_code(DevPlan P)
 {
-    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
+    GAL_WALK_SETPRIO();  // latency-bound: win issue arbitration against a co-running k_synth
     // a wave = 64 consecutive epochs of ONE slot (similar trip counts, idle slots leave as whole waves)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.E * P.S) return;
@@ -102,143 +112,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return u2d(((uint64_t)hi << 32) | lo);
 }
 
-// k_carr_guess: ideal (unrounded-chain) phase at every EPOCH start and the ideal last wrap before it -- first guesses
-// for the speculative stitcher, nothing here has to be exact.  One 256-thread block per slot, one epoch per thread
-// (tiles of 256 epochs with a carry): (1) the phase recurrence p <- frac(p + N d_e), restarted at (re)allocations, is a
-// segmented prefix sum of the fractional advances (round 1 walked the epochs one by one in a single wave: 0.08 ms of
-// the 0.5 ms a lone handle waits for its walker chain); (2) every thread predicts the last wrap inside its own epoch
-// in closed form; (3) a "last one that speaks" scan turns those into the last wrap (or chain root) at or before every
-// epoch start.
 // 256 threads = one wave per SIMD: beside a running k_synth (which fills every SIMD's register file) a block can start
 // as soon as ONE synthesis block retires; a 1024-thread block would have to wait for an entirely empty CU
 #define GUESS_THREADS 256
-__device__ __forceinline__ double guess_reduce(double x, double d)
-{
-    // the reference keeps the phase in (-1, 1) with the sign of the step it was last wrapped with (:531-532)
-    x = x - __builtin_trunc(x);
-    if (x != 0.0 && d != 0.0 && ((x < 0.0) != (d < 0.0))) x += d < 0.0 ? -1.0 : 1.0;
-    return x;
-}
-
-__global__ __launch_bounds__(GUESS_THREADS) void k_carr_guess(DevPlan P)
-{
-    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
-    __shared__ double s_v[GUESS_THREADS], s_r[GUESS_THREADS];
-    __shared__ int s_f[GUESS_THREADS], s_kind[GUESS_THREADS];
-    __shared__ long long s_w[GUESS_THREADS];
-    const int s = blockIdx.x;
-    const int t = threadIdx.x;
-    const double start0 = P.state_in[s].carr_phase;
-    double c_val = 0.0;  // unreduced phase after the last epoch of the previous tile
-    int c_kind = 0;      // carry of the event scan: kind 0 nothing yet, 1 defined, 2 chain broken
-    long long c_w = 0;
-    double c_r = 0.0;
-    for (int base = 0; base < P.E; base += GUESS_THREADS) {
-        const int e = base + t;
-        const bool in = e < P.E;
-        const int idx = (in ? e : 0) * P.S + s;
-        const int prn = in ? P.prn[idx] : 0;
-        const uint32_t fl = P.flags[idx];
-        const double ds_raw = P.dstep[idx];
-        const bool reset = prn > 0 && ((fl & GAL_CH_RESTART) || e == 0);
-        const double p0 = (fl & GAL_CH_RESTART) ? P.p0[idx] : start0;
-        const double d = eff_step(ds_raw);  // mean advance of the rounded chain (nco_walk.h)
-        double adv = prn > 0 ? (double)P.N * d : 0.0;  // idle epochs leave the phase alone
-        adv = adv - __builtin_trunc(adv);
-        // ---- (1) inclusive segmented sum: value after epoch e, counted from the last restart
-        s_v[t] = reset ? p0 + adv : adv;
-        s_f[t] = reset ? 1 : 0;
-        __syncthreads();
-        for (int off = 1; off < GUESS_THREADS; off <<= 1) {
-            double v2 = 0.0;
-            int f2 = 0;
-            const bool take = t >= off && s_f[t] == 0;
-            if (take) {
-                v2 = s_v[t - off];
-                f2 = s_f[t - off];
-            }
-            __syncthreads();
-            if (take) {
-                s_v[t] += v2;
-                s_f[t] = f2;
-            }
-            __syncthreads();
-        }
-        // unreduced phase at the START of my epoch: what the epoch before left (or the carry of the previous tile)
-        double before = c_val;
-        if (t > 0) before = s_f[t - 1] ? s_v[t - 1] : c_val + s_v[t - 1];
-        const double mine = reset ? p0 : guess_reduce(before, d);
-        const double tile_end = s_f[GUESS_THREADS - 1] ? s_v[GUESS_THREADS - 1] : c_val + s_v[GUESS_THREADS - 1];
-        __syncthreads();
-        c_val = tile_end - __builtin_trunc(tile_end);  // (only the fraction matters; keeps the sums small)
-        // ---- (2) the last event up to the END of my epoch: a wrap inside it, else its root, else nothing
-        int kind = 0;
-        long long w = 0;
-        double r = 0.0;
-        if (in && prn <= 0) kind = 2;
-        if (prn > 0) {
-            int om;
-            double rr;
-            if (ideal_last_wrap(mine, d, P.N, &om, &rr)) {
-                kind = 1;
-                w = (long long)e * P.N + om;
-                r = rr;
-            } else if (reset) {
-                kind = 1;
-                w = (long long)e * P.N;
-                r = mine;
-            }
-        }
-        // ---- (3) "the last one that speaks": inclusive scan, then look at the thread before me
-        s_kind[t] = kind;
-        s_w[t] = w;
-        s_r[t] = r;
-        __syncthreads();
-        for (int off = 1; off < GUESS_THREADS; off <<= 1) {
-            int k2 = 0;
-            long long w2 = 0;
-            double r2 = 0.0;
-            const bool take = t >= off && s_kind[t] == 0;
-            if (take) {
-                k2 = s_kind[t - off];
-                w2 = s_w[t - off];
-                r2 = s_r[t - off];
-            }
-            __syncthreads();
-            if (take) {
-                s_kind[t] = k2;
-                s_w[t] = w2;
-                s_r[t] = r2;
-            }
-            __syncthreads();
-        }
-        int xk = c_kind;
-        long long xw = c_w;
-        double xr = c_r;
-        if (t > 0 && s_kind[t - 1] != 0) {
-            xk = s_kind[t - 1];
-            xw = s_w[t - 1];
-            xr = s_r[t - 1];
-        }
-        if (in && prn > 0) {
-            P.pguess[(size_t)s * P.E + e] = mine;
-            const bool use_root = reset || xk != 1;  // (a chain without a root is rejected on the host)
-            P.gss_w[(size_t)s * P.E + e] = use_root ? (long long)e * P.N : xw;
-            P.gss_r[(size_t)s * P.E + e] = use_root ? mine : xr;
-        }
-        if (s_kind[GUESS_THREADS - 1] != 0) {  // block-uniform: the last speaker of this tile is the carry of the next
-            c_kind = s_kind[GUESS_THREADS - 1];
-            c_w = s_w[GUESS_THREADS - 1];
-            c_r = s_r[GUESS_THREADS - 1];
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) {
-        // the batch's counters start here (no memset in front of the chain); UNVERIFIED != 0 forces the first walk
-        P.ctr[threadIdx.x] = threadIdx.x == CTR_UNVERIFIED ? 1 : 0;
-    }
-}
-
+// (The first guesses of the speculation -- ideal-arithmetic phase at every epoch start, ideal last wrap before it -- are computed by
+// gal_synth_plan on the host since round 5, synth_api.cpp: carrier_guesses; rounds 1-4: a kernel here, k_carr_guess.)
 __device__ __forceinline__ int d_residue_u52(double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); }
 
 // TRANSLATED acceptance of a leg (called by the stitchers, k_carr_scan / k_scanm_apply, for a leg whose anchor is the
@@ -302,8 +180,15 @@ __device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, con
 // predicted by ideal arithmetic (k_carr_guess / ideal_last_wrap).
 __global__ void k_walk_carr(DevPlan P, int first)
 {
-    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
-    if (P.ctr[CTR_UNVERIFIED] == 0) return;  // converged: remaining enqueued passes are no-ops
+    GAL_WALK_SETPRIO();  // latency-bound: win issue arbitration against a co-running k_synth
+    if (first) {
+        // the batch's counters start here (no memset, no kernel in front of the chain: rounds 1-4 had k_carr_guess do it);
+        // UNVERIFIED != 0 makes the stitch behind this pass work.  Nothing else in a first pass reads or writes them (the legs it
+        // walks -- every active one -- are counted on the host)
+        if (blockIdx.x == 0 && threadIdx.x < CTR_COUNT) P.ctr[threadIdx.x] = threadIdx.x == CTR_UNVERIFIED ? 1 : 0;
+    } else if (P.ctr[CTR_UNVERIFIED] == 0) {
+        return;  // converged: remaining enqueued passes are no-ops
+    }
     // a wave = 64 consecutive legs of ONE slot: similar Doppler, hence similar trip counts (a wave runs as long
     // as its slowest lane), idle slots are whole waves that leave at once, and the leg arrays are read coalesced
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,12 +207,12 @@ __global__ void k_walk_carr(DevPlan P, int first)
         // first pass: anchor from ideal arithmetic (predicted last wrap at or before the leg start)
         int om;
         double rr;
-        if (ideal_last_wrap(P.pguess[(size_t)s * P.E + e], eff_step(P.dstep[idx]), w * L, &om, &rr)) {
+        if (ideal_last_wrap(P.pguess[idx], eff_step(P.dstep[idx]), w * L, &om, &rr)) {  // (guess arrays: epoch-major, from the host)
             cur = (long long)e * P.N + om;
             p = rr;
         } else {
-            cur = P.gss_w[(size_t)s * P.E + e];
-            p = P.gss_r[(size_t)s * P.E + e];
+            cur = P.gss_w[idx];
+            p = P.gss_r[idx];
         }
         P.anc_w[li] = cur;
         P.anc_r[li] = p;
@@ -385,8 +270,10 @@ __global__ void k_walk_carr(DevPlan P, int first)
     P.tpos[li] = tpos;
     P.dirty[li] = 0;
     P.risk[li] = 0;  // walked, not translated
-    const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
-    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
+    if (!first) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
+    }
 }
 
 // k_verify_carr: legs of the executed epochs walked once more, genuinely and in closed form, from their own first checkpoint:
@@ -650,7 +537,7 @@ __device__ __forceinline__ void stitch_publish(const DevPlan &P, const int t, co
 #define SCAN_THREADS 1024
 __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 {
-    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
+    GAL_WALK_SETPRIO();  // latency-bound: win issue arbitration against a co-running k_synth
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_kind[SCAN_THREADS];
     __shared__ long long s_w[SCAN_THREADS];
@@ -843,7 +730,7 @@ __device__ __forceinline__ void scanm_range(const DevPlan &P, int g, int *i0, in
 // phase A: claim summary of my legs + block-local "last one that speaks" scan
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_claims(DevPlan P, ScanM M)
 {
-    __builtin_amdgcn_s_setprio(3);
+    GAL_WALK_SETPRIO();
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_kind[SCANM_THREADS];
     __shared__ long long s_w[SCANM_THREADS];
@@ -958,7 +845,7 @@ __device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, in
 // phase B: fold my legs (segmented AND + D map) + block-local inclusive scan of the folds
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M)
 {
-    __builtin_amdgcn_s_setprio(3);
+    GAL_WALK_SETPRIO();
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_fv[SCANM_THREADS], s_v[SCANM_THREADS], s_ic[SCANM_THREADS];
     __shared__ double s_K[SCANM_THREADS], s_c[4][SCANM_THREADS];
@@ -1050,7 +937,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M
 // phase C: replay my legs with the true carries and apply (sweep 3 of k_carr_scan)
 __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM M)
 {
-    __builtin_amdgcn_s_setprio(3);
+    GAL_WALK_SETPRIO();
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
     __shared__ int s_unver, s_rewalk, s_shifts, s_last;
     const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
@@ -1198,7 +1085,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
 // critical path of a lone handle).
 __global__ __launch_bounds__(GUESS_THREADS) void k_pages(DevPlan P)
 {
-    __builtin_amdgcn_s_setprio(3);  // latency-bound: win issue arbitration against a co-running k_synth
+    GAL_WALK_SETPRIO();  // latency-bound: win issue arbitration against a co-running k_synth
     __shared__ int s_ev[GUESS_THREADS];
     const int s = blockIdx.x;
     const int t = threadIdx.x;
@@ -2373,11 +2260,6 @@ extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 {
     const int n = P->E * P->S;
     hipLaunchKernelGGL(k_walk_code, dim3((n + 63) / 64), dim3(64), 0, st, *P);
-}
-
-extern "C" void galk_launch_carr_guess(const DevPlan *P, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_carr_guess, dim3(P->S), dim3(GUESS_THREADS), 0, st, *P);
 }
 
 extern "C" void galk_launch_verify_carr(const DevPlan *P, hipStream_t st)

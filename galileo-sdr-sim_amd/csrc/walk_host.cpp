@@ -65,6 +65,59 @@ void galwalk_code(double x, int ibit, double c, int N, int R, double *cpx, uint3
     *flipped = e.flipped;
 }
 
+// The code chain of one epoch in `legs` legs, as k_walk_code runs it on the device (synth_kernels.hip): every leg walked from its
+// ideal-arithmetic anchor, then the stitch from leg to leg -- accepted as it stands, translated, or walked again from the true
+// anchor.  stats[0..2]: legs accepted as walked / translated / walked again.  force_tie != 0: treat the step as tie-prone.
+void galwalk_code_legs(double x0, int ib0, double c, int N, int R, int legs, double *cpx, uint32_t *cpi, double *xend, int *ibend,
+                       int *flipped, int *stats, int force_tie)
+{
+    const int nchunks = (N + R - 1) / R;
+    const int Lk = (nchunks + legs - 1) / legs;
+    const bool tie = code_tie_prone(c) || force_tie;
+    std::vector<CodeEvent> anc(legs);
+    std::vector<CodeLeg> leg(legs);
+    std::vector<int> have(legs, 0);
+    auto walk = [&](int k) {
+        const int n0 = k * Lk * R;
+        const int n1 = std::min(N, (k + 1) * Lk * R);
+        leg[k] = code_leg_walk(anc[k], c, 1.0 / c, n0, n1 - n0, R, [&](int ci, double x, int ib, int fl) {
+            cpx[k * Lk + ci] = x;
+            cpi[k * Lk + ci] = (uint32_t)ib | ((uint32_t)fl << 16);
+        });
+    };
+    for (int k = 0; k < legs; ++k) {  // (on the device: all legs at once)
+        if (k * Lk * R >= N) continue;
+        have[k] = 1;
+        if (k == 0) {
+            anc[k].w = -1; anc[k].r = x0; anc[k].ib = ib0; anc[k].fl = 0;
+        } else {
+            anc[k] = code_ideal_anchor(x0, ib0, c, k * Lk * R);
+        }
+        walk(k);
+    }
+    stats[0] = stats[1] = stats[2] = 0;
+    int last = 0;
+    for (int k = 1; k < legs; ++k) {
+        if (!have[k]) continue;
+        double dl;
+        const int how = code_leg_accept(anc[k], leg[k - 1].claim, leg[k].margin, tie, &dl);
+        stats[how] += 1;
+        if (how == 1) {
+            const int n0 = k * Lk * R, n1 = std::min(N, (k + 1) * Lk * R);
+            for (int ci = 0; ci * R < n1 - n0; ++ci) cpx[k * Lk + ci] += dl;
+            leg[k].x += dl;
+            leg[k].claim.r += dl;
+        } else if (how == 2) {
+            anc[k] = leg[k - 1].claim;
+            walk(k);
+        }
+        last = k;
+    }
+    *xend = leg[last].x;
+    *ibend = leg[last].ibit;
+    *flipped = leg[last].fl;
+}
+
 void galwalk_code_brute(double x, int ibit, double c, int N, int R, double *cpx, uint32_t *cpi, double *xend,
                         int *ibend, int *flipped)
 {

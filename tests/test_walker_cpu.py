@@ -26,6 +26,7 @@ def W(pkg):
     lib.galwalk_carr_iters.argtypes = [d, d, i]
     lib.galwalk_code.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
     lib.galwalk_code_brute.argtypes = [d, i, d, i, i, vp, vp, vp, vp, vp]
+    lib.galwalk_code_legs.argtypes = [d, i, d, i, i, i, vp, vp, vp, vp, vp, vp, i]
     lib.galwalk_spec_wrap.restype = i
     lib.galwalk_spec_wrap.argtypes = [i, i, i, i, vp, vp, vp, vp, d, i, vp, vp, vp, i, i, vp, i, vp]
     return lib
@@ -128,6 +129,71 @@ def test_code_small_steps_are_stepped_one_by_one(W):
         (ax, ai, axe, aie, afl), (bx, bi, bxe, bie, bfl) = _code_pair(W, x, int(rng.integers(0, 500)), c, 60000, 1024)
         assert np.array_equal(ax.view(np.uint64), bx.view(np.uint64)) and np.array_equal(ai, bi), (x, c)
         assert (np.float64(axe).view(np.uint64), aie, afl) == (np.float64(bxe).view(np.uint64), bie, bfl), (x, c)
+
+
+def _code_legs(W, x, ib, c, N, R, legs, force_tie=0):
+    nc = (N + R - 1) // R
+    cx, ci = np.zeros(nc), np.zeros(nc, dtype=np.uint32)
+    xe, ie, fl = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+    st = np.zeros(3, dtype=np.int32)
+    W.galwalk_code_legs(x, ib, c, N, R, legs, cx.ctypes.data, ci.ctypes.data, ctypes.byref(xe), ctypes.byref(ie), ctypes.byref(fl),
+                        st.ctypes.data, force_tie)
+    bx, bi = np.zeros(nc), np.zeros(nc, dtype=np.uint32)
+    bxe, bie, bfl = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+    W.galwalk_code_brute(x, ib, c, N, R, bx.ctypes.data, bi.ctypes.data, ctypes.byref(bxe), ctypes.byref(bie), ctypes.byref(bfl))
+    ok = (np.array_equal(cx.view(np.uint64), bx.view(np.uint64)) and np.array_equal(ci, bi) and
+          (np.float64(xe.value).view(np.uint64), ie.value, fl.value) == (np.float64(bxe.value).view(np.uint64), bie.value, bfl.value))
+    return ok, st
+
+
+def test_code_chain_in_legs(W):
+    """The code chain of an epoch in speculative legs (nco_walk.h: code_leg_walk / code_ideal_anchor / code_leg_accept, the host
+    statement of k_walk_code's lanes and their in-wave stitch): every leg walked from its ideal-arithmetic anchor, then accepted as
+    walked, translated by the anchor's error, or walked again -- checkpoints, symbol counters, flip flags and end state must be
+    brute-force stepping's, bit for bit, whatever the stitch decided; at the reference's geometry nearly every leg is translated."""
+    rng = np.random.default_rng(41)
+    tot = np.zeros(3, dtype=np.int64)
+    for t in range(160):
+        f = rng.uniform(-6000, 6000)
+        c = (1.023e6 + f * 0.0006493506493506494) * DELT
+        x = rng.uniform(0, 4092) if t % 5 else rng.uniform(4092, 6138)  # (a wrap pending at the epoch's first sample)
+        ib = int(rng.integers(0, 500)) if t % 4 else int(rng.integers(470, 500))
+        legs = int(rng.choice([2, 4, 8, 16]))
+        N, R = (260000, 1024) if t % 3 else (int(rng.integers(3000, 90000)), int(rng.choice([256, 416, 1024, 1040])))
+        ok, st = _code_legs(W, x, ib, c, N, R, legs)
+        assert ok, (x, ib, c, N, R, legs)
+        tot += st
+    assert tot[1] > 4 * (tot[0] + tot[2]), tot  # translation is the rule
+    # other sample rates (steps 0.04 .. 1 chip per sample), few-bit steps (every binade somebody's tie binade), tie-prone steps
+    for rate, N in [(25e6, 250000), (2.0e6, 50000), (4.092e6, 40000), (1.023e6, 30000), (8e6, 80000)]:
+        for k in range(12):
+            c = 1.023e6 / rate * (1.0 + rng.uniform(-3e-6, 3e-6))
+            if k % 3 == 0:
+                c = float(np.round(c * 2.0 ** (20 + 3 * (k // 3))) / 2.0 ** (20 + 3 * (k // 3)))  # a multiple of 2^-20 .. 2^-29: tie-prone
+            ok, st = _code_legs(W, rng.uniform(0, 4092), int(rng.integers(0, 500)), c, N, 256, int(rng.choice([2, 4, 8])))
+            assert ok, (rate, c)
+    # every leg walked again (the tie-prone path forced onto ordinary steps): the serial fallback is exact too
+    for t in range(20):
+        c = (1.023e6 + rng.uniform(-3500, 3500) * 0.0006493506493506494) * DELT
+        ok, st = _code_legs(W, rng.uniform(0, 4092), int(rng.integers(0, 500)), c, 100000, 1024, 4, force_tie=1)
+        assert ok and st[1] == 0, st
+
+
+def test_code_leg_translation_respects_its_margin(W):
+    """States within a few ulps of a binade boundary or of the wrap threshold: the margin must send such legs back to be walked --
+    phases placed so that the second leg's first wrap residual is tiny (a shift the size of the anchor's error would un-wrap it) and
+    so that a crossing into [2048, 4096) lands within 2^-38 of 2048."""
+    rng = np.random.default_rng(43)
+    n_bad = 0
+    for t in range(300):
+        c = (1.023e6 + rng.uniform(-3500, 3500) * 0.0006493506493506494) * DELT
+        k = int(rng.integers(1, 30000))
+        # x0 such that the ideal phase k samples on sits a hair above 4092 (t even) or above 2048 (t odd)
+        target = (4092.0 if t % 2 == 0 else 2048.0) + float(rng.integers(-6, 7)) * 2.0 ** -39
+        x = (target - k * c) % 4092.0
+        ok, st = _code_legs(W, x, int(rng.integers(0, 500)), c, 60000, 1024, 4)
+        n_bad += not ok
+    assert n_bad == 0
 
 
 def _chain_truth(W, p, d, N):
