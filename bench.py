@@ -425,7 +425,7 @@ def main():
             # RCCL carries what the path has to exchange -- the report reductions behind the timed region.  The BARRIERS
             # around the timed region go through a gloo group of the same ranks (process barrier on the CPU, then
             # torch.cuda.synchronize()): an RCCL barrier is a device kernel on one more hardware queue, and the first half
-            # dozen steps behind it run 20-30 % slow (profiles/r03k_rccl_slowdown6.log).  GAL_BENCH_RCCL=eager creates the
+            # dozen steps behind it run 20-30 % slow (profiles/archive/r03k_rccl_slowdown6.log).  GAL_BENCH_RCCL=eager creates the
             # communicator here instead of at its first collective, GAL_BENCH_BARRIER=rccl sends the barriers through it.
             if os.environ.get("GAL_BENCH_RCCL", "lazy") == "eager":
                 dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -439,7 +439,7 @@ def main():
 
     # When the process group is initialised matters on this runtime: HIP creates the hardware queue of a stream at the
     # stream's first use, and which queues end up next to each other decides how well the walker chain of one handle runs
-    # beside the synthesis kernel of the other (profiles/r03k_rccl_slowdown*.log, r03k_queue_map.log: the same bench reads
+    # beside the synthesis kernel of the other (profiles/archive/r03k_rccl_slowdown*.log, r03k_queue_map.log: the same bench reads
     # 1.25 ms per step in a plain process and 1.42 with the RCCL communicator created first).  "late" (default) = after
     # the engines exist and a first step has used every one of their streams; "early" = first thing, "mid" = after the
     # engines are planned but before their first step.

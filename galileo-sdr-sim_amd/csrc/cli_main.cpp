@@ -131,7 +131,7 @@ public:
         // Sequential sink into a regular file of known size: a helper thread allocates the file's pages ahead of the writes
         // (fallocate, size kept: the file grows as it is written), 64 MB at a time, WHILE the device starts up -- the run's
         // write()s then copy into pages that exist (tmpfs on the MI355X host: 1.19 GB allocate 70 ms, write() into allocated
-        // pages 130 ms, write() that allocates as it goes 190 ms; profiles/r03j_sink_probe.log).  Failure is not an error:
+        // pages 130 ms, write() that allocates as it goes 190 ms; profiles/archive/r03j_sink_probe.log).  Failure is not an error:
         // the writes allocate for themselves then.  GAL_SINK=noprealloc turns it off.
         if (!map_ && own_fd_ && fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode) && total_ > 0 &&
             !(force && (strcmp(force, "noprealloc") == 0))) {
@@ -562,7 +562,7 @@ int main(int argc, char *argv[])
         // Default: the sequential sink.  Measured on the MI355X host (256 cores, tmpfs, 1.25 GB): write() stream 0.20 s;
         // mapped sink with 4 / 8 / 16 copy threads 0.24 / 0.22 / 0.24 s INCLUDING the unmap (0.10-0.21 s without it, which is
         // what round 3's first measurements showed): the kernel inserts pages into ONE file's page cache at ~6 GB/s whoever
-        // asks -- write(), page faults of many threads, pwrite()s of many threads (inode lock) -- profiles/r03a_sink_probe.log.
+        // asks -- write(), page faults of many threads, pwrite()s of many threads (inode lock) -- profiles/archive/r03a_sink_probe.log.
         n_writers = 0;
     }
     Sink sink;
@@ -606,7 +606,7 @@ int main(int argc, char *argv[])
     hipStreamCreateWithFlags(&copy_stream[0], hipStreamNonBlocking);
     hipStreamCreateWithFlags(&copy_stream[1], hipStreamNonBlocking);
     // First use of the copy path belongs to the start-up, not to the run: the first device -> host copy of a process
-    // took 8 ms on its own (profiles/r03p_cli_batches.log: batch 2 started 10.4 ms into a run whose batches take 2.35 ms)
+    // took 8 ms on its own (profiles/archive/r03p_cli_batches.log: batch 2 started 10.4 ms into a run whose batches take 2.35 ms)
     if (!getenv("GAL_CLI_COLD_COPY")) {
         for (int i = 0; i < 2; ++i)
             for (int k = 0; k < 2; ++k) {

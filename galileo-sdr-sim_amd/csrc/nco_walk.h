@@ -390,12 +390,21 @@ struct CodeTrack {
     int last_ib;     // symbol counter behind that wrap
     int last_fl;     // `flipped` behind that wrap
     double margin;   // smallest distance of a visited state to a boundary of its binade or to the wrap threshold
+    int tpos;        // tie-prone steps: local index of the first state that FOLLOWS a state in [2048, 4096) inside that binade, -1: none
+    double tx;       // ... and that state (see code_tie_prone)
 };
 
+// Steps that are an ODD multiple of 2^-42: in [2048, 4096) (ulp 2^-41) every addition is then a tie, resolved to the even
+// neighbour -- which depends on the parity of x / 2^-41, and a shift by an odd multiple of 2^-41 flips that.  (A multiple of 2^-41
+// adds exactly there; below 2048 every binade's ulp divides 2^-42 and the shift is an even multiple of it: no tie hangs on it.)
+// What saves the translation: the FIRST addition inside [2048, 4096) leaves x / 2^-41 even whatever it was, so from the second state
+// in that binade on (CodeTrack::tpos) two trajectories differ by a constant even multiple again -- the stitch walks the few
+// hundred samples from the true anchor to that state once more and reads the new shift off it (code_leg_accept: 3).
 GAL_HD bool code_tie_prone(double cstep)
 {
     const double t42 = cstep * 4398046511104.0;  // * 2^42, exact
-    return !(cstep < 4.0) || t42 == (double)(long long)t42;
+    if (!(cstep < 4.0)) return true;
+    return t42 == (double)(long long)t42 && ((long long)t42 & 1LL);
 }
 
 // code_walk with the bookkeeping of a speculative leg.  Same states as code_walk (the batches are the same closed forms), bit for
@@ -411,6 +420,8 @@ GAL_HD CodeTrack code_walk_track(double x, int ibit, double cstep, double inv_c,
     o.last_r = 0.0;
     o.last_ib = 0;
     o.last_fl = 0;
+    o.tpos = -1;
+    o.tx = 0.0;
     const uint64_t cb = d2u(cstep);
     const uint32_t ed = (uint32_t)(cb >> 52);
     const bool lean = (cstep >= 9.5367431640625e-07) && (cstep < 4.0) && (x >= 0.0);
@@ -422,6 +433,7 @@ GAL_HD CodeTrack code_walk_track(double x, int ibit, double cstep, double inv_c,
             ++c;
             next_cp += R;
         }
+        const bool in_top = x >= 2048.0 && x < 4092.0;  // (this state is added to inside [2048, 4096): what follows it is even)
         const bool ge = x >= 4092.0;
         x = x - (ge ? 4092.0 : 0.0);
         ibit += ge ? 1 : 0;
@@ -472,6 +484,10 @@ GAL_HD CodeTrack code_walk_track(double x, int ibit, double cstep, double inv_c,
             emit(c, fma_exact((double)(next_cp - i), inc, x), ibit, o.flipped);
             ++c;
             next_cp += R;
+        }
+        if (in_top && o.tpos < 0 && i + 1 <= N) {  // the state behind this one: by the batch's closed form or by the genuine step
+            o.tpos = i + 1;
+            o.tx = n >= 1 ? fma_exact(1.0, inc, x) : x + cstep;
         }
         x = fma_exact((double)n, inc, x);
         i += n;
@@ -529,8 +545,10 @@ GAL_HD CodeEvent code_ideal_anchor(double x0, int ib0, double cstep, int n)
 
 // What the stitch does with leg k once the claim `prev` of the legs in front of it is TRUE: 0 = the leg was walked from that very
 // anchor (exact as it stands), 1 = same wrap, residual off by *delta, and the walk's margin covers it: every state of the leg is
-// the walked one + *delta, 2 = walk it again from `prev`.
-GAL_HD int code_leg_accept(const CodeEvent &anchor, const CodeEvent &prev, double margin, bool tie_prone, double *delta)
+// the walked one + *delta, 3 = the same up to sample tpos, with a shift to be read off the true state there from it on (tie-prone
+// step, delta an odd multiple of 2^-41, and the walk reached a second state in [2048, 4096): code_leg_upto), 2 = walk it again
+// from `prev`.
+GAL_HD int code_leg_accept(const CodeEvent &anchor, const CodeEvent &prev, double margin, bool tie_prone, int tpos, double *delta)
 {
     *delta = 0.0;
     if (anchor.w != prev.w || anchor.ib != prev.ib || anchor.fl != prev.fl) return 2;
@@ -538,9 +556,11 @@ GAL_HD int code_leg_accept(const CodeEvent &anchor, const CodeEvent &prev, doubl
     if (anchor.w < 0) return 2;  // (two different start states: cannot happen, the start is given)
     const double dl = prev.r - anchor.r;  // both multiples of 2^-41 below one step: exact
     const double adl = dl < 0.0 ? -dl : dl;
-    if (tie_prone || !(adl + 9.094947017729282e-13 /* 2^-40 */ < margin)) return 2;
+    // (2^-39: the shift behind a tie step is delta +- 2^-41, and the margins are a last place short of the true distances)
+    if (!(adl + 1.8189894035458565e-12 /* 2^-39 */ < margin)) return 2;
     *delta = dl;
-    return 1;
+    const bool odd = ((long long)(dl * 2199023255552.0 /* 2^41 */) & 1LL) != 0;
+    return (tie_prone && odd && tpos >= 0) ? 3 : 1;
 }
 
 // One leg of the code chain, walked from `anchor`: silently up to the leg's first sample n0 (no checkpoints), then through its nl
@@ -550,6 +570,8 @@ struct CodeLeg {
     double x;         // pre-check state after the leg's last sample
     int ibit, fl;
     double margin;
+    int tpos;         // sample of the epoch whose pre-check state is the first one behind an addition inside [2048, 4096), -1: none
+    double tx;        // ... and that state as walked
 };
 
 template <class Emit>
@@ -579,7 +601,25 @@ GAL_HD CodeLeg code_leg_walk(const CodeEvent &anchor, double cstep, double inv_c
     o.ibit = t2.ibit;
     o.fl = fl1 | t2.flipped;
     o.margin = t1.margin < t2.margin ? t1.margin : t2.margin;
+    o.tpos = t1.tpos >= 0 ? start + t1.tpos : (t2.tpos >= 0 ? n0 + t2.tpos : -1);
+    o.tx = t1.tpos >= 0 ? t1.tx : t2.tx;
     return o;
+}
+
+// The true state at sample `upto` of the epoch (its pre-check state) from a TRUE anchor in front of it, emitting the checkpoints
+// of the chunk starts in [n0, upto) on the way (the leg's own, where upto lies inside it): the stitch's second look at the stretch
+// up to CodeLeg::tpos of a tie-prone leg.
+template <class Emit>
+GAL_HD double code_leg_upto(const CodeEvent &anchor, double cstep, double inv_c, int n0, int upto, int R, Emit emit)
+{
+    const int start = anchor.w < 0 ? 0 : anchor.w;
+    const int s_end = upto < n0 ? upto : n0;
+    const CodeTrack t1 = code_walk_track(anchor.r, anchor.ib, cstep, inv_c, s_end - start, R, s_end - start, [](int, double, int, int) {});
+    if (upto <= n0) return t1.x;
+    const int fl1 = anchor.fl | t1.flipped;
+    const CodeTrack t2 = code_walk_track(t1.x, t1.ibit, cstep, inv_c, upto - n0, R, 0,
+                                         [&](int c, double x, int ib, int fl) { emit(c, x, ib, fl1 | fl); });
+    return t2.x;
 }
 
 // ---------------------------------------------------------------------------------------------

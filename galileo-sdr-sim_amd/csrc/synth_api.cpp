@@ -831,6 +831,18 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         P.cls = (cls >= 2 && std::fabs(period - (double)cls * R) < 0.01 && nchunks % cls == 0) ? cls : 1;
     }
     P.W = W; P.Lc = Lc; P.LEGS = (int)LEGS;
+    {
+        // the code chain of an epoch in legs (k_walk_code): 4 side by side in a long batch -- 88 + <= 13 dependent closed-form steps
+        // per lane instead of 351 --, 16 where a batch of a few epochs is all latency
+        int wc = E * 8 < 256 ? 16 : 4;
+#ifdef GAL_TEST_HOOKS
+        if (const char *env = getenv("GAL_CODE_LEGS")) wc = atoi(env) > 0 ? atoi(env) : wc;
+#endif
+        while (wc > 1 && (wc & (wc - 1))) wc &= wc - 1;  // a power of two
+        wc = wc > 64 ? 64 : wc;
+        P.Wc = wc;
+        P.Lkc = (nchunks + wc - 1) / wc;
+    }
     P.delt = 1.0 / h->cfg.sample_rate;
     P.cs25 = kCS25;
     P.params = (const gal_chan_epoch_t *)(base + o_params);

@@ -69,34 +69,113 @@ using namespace galdev;
 // (The SoA copies of the epoch records -- prn, flags, ib0, x0, p0, cstep, dstep, page_next -- are written by
 // gal_synth_plan on the host, into the upload region: round 2 had a kernel for it, one more launch in front of the chain.)
 // ------------------------------------------------------------------------------------------------
+// One lane per (slot, epoch, LEG): the code chain restarts every epoch from host-known values (src/gal-sig.cpp:336), and since
+// round 5 an epoch's chain is cut into P.Wc legs (4 in a long batch, up to 16 where a batch of a few epochs is all latency) that
+// are walked side by side -- rounds 1-4 walked an epoch's 351 dependent closed-form steps in ONE lane, 0.22 ms, the long pole of a
+// lone handle's walker chain and of a one-epoch call.  Leg 0 starts from the epoch's own state; leg k > 0 from the last wrap in
+// front of it as ideal arithmetic predicts it, and the legs of an epoch -- neighbouring lanes -- are then stitched from left to
+// right: accepted as walked, TRANSLATED by what the anchor was off (a multiple of 2^-41; the walk's margin covers it), or walked
+// again from the true anchor (nco_walk.h: code_leg_walk / code_ideal_anchor / code_leg_accept, with the host statement of this
+// kernel, walk_host.cpp: galwalk_code_legs, tested against brute-force stepping in tests/test_walker_cpu.py).
+__device__ __forceinline__ double shfl_up1_f64(double v)
+{
+    const uint64_t u = d2u(v);
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)u, 1), hi = (uint32_t)__shfl_up((int)(uint32_t)(u >> 32), 1);
+    return u2d(((uint64_t)hi << 32) | lo);
+}
+
 __global__ void k_walk_code(DevPlan P)
 {
     GAL_WALK_SETPRIO();  // latency-bound: win issue arbitration against a co-running k_synth
-    // a wave = 64 consecutive epochs of ONE slot (similar trip counts, idle slots leave as whole waves)
+    // a wave = 64 / Wc consecutive epochs of ONE slot, the Wc legs of an epoch in neighbouring lanes (similar trip counts, idle slots
+    // leave as whole waves)
+    const int Wc = P.Wc;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.E * P.S) return;
-    const int s = t / P.E;
-    const int idx = (t - s * P.E) * P.S + s;
+    if (t >= P.E * P.S * Wc) return;  // (Wc divides 64: a group of legs is inside one wave, and leaves as a whole)
+    const int k = t & (Wc - 1);
+    const int se = t / Wc;
+    const int s = se / P.E;
+    const int idx = (se - s * P.E) * P.S + s;
     if (P.prn[idx] <= 0) return;
     double *cpx = P.cp_x + (size_t)idx * P.CP1;
     uint32_t *cpi = P.cp_ib + (size_t)idx * P.CP1;
     const double c = P.cstep[idx];
+    const double x0 = P.x0[idx];
+    const int ib0 = P.ib0[idx];
     if (idx < P.cp_e0 * P.S) {
         // an epoch in front of the executed range: only its page flip matters (k_pages), no checkpoint is read
-        const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], c, 1.0 / c, P.N, P.N, [](int, double, int, int) {});
-        P.flip_in[idx] = (uint8_t)end.flipped;
+        if (k == 0) {
+            const CodeEnd end = code_walk(x0, ib0, c, 1.0 / c, P.N, P.N, [](int, double, int, int) {});
+            P.flip_in[idx] = (uint8_t)end.flipped;
+        }
         return;
     }
-    const CodeEnd end = code_walk(P.x0[idx], P.ib0[idx], c, 1.0 / c, P.N, P.R,
-                                  [&](int k, double x, int ibit, int flipped) {
-                                      cpx[k] = x;
-                                      cpi[k] = (uint32_t)ibit | ((uint32_t)flipped << 16);
-                                  });
-    cpx[P.nchunks] = end.x;
-    cpi[P.nchunks] = (uint32_t)end.ibit | ((uint32_t)end.flipped << 16);
-    // a wrap still pending after the last sample is discarded by the next epoch's overwrite
-    // (SURVEY.md §7.3-3), so only flips that happened inside the loop count
-    P.flip_in[idx] = (uint8_t)end.flipped;
+    const int Lk = P.Lkc;  // chunks per leg
+    const int n0 = k * Lk * P.R;
+    int n1 = (k + 1) * Lk * P.R;
+    n1 = n1 > P.N ? P.N : n1;
+    const bool have = n0 < P.N;
+    const bool last = have && (k == Wc - 1 || (k + 1) * Lk * P.R >= P.N);  // the leg that ends the epoch
+    CodeEvent anc;
+    anc.w = -1; anc.r = x0; anc.ib = ib0; anc.fl = 0;
+    if (k > 0 && have) anc = code_ideal_anchor(x0, ib0, c, n0);
+    CodeLeg L;
+    L.claim = anc; L.x = x0; L.ibit = ib0; L.fl = 0; L.margin = 0.0; L.tpos = -1; L.tx = 0.0;
+    const double inv_c = 1.0 / c;
+    auto emit = [&](int ci, double x, int ib, int fl) {
+        cpx[k * Lk + ci] = x;
+        cpi[k * Lk + ci] = (uint32_t)ib | ((uint32_t)fl << 16);
+    };
+    if (have) L = code_leg_walk(anc, c, inv_c, n0, n1 - n0, P.R, emit);
+    // ---- the stitch, leg by leg: lane k looks at the (by then true) claim of lane k - 1
+    const bool tie = code_tie_prone(c);
+    double shift = 0.0;   // what the leg's checkpoints are to be moved by ...
+    int shift_from = 0;   // ... from this sample of the epoch on (translation across a tie step: the ones in front of it are rewritten)
+    for (int step = 1; step < Wc; ++step) {
+        CodeEvent prev;
+        prev.w = __shfl_up(L.claim.w, 1);
+        prev.r = shfl_up1_f64(L.claim.r);
+        prev.ib = __shfl_up(L.claim.ib, 1);
+        prev.fl = __shfl_up(L.claim.fl, 1);
+        if (k != step || !have) continue;
+        double dl;
+        const int how = code_leg_accept(anc, prev, L.margin, tie, L.tpos, &dl);
+        if (how == 1) {
+            shift = dl;
+            shift_from = n0;
+            L.x += dl;
+            L.claim.r += dl;
+        } else if (how == 3) {
+            const double xt = code_leg_upto(prev, c, inv_c, n0, L.tpos, P.R, emit);
+            shift = xt - L.tx;
+            shift_from = L.tpos;
+            L.x += shift;
+            if (L.claim.w == anc.w) L.claim = prev;
+            else L.claim.r += shift;
+        } else if (how == 2) {
+            anc = prev;
+            L = code_leg_walk(anc, c, inv_c, n0, n1 - n0, P.R, emit);
+        }
+    }
+    if (!have) return;
+    if (shift != 0.0) {  // the leg's own checkpoints, eight read-modify-writes in flight
+        const int nck = (n1 - n0 + P.R - 1) / P.R;
+        for (int c0 = 0; c0 < nck; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (c0 + q < nck && n0 + (c0 + q) * P.R >= shift_from) ? cpx[k * Lk + c0 + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (c0 + q < nck && n0 + (c0 + q) * P.R >= shift_from) cpx[k * Lk + c0 + q] = v[q] + shift;
+        }
+    }
+    if (last) {
+        cpx[P.nchunks] = L.x;
+        cpi[P.nchunks] = (uint32_t)L.ibit | ((uint32_t)L.fl << 16);
+        // a wrap still pending after the last sample is discarded by the next epoch's overwrite
+        // (SURVEY.md section 7.3-3), so only flips that happened inside the loop count
+        P.flip_in[idx] = (uint8_t)L.fl;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2258,7 +2337,7 @@ typedef const volatile __attribute__((address_space(3))) double *lds_vf64_ptr;
 
 extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 {
-    const int n = P->E * P->S;
+    const int n = P->E * P->S * P->Wc;  // one lane per leg of the code chain
     hipLaunchKernelGGL(k_walk_code, dim3((n + 63) / 64), dim3(64), 0, st, *P);
 }
 

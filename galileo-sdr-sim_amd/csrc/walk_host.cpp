@@ -67,13 +67,13 @@ void galwalk_code(double x, int ibit, double c, int N, int R, double *cpx, uint3
 
 // The code chain of one epoch in `legs` legs, as k_walk_code runs it on the device (synth_kernels.hip): every leg walked from its
 // ideal-arithmetic anchor, then the stitch from leg to leg -- accepted as it stands, translated, or walked again from the true
-// anchor.  stats[0..2]: legs accepted as walked / translated / walked again.  force_tie != 0: treat the step as tie-prone.
+// anchor.  stats[0..3]: legs accepted as walked / translated / walked again / translated across a tie.  force_tie != 0: never translate.
 void galwalk_code_legs(double x0, int ib0, double c, int N, int R, int legs, double *cpx, uint32_t *cpi, double *xend, int *ibend,
                        int *flipped, int *stats, int force_tie)
 {
     const int nchunks = (N + R - 1) / R;
     const int Lk = (nchunks + legs - 1) / legs;
-    const bool tie = code_tie_prone(c) || force_tie;
+    const bool tie = code_tie_prone(c);
     std::vector<CodeEvent> anc(legs);
     std::vector<CodeLeg> leg(legs);
     std::vector<int> have(legs, 0);
@@ -95,18 +95,33 @@ void galwalk_code_legs(double x0, int ib0, double c, int N, int R, int legs, dou
         }
         walk(k);
     }
-    stats[0] = stats[1] = stats[2] = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
     int last = 0;
     for (int k = 1; k < legs; ++k) {
         if (!have[k]) continue;
         double dl;
-        const int how = code_leg_accept(anc[k], leg[k - 1].claim, leg[k].margin, tie, &dl);
+        int how = code_leg_accept(anc[k], leg[k - 1].claim, leg[k].margin, tie, leg[k].tpos, &dl);
+        if (force_tie && how != 0) how = 2;
         stats[how] += 1;
+        const int n0 = k * Lk * R, n1 = std::min(N, (k + 1) * Lk * R);
         if (how == 1) {
-            const int n0 = k * Lk * R, n1 = std::min(N, (k + 1) * Lk * R);
             for (int ci = 0; ci * R < n1 - n0; ++ci) cpx[k * Lk + ci] += dl;
             leg[k].x += dl;
             leg[k].claim.r += dl;
+        } else if (how == 3) {
+            // true state at tpos from the true anchor (the checkpoints in front of it come out of this walk), the rest shifted by
+            // what the two trajectories differ by there
+            const int tp = leg[k].tpos;
+            const double xt = code_leg_upto(leg[k - 1].claim, c, 1.0 / c, n0, tp, R, [&](int ci, double x, int ib, int fl) {
+                cpx[k * Lk + ci] = x;
+                cpi[k * Lk + ci] = (uint32_t)ib | ((uint32_t)fl << 16);
+            });
+            const double dl2 = xt - leg[k].tx;
+            for (int ci = 0; ci * R < n1 - n0; ++ci)
+                if (n0 + ci * R >= tp) cpx[k * Lk + ci] += dl2;
+            leg[k].x += dl2;  // (tpos lies inside the walk: the end is behind it)
+            if (leg[k].claim.w == anc[k].w) leg[k].claim = leg[k - 1].claim;  // no wrap seen: the anchor's event, true value
+            else leg[k].claim.r += dl2;                                      // (the first wrap behind the anchor lies behind tpos)
         } else if (how == 2) {
             anc[k] = leg[k - 1].claim;
             walk(k);

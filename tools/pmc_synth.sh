@@ -34,7 +34,7 @@ res["launches_averaged"] = {k: len(v) for k, v in acc.items()}
 if "WRITE_SIZE" in res and "FETCH_SIZE" in res:
     # WRITE_SIZE is in KiB on gfx950 (tools/wrcal.hip: exact for a coalesced 1 GiB fill); FETCH_SIZE counts
     # 32-byte requests against a 64-byte unit there, i.e. the raw KiB figure is doubled (MI355X_MICROARCH guide,
-    # HBM / rocprofv3 section) -- same correction as in profiles/r01_pmc_write_fetch.md
+    # HBM / rocprofv3 section) -- same correction as in profiles/archive/r01_pmc_write_fetch.md
     res["hbm_bytes_per_launch"] = int((res["WRITE_SIZE"] + 2.0 * res["FETCH_SIZE"]) * 1024)
 json.dump(res, open("gpurun_out/%s_pmc_k_synth_all.json" % tag, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))

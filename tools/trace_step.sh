@@ -9,8 +9,8 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last complete step: from the last k_carr_guess to the end of the following k_synth
-idx = [i for i, r in enumerate(rows) if "k_carr_guess" in r["Kernel_Name"]]
+# last complete step: from the last-but-one k_walk_carr (the head of the walker chain) to the end of the following k_synth
+idx = [i for i, r in enumerate(rows) if "k_walk_carr" in r["Kernel_Name"]]
 i0 = idx[-2]
 t0 = int(rows[i0]["Start_Timestamp"])
 prev_end = t0
