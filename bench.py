@@ -371,6 +371,10 @@ def main():
                     "25 MS/s); dyn = config 3 (12 SVs, Doppler from a 10 Hz circular track); locations = config 5 "
                     "literally: rank r simulates static site r of 8 for 300 s from tests/golden/20feb2022.rnx through "
                     "the real host front-end (7-10 SVs per site, so the ranks' work differs)")
+    ap.add_argument("--as-rank", default=None, metavar="R/N", help="--shard scenario: do the work of rank R of N in THIS process, alone on "
+                    "the device (no process group): its epoch range, walker and kernel time.  tools/strong_split_alone.sh runs every rank "
+                    "of a world this way, one after the other, to read shard.epoch_range's balance off ONE GPU without the ranks "
+                    "disturbing each other; says nothing about scaling")
     ap.add_argument("--site", type=int, default=None, help="--workload locations: the site (0..7 of shard.LOCATIONS) this process "
                     "simulates instead of site `rank` -- the per-site 1-GPU baseline of config 5 (tools/config5_sites.sh)")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4],
@@ -466,6 +470,12 @@ def main():
         params = pkg.shard.rank_workload(0 if strong else rank, args.epochs, n_chan=args.channels, n_slots=n_slots,
                                          samples_per_epoch=n_samp, sample_rate=rate, dyn_track=(args.workload == "dyn"))
     e_first, e_count = pkg.shard.epoch_range(rank, world, args.epochs) if strong else (0, args.epochs)
+    as_rank = None
+    if args.as_rank:
+        if not strong or world != 1:
+            raise SystemExit("--as-rank needs --shard scenario in a single process")
+        as_rank = tuple(int(v) for v in args.as_rank.split("/"))
+        e_first, e_count = pkg.shard.epoch_range(as_rank[0], as_rank[1], args.epochs)
     depth = args.pipeline
     engines, outs, streams = [], [], []
     for k in range(depth):
@@ -612,6 +622,11 @@ def main():
                 "rank_imbalance": round(max(r["avg_walk_ms"] + r["avg_kernel_ms"] for r in per_rank) /
                                         max(1e-9, sum(r["avg_walk_ms"] + r["avg_kernel_ms"] for r in per_rank) / len(per_rank)), 3)}
                if per_rank else {}),
+            **({"as_rank": {"rank": as_rank[0], "of": as_rank[1], "epochs": [int(e_first), int(e_first + e_count)],
+                            "avg_walk_ms": round(ms_walk / args.steps, 4), "avg_kernel_ms": round(ms_synth / args.steps, 4),
+                            "legs_walked": int(engines[0].walk_counts()[0]),
+                            "note": "this rank's share of ONE scenario, run alone on the device: a balance check, not a scaling measurement"}}
+               if as_rank else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "preroll_steps": preroll_steps,  # un-timed device wake-up in front of the warm-up steps (--preroll-ms)

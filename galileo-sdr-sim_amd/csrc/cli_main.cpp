@@ -311,6 +311,7 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
             per_gpu > 1 ? "es" : "");
     std::vector<pid_t> lane_pid(lanes, 0);
     std::vector<int> lane_site(lanes, -1);
+    std::vector<std::chrono::steady_clock::time_point> lane_t0(lanes);
     const auto t0 = std::chrono::steady_clock::now();
     size_t next = 0, done = 0;
     int failed = 0;
@@ -346,6 +347,7 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
             }
             lane_pid[l] = pid;
             lane_site[l] = (int)next;
+            lane_t0[l] = std::chrono::steady_clock::now();
             ++next;
         }
         int status = 0;
@@ -360,8 +362,10 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
             struct stat sb;
             const long long bytes = stat(s.out.c_str(), &sb) == 0 ? (long long)sb.st_size : 0;
             const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
-            fprintf(stderr, "site %d (%s) on GPU %d -> %s: %s, %lld bytes\n", lane_site[l], s.llh.c_str(), l % n_gpus,
-                    s.out.c_str(), ok ? "ok" : "FAILED", bytes);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - lane_t0[l]).count();
+            // (the child's wall time: HIP start-up, front-end, synthesis, device->host copy, file -- the sink, not the engine, sets it)
+            fprintf(stderr, "site %d (%s) on GPU %d -> %s: %s, %lld bytes in %.2f s = %.0f Msamples/s = %.2f GB/s into its file\n", lane_site[l],
+                    s.llh.c_str(), l % n_gpus, s.out.c_str(), ok ? "ok" : "FAILED", bytes, dt, bytes / 4 / dt / 1e6, bytes / dt / 1e9);
             if (!ok) ++failed;
             total_bytes += bytes;
             lane_pid[l] = 0;
@@ -374,7 +378,8 @@ int run_sites(const char *self, const std::vector<std::string> &base_args, const
     }
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "\nDone!\nSites = %zu  failed = %d  Process time = %.2f [sec]  (%.1f Msamples/s aggregate over %d GPU%s, incl. process "
-                    "start-up)\n", sites.size(), failed, el, total_bytes / 4 / el / 1e6, n_gpus, n_gpus > 1 ? "s" : "");
+                    "start-up; per site the device->host link and the file system bound this figure, not the synthesis engine: see the "
+                    "per-site lines)\n", sites.size(), failed, el, total_bytes / 4 / el / 1e6, n_gpus, n_gpus > 1 ? "s" : "");
     return failed ? 1 : 0;
 }
 
