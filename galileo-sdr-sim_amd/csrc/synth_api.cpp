@@ -78,7 +78,6 @@ void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
 void galk_launch_verify_carr(const DevPlan *P, hipStream_t st);
-void galk_launch_tr_apply(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state, uint32_t *h_flag, uint32_t seq, hipStream_t st);
 int galk_scanm_blocks(int legs);
@@ -242,7 +241,6 @@ struct gal_synth {
     std::vector<int> group_kind;     // 1: k_synth_g, 0: k_synth (k_synth_g batches: the records that are not fit for it, accumulating)
     int all_first = 0, all_count = 0;  // k_synth_g batches with records of kind 0: the groups that hold ALL records (list-overflow path)
     int n_exact_records = 0;         // records of the batch that take the exact-replay launch behind k_synth_g
-    unsigned long long exact_slot_mask = 0;  // ... and the slots they sit in (k_synth reads those slots' checkpoints: translated in place)
     uint8_t *d_act = nullptr;  // [groups][E][kActRow]
     int *d_nact = nullptr;     // [groups][E]
     int nact_max = 0;
@@ -741,13 +739,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         return ng;
     };
     int n_exact_records = 0;
-    h->exact_slot_mask = 0;
     if (fam_g) {
-        for (int e = 0; e < E; ++e)
-            for (int k2 = 0; k2 < nact_all[e]; ++k2) {
-                const uint8_t s2 = act_all[(size_t)e * S + k2];
-                if (!(rec_g[(size_t)e * S + s2] && rec_mode[(size_t)e * S + s2] == g_mode)) h->exact_slot_mask |= 1ull << s2;
-            }
         h->n_groups = add_groups(1, [&](size_t i) { return rec_g[i] && rec_mode[i] == g_mode; });
         h->n_groups += add_groups(0, [&](size_t i) { return !(rec_g[i] && rec_mode[i] == g_mode); });
         n_exact_records = (int)(n_records - n_grec);
@@ -789,7 +781,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmr = take(LEGS * S * 8);
     const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S), o_risk = take(LEGS * S);
-    const size_t o_trdl = take(LEGS * S * 8);
     const size_t zero_end = off;
     const size_t o_clmw = take(LEGS * S * 8);  // "no claim" = -1
     const size_t o_state_out = take(sizeof(gal_chan_state_t) * S);
@@ -870,9 +861,6 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.pend = (double *)(base + o_pend);
     P.verified = (uint8_t *)(base + o_ver); P.dirty = (uint8_t *)(base + o_dirty); P.risk = (uint8_t *)(base + o_risk);
     P.ver_mod = 1; P.ver_rem = 0;
-    P.tr_dl = (double *)(base + o_trdl);
-    P.lc_magic = (uint32_t)(((1ull << 32) + (uint64_t)Lc - 1) / (uint64_t)Lc);
-    P.inplace_mask = ~0ull;  // (set per batch in gal_synth_execute_range)
     P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
     P.scanm = multi_scan ? (void *)(base + o_scanm) : nullptr;
@@ -1000,14 +988,12 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
     const int g_first = overflow_set ? h->all_first : 0, g_count = overflow_set ? h->all_count : h->n_groups;
     DevPlan Px = h->P;  // what an exact-replay launch of a k_synth_g batch sees
     if (h->P.fam == 1 || overflow_set) Px.rw = 0;
-    DevPlan Pg = h->P;  // what k_synth_g / k_repair_g see: the leg arrays' slot stride of THIS batch (the walkers' cut plan)
-    Pg.LEGS = h->Pw.LEGS;
     for (int k = 0; k < g_count; ++k) {
         const int g = g_first + k;
         const uint8_t *act = h->d_act + (size_t)g * h->P.E * kActRow;
         const int *nact = h->d_nact + (size_t)g * h->P.E;
         const bool on_g = h->P.fam == 1 && h->group_kind[g] == 1;
-        const int rc = on_g ? galk_launch_synth_g(&Pg, h->d_plan, h->group_nch[g], k > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream)
+        const int rc = on_g ? galk_launch_synth_g(&h->P, h->d_plan, h->group_nch[g], k > 0, act, nact, iq, h->range_e0, h->range_ne, h->stream)
                             : galk_launch_synth(h->P.fam == 1 || overflow_set ? &Px : &h->P, h->d_plan, h->group_nch[g], k > 0, act, nact, iq,
                                                 h->range_e0, h->range_ne, h->stream);
         if (rc) return fail(GAL_E_INVAL, "no synthesis kernel for %d channels per group", h->group_nch[g]);
@@ -1015,7 +1001,7 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
     // the groups k_synth_g could not decide (chip pattern or table index within the rounding drift of a boundary), exactly
     if (h->P.fam == 1) {
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));  // (k_synth_g's time and k_repair_g's are reported apart)
-        galk_launch_repair_g(&Pg, iq, h->range_e0, h->stream);
+        galk_launch_repair_g(&h->P, iq, h->range_e0, h->stream);
     }
     HIP_TRY(hipGetLastError());
     return GAL_OK;
@@ -1059,8 +1045,6 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->Pw.cp_e0 = first_epoch;
     // k_verify_carr (k_synth_g batches): an eighth of the leg positions per batch, rotating with the handle's batch count, plus the
     // legs whose translation was not overwhelmingly inside its margin; GAL_CFG_VERIFY_ALL: every leg (synth_kernels.hip)
-    // carrier legs are translated in place where k_synth reads the checkpoints, deferred elsewhere (synth_dev.h: tr_dl)
-    h->Pw.inplace_mask = h->P.fam == 1 ? h->exact_slot_mask : ~0ull;
     h->Pw.ver_mod = (h->cfg.flags & GAL_CFG_VERIFY_ALL) ? 1 : kVerifyRotation;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_VERIFY_MOD")) h->Pw.ver_mod = atoi(env) > 0 ? atoi(env) : h->Pw.ver_mod;  // timing experiments
@@ -1292,7 +1276,6 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
         // the masks): the batch once more with the exact-replay kernel, which takes any input
         h->P.fam = 0;
         h->Pw.fam = 0;
-        galk_launch_tr_apply(&h->Pw, st);  // k_synth reads the carrier checkpoints as they stand: the deferred shifts go in now
         HIP_TRY(hipMemsetAsync(P->ctr + CTR_MISMATCH, 0, sizeof(int), st));
         HIP_TRY(hipEventRecord(h->ev[1], st));
         h->stats.synth_runs += 1;

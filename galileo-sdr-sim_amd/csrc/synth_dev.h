@@ -64,14 +64,6 @@ struct DevPlan {
     int8_t *tdir;        // rounding direction of the first tie the walk met (WalkOut::tdir), 0 = none
     long long *tpos;     // global sample index right after that tie step
     double *shift;       // pending translation (new anchor residual - walked anchor residual)
-    // DEFERRED translation (round 5): where every consumer of a slot's carrier checkpoints adds the shift itself (k_synth_g's loader
-    // lanes, k_repair_g, k_verify_carr -- gal_cp_p below), a translated leg's 32 checkpoints are not rewritten: the stitch only
-    // accumulates what they are off by.  Still translated in place: slots whose checkpoints k_synth reads (inplace_mask: every slot
-    // of a k_synth batch, the slots with records the group kernel cannot take), and the rare leg whose translation flips a tie (two
-    // shifts, one either side of the tie step: nco_walk.h, WalkOut::tdir).
-    double *tr_dl;       // [S][LEGS] what the leg's checkpoints (and, for an epoch's last leg, its end-of-epoch entry) are off by
-    unsigned long long inplace_mask;  // bit s: slot s is translated in place
-    uint32_t lc_magic;   // ceil(2^32 / Lc): chunk / Lc = mulhi(chunk, lc_magic) (chunk x Lc < 2^32)
     uint8_t *risk;       // 1: the leg was accepted by a translation that used more than 1/256 of its binade margin: k_verify_carr
                          // re-walks such a leg in every batch, whatever the rotation says
     int ver_mod, ver_rem;  // k_verify_carr re-walks the legs i = ver_rem (mod ver_mod) of the executed epochs (1, 0: every leg)
@@ -111,20 +103,6 @@ struct SynGeom {
     int cls, per;  // lane order: position L of the epoch replays chunk (L % per) * cls + L / per, per = nchunks / cls
     int e0;  // first epoch of the executed range (the output buffer starts there)
     int ne;  // epochs of the launch (k_synth_g: its blocks cut ne x nchunks chunks among themselves)
-    int legs, W;         // k_synth_g / k_repair_g: slot stride of the carrier leg arrays in this batch, legs per epoch (gal_cp_p)
-    uint32_t lc_magic;   // ... chunk / Lc = mulhi(chunk, lc_magic)
 };
 
-
-#if defined(__HIPCC__)
-// The carrier checkpoint in front of chunk c of (epoch e, slot s) -- c = nchunks: the state behind the epoch's last sample -- with
-// the deferred shift of its leg applied.  The sum is the true phase, a double: exact.  `legs`: the leg arrays' slot stride (the
-// walkers' cut plan: first executed epoch + count, times W).
-__device__ __forceinline__ double gal_cp_p(const DevPlan &P, const int legs, const int s, const int e, const int c)
-{
-    const double v = P.cp_p[((size_t)e * P.S + s) * P.CP1 + c];
-    const int w = c >= P.nchunks ? P.W - 1 : (int)__umulhi((uint32_t)c, P.lc_magic);
-    return v + P.tr_dl[(size_t)s * legs + (size_t)e * P.W + w];
-}
-#endif
 #endif

@@ -570,16 +570,11 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     typedef const __attribute__((address_space(1))) uint32_t *sg_gbl_u32;
     const sg_gbl_f64 g_cpx = (sg_gbl_f64)(uintptr_t)p_cpx + cpl, g_cpp = (sg_gbl_f64)(uintptr_t)p_cpp + cpl;
     const sg_gbl_u32 g_cpi = (sg_gbl_u32)(uintptr_t)p_cpi + cpl;
-    // what the carrier checkpoints of the chunk's leg are off by (deferred translation, synth_dev.h: gal_cp_p): row of the loader
-    // lane's slot and epoch in the leg arrays
-    const sg_gbl_f64 g_trd = (sg_gbl_f64)(uintptr_t)Pd->tr_dl + ((size_t)(ixl - e * G.S) * G.legs + (size_t)e * G.W);
-    double ldl = 0.0;
     auto fetch = [&](const int cc) {
         const int ce = cc < c_end ? cc : c_end - 1;
         lx = g_cpx[ce];
         lp = g_cpp[ce];
         lib = g_cpi[ce];
-        ldl = g_trd[__umulhi((uint32_t)ce, G.lc_magic)];
     };
     auto stage = [&](const int buf) {
         SgRec r;
@@ -589,7 +584,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         // (idle positions: phases far from every boundary the kernel looks at -- their zero checkpoints would sit ON one, 511 p = 0,
         // and list every group of the epoch)
         r.yc = onl ? x + x : 0.5;
-        r.pm = onl ? u2d(d2u(lp + ldl) ^ ((uint64_t)dsgnl << 32)) : 0.25;
+        r.pm = onl ? u2d(d2u(lp) ^ ((uint64_t)dsgnl << 32)) : 0.25;
         r.s = sl;
         r.dabs = dabsl;
         if (lane < NCH) {
@@ -711,7 +706,7 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
             const uint32_t cib = P.cp_ib[cp];
             const CodeEnd ce = code_walk(P.cp_x[cp], (int)(cib & 0xffffu), cst, 1.0 / cst, 16 * g, 1 << 30, [](int, double, int, int) {});
             double x = ce.x;
-            double p = carr_walk_track(gal_cp_p(P, G.legs, s, e, c), d, 1.0 / __builtin_fabs(d), 16 * g, 16 * g + 1, 16 * g + 1, [](int, double) {}).p;
+            double p = carr_walk_track(P.cp_p[cp], d, 1.0 / __builtin_fabs(d), 16 * g, 16 * g + 1, 16 * g + 1, [](int, double) {}).p;
             {
                 // ... and both chains walked on to the END of the chunk: they must arrive at the next checkpoint, bit for bit (the
                 // end-of-epoch state behind the last chunk).  The listed groups are scattered over the batch by the bits of the
@@ -725,7 +720,7 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
                 const uint32_t fl_end = (cib >> 16) | (uint32_t)ce.flipped | (uint32_t)ce2.flipped;
                 const double p2 = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), rem, rem + 1, rem + 1, [](int, double) {}).p;
                 const bool bad = d2u(ce2.x) != d2u(P.cp_x[cp + 1]) || ((uint32_t)ce2.ibit | (fl_end << 16)) != P.cp_ib[cp + 1] ||
-                                 d2u(p2) != d2u(gal_cp_p(P, G.legs, s, e, c + 1));
+                                 d2u(p2) != d2u(P.cp_p[cp + 1]);
                 if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], 1);
             }
             // Everything the 16 samples read from memory, fetched in one go (a load per sample and table would make this a
@@ -870,9 +865,6 @@ static SynGeom sg_geom(const DevPlan *P, int e0, int ne)
     SynGeom G;
     G.e0 = e0;
     G.ne = ne;
-    G.legs = P->LEGS;  // (the caller's copy of the plan carries the batch's stride: first executed epoch + count, times W)
-    G.W = P->W;
-    G.lc_magic = P->lc_magic;
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1;
     G.blocks_per_epoch = ne > 0 ? sg_bpe(P, ne) : 1;
     G.cls = 1;

@@ -228,14 +228,8 @@ __device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, con
     nck = nck > P.Lc ? P.Lc : nck;
     const size_t base = (size_t)idx * P.CP1 + (size_t)w * P.Lc;
     double *cpp = P.cp_p + base;
-    if (!flip && !((P.inplace_mask >> s) & 1ull)) {
-        // deferred: the consumers of this slot's checkpoints add the shift themselves (synth_dev.h: gal_cp_p).  (A translation that
-        // flips a tie has two shifts, one either side of the tie step: in place, like the slots k_synth reads; the two kinds add up)
-        P.tr_dl[li] += dl;
-        if (defer) defer->nck = 0;
-    } else if (defer) {
+    if (defer) {
         defer->dl = dl; defer->dl2 = dl2; defer->tp = tp; defer->A = A; defer->base = base; defer->nck = nck;
-        if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
     } else {
         // (eight independent read-modify-writes in flight: a plain loop waits for every load)
         for (int c0 = 0; c0 < nck; c0 += 8) {
@@ -246,8 +240,8 @@ __device__ __forceinline__ void translate_leg(const DevPlan &P, const int s, con
             for (int k = 0; k < 8; ++k)
                 if (c0 + k < nck) cpp[c0 + k] = v[k] + ((A + (long long)(c0 + k) * P.R >= tp) ? dl2 : dl);
         }
-        if (w == P.W - 1) cpp[nck] += dl2;
     }
+    if (w == P.W - 1) cpp[nck] += dl2;  // (a tie step, if any, lies before the end of the leg)
     if (__builtin_fabs(dl) * 256.0 > P.marg[li]) P.risk[li] = 1;  // not overwhelmingly inside the margin: verified in every batch
     P.pend[li] += dl2;
     if (P.clm_w[li] >= 0) P.clm_r[li] += (P.clm_w[li] >= tp) ? dl2 : dl;
@@ -355,7 +349,6 @@ __global__ void k_walk_carr(DevPlan P, int first)
     P.tpos[li] = tpos;
     P.dirty[li] = 0;
     P.risk[li] = 0;  // walked, not translated
-    P.tr_dl[li] = 0.0;
     if (!first) {
         const uint64_t m = __builtin_amdgcn_ballot_w64(true);  // one atomic per wave
         if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicAdd(&P.ctr[CTR_WALKS], __builtin_popcountll(m));
@@ -410,33 +403,10 @@ __global__ void k_verify_carr(DevPlan P)
     if (n <= 0) return;
     const double d = P.dstep[idx];
     const double *cpp = P.cp_p + (size_t)idx * P.CP1 + (size_t)w * P.Lc;
-    // (the leg's deferred shift, see synth_dev.h: gal_cp_p -- one value for the whole leg)
-    const double dl = P.tr_dl[(size_t)s * P.LEGS + i];
     int bad = 0;
-    const WalkOut o = carr_walk_track(cpp[0] + dl, d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { bad += (cpp[c] + dl) != v; });
-    // the next leg's first checkpoint, or the end-of-epoch state
-    bad += gal_cp_p(P, P.LEGS, s, e, w * P.Lc + (n + P.R - 1) / P.R) != o.p;
+    const WalkOut o = carr_walk_track(cpp[0], d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { bad += cpp[c] != v; });
+    bad += cpp[(n + P.R - 1) / P.R] != o.p;  // the next leg's first checkpoint, or the end-of-epoch state
     if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
-}
-
-// k_tr_apply: the deferred shifts of a batch's carrier legs (DevPlan::tr_dl) written into the checkpoints after all -- in front of
-// the one consumer that does not add them itself, k_synth, when gal_synth_finish repeats a k_synth_g batch on it (list overflow).
-__global__ void k_tr_apply(DevPlan P)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.LEGS * P.S) return;
-    const int s = t / P.LEGS, i = t - s * P.LEGS;
-    const size_t li = (size_t)s * P.LEGS + i;
-    const double dl = P.tr_dl[li];
-    if (dl == 0.0) return;
-    const int e = i / P.W, w = i - e * P.W;
-    if (e < P.cp_e0 || P.prn[e * P.S + s] <= 0) return;
-    int nck = P.nchunks - w * P.Lc;
-    nck = nck > P.Lc ? P.Lc : nck;
-    double *cpp = P.cp_p + (size_t)(e * P.S + s) * P.CP1 + (size_t)w * P.Lc;
-    for (int c = 0; c < nck; ++c) cpp[c] += dl;
-    if (w == P.W - 1) cpp[nck] += dl;
-    P.tr_dl[li] = 0.0;
 }
 
 // k_carr_scan: one 1024-thread block per slot stitches the legs.  Sequential statement (what the three
@@ -2369,12 +2339,6 @@ extern "C" void galk_launch_walk_code(const DevPlan *P, hipStream_t st)
 {
     const int n = P->E * P->S * P->Wc;  // one lane per leg of the code chain
     hipLaunchKernelGGL(k_walk_code, dim3((n + 63) / 64), dim3(64), 0, st, *P);
-}
-
-extern "C" void galk_launch_tr_apply(const DevPlan *P, hipStream_t st)
-{
-    const int n = P->LEGS * P->S;
-    hipLaunchKernelGGL(k_tr_apply, dim3((n + 255) / 256), dim3(256), 0, st, *P);
 }
 
 extern "C" void galk_launch_verify_carr(const DevPlan *P, hipStream_t st)
