@@ -40,21 +40,50 @@ def rank_location_scenario(scenario_cls, nav_file, rank, duration_s=300.0, start
 
 
 WALK_COST = 0.1  # walking an epoch's NCO chains silently, relative to synthesising it (VALU work: walkers 37 M against
-                 # k_synth_g's 429 M wave-instructions per 1199 epochs, and legs in front of a range may be walked twice)
+                 # k_synth_g's 417 M wave-instructions per 1199 epochs; measured: +0.0001 ms of walker chain per prefix epoch against
+                 # 0.00107 ms of synthesis per epoch, profiles/r05m_strong_split_alone_before.log)
+PREFIX_PASS_COST = 215.0  # ... and what ANY prefix costs on top, in epochs of synthesis: legs in front of the executed range are never
+                          # accepted by translation (their checkpoints do not exist, nothing could check them), so a rank with a prefix
+                          # runs a second walker pass: 0.44 ms of chain against 0.21 (same log) = 0.23 ms = 215 epochs of k_synth_g
 
 
-def epoch_range(rank, world, n_epochs, walk_cost=WALK_COST):
+def epoch_range(rank, world, n_epochs, walk_cost=WALK_COST, prefix_pass_cost=PREFIX_PASS_COST):
     """Contiguous epoch range [first, first + count) of ONE scenario for rank `rank` (strong scaling, SURVEY.md
     §8e-ii): every rank plans the whole scenario and synthesises only its own range (gal_synth_execute_range).  The
     carrier chain never restarts, so a rank WALKS the epochs [0, first + count) -- its prefix silently -- and the ranges are
-    cut so that walk(prefix + range) + synth(range) is the same on every rank: with w = walk_cost the boundaries satisfy
-    w b[r+1] + (b[r+1] - b[r]) = const, i.e. later ranks get shorter ranges (w = 0: equal ranges)."""
-    def bounds():
-        if walk_cost <= 0.0 or world == 1:
-            return [(k * n_epochs) // world for k in range(world + 1)]
-        q = 1.0 / (1.0 + walk_cost)
-        total = 1.0 - q ** world
-        b = [int(round(n_epochs * (1.0 - q ** k) / total)) for k in range(world + 1)]
+    cut so that walk + synth is the same on every rank.  Cost model, in epochs of synthesis: rank 0 pays its count; a rank with a
+    prefix b pays count + walk_cost * b + prefix_pass_cost (the second walker pass its prefix legs need).  Rank 0 therefore gets
+    the longest range, and the later ranks shorter and shorter ones.  (walk_cost = 0 and prefix_pass_cost = 0: equal ranges.)
+    Round 4's model had the proportional term only: ranks measured ALONE on one GPU were 16 % / 15 % / 9 % out of balance at
+    world 2 / 4 / 8 (tools/strong_split_alone.sh)."""
+    if world == 1:
+        return 0, n_epochs
+
+    def counts(T):
+        out, b = [], 0.0
+        for r in range(world):
+            n = T if r == 0 else T - prefix_pass_cost - walk_cost * b
+            n = max(n, 0.0)
+            out.append(n)
+            b += n
+        return out
+
+    if walk_cost <= 0.0 and prefix_pass_cost <= 0.0:
+        b = [(k * n_epochs) // world for k in range(world + 1)]
+    else:
+        lo, hi = 0.0, float(n_epochs) + prefix_pass_cost + 1.0
+        for _ in range(80):  # the level T at which the ranges add up to the scenario
+            mid = 0.5 * (lo + hi)
+            if sum(counts(mid)) < n_epochs:
+                lo = mid
+            else:
+                hi = mid
+        c = counts(hi)
+        b = [0]
+        acc = 0.0
+        for r in range(world):
+            acc += c[r]
+            b.append(int(round(acc)))
         m = 1 if n_epochs >= world else 0  # every rank at least one epoch where there are enough of them
         b[0] = 0
         for k in range(1, world):
@@ -62,9 +91,6 @@ def epoch_range(rank, world, n_epochs, walk_cost=WALK_COST):
         b[world] = n_epochs
         for k in range(world - 1, 0, -1):
             b[k] = min(b[k], b[k + 1] - m)
-        return b
-
-    b = bounds()
     return b[rank], b[rank + 1] - b[rank]
 
 
