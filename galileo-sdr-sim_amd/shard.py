@@ -39,12 +39,12 @@ def rank_location_scenario(scenario_cls, nav_file, rank, duration_s=300.0, start
     return scenario_cls(nav_file, llh=llh, start=start, duration_s=duration_s, iono_enable=True, n_slots=n_slots).all(), llh
 
 
-WALK_COST = 0.1  # walking an epoch's NCO chains silently, relative to synthesising it (VALU work: walkers 37 M against
-                 # k_synth_g's 417 M wave-instructions per 1199 epochs; measured: +0.0001 ms of walker chain per prefix epoch against
-                 # 0.00107 ms of synthesis per epoch, profiles/r05m_strong_split_alone_before.log)
-PREFIX_PASS_COST = 215.0  # ... and what ANY prefix costs on top, in epochs of synthesis: legs in front of the executed range are never
+WALK_COST = 0.16  # walking an epoch's NCO chains silently, relative to synthesising it (VALU work: walkers 37 M against
+                 # k_synth_g's 417 M wave-instructions per 1199 epochs = 0.09; measured, ranks run alone on one GPU: +0.000145 ms of
+                 # walker chain per prefix epoch against 0.00088 ms of synthesis per epoch, profiles/r05n_strong_split_alone.log)
+PREFIX_PASS_COST = 200.0  # ... and what ANY prefix costs on top, in epochs of synthesis: legs in front of the executed range are never
                           # accepted by translation (their checkpoints do not exist, nothing could check them), so a rank with a prefix
-                          # runs a second walker pass: 0.44 ms of chain against 0.21 (same log) = 0.23 ms = 215 epochs of k_synth_g
+                          # runs a second walker pass: 0.40 ms of chain at prefix 0 against 0.22 (same log) = 0.18 ms = 200 epochs of k_synth_g
 
 
 def epoch_range(rank, world, n_epochs, walk_cost=WALK_COST, prefix_pass_cost=PREFIX_PASS_COST):
@@ -55,7 +55,7 @@ def epoch_range(rank, world, n_epochs, walk_cost=WALK_COST, prefix_pass_cost=PRE
     prefix b pays count + walk_cost * b + prefix_pass_cost (the second walker pass its prefix legs need).  Rank 0 therefore gets
     the longest range, and the later ranks shorter and shorter ones.  (walk_cost = 0 and prefix_pass_cost = 0: equal ranges.)
     Round 4's model had the proportional term only: ranks measured ALONE on one GPU were 16 % / 15 % / 9 % out of balance at
-    world 2 / 4 / 8 (tools/strong_split_alone.sh)."""
+    world 2 / 4 / 8 (tools/strong_split_alone.sh; with this model 1.09 / 1.06 / 1.07 at its first constants, profiles/r05n_*)."""
     if world == 1:
         return 0, n_epochs
 

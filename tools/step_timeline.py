@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-handle cycle of the pipelined bench out of a rocprofv3 --kernel-trace CSV: for every k_synth launch the time since the
-previous k_synth END on the same queue splits into host gap (k_synth end -> k_carr_guess start of that handle's next batch),
-walker chain (k_carr_guess start -> last walker kernel end) and wait (walker end -> k_synth start); plus the kernel's own
+previous k_synth END on the same queue splits into host gap (k_synth end -> first k_walk_carr of that handle's next batch),
+walker chain (that k_walk_carr's start -> last walker kernel end) and wait (walker end -> k_synth start); plus the kernel's own
 duration.  Medians over the steady-state launches.   tools/step_timeline.py <kernel_trace.csv> [label]"""
 import csv
 import statistics
@@ -18,16 +18,16 @@ def main():
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qcol], n.split("(")[0].replace("void ", "")))
     ev.sort()
     synth = [e for e in ev if e[3].startswith("k_synth")]
-    walkers = [e for e in ev if e[3].startswith(("k_carr_guess", "k_walk", "k_scanm", "k_carr_scan", "k_pages"))]
+    walkers = [e for e in ev if e[3].startswith(("k_walk", "k_scanm", "k_carr_scan", "k_pages"))]
     qs = sorted(set(e[2] for e in synth))
     out = {"gap": [], "walk": [], "wait": [], "synth": [], "cycle": []}
     for q in qs:
         s = [e for e in synth if e[2] == q]
         for a, b in zip(s[:-1], s[1:]):
             w = [e for e in walkers if a[1] <= e[0] <= b[0]]
-            # the walkers of THIS handle's next batch: those whose first kernel is a k_carr_guess after a's end; with two
+            # the walkers of THIS handle's next batch: those from the first k_walk_carr after a's end on; with two
             # handles the other handle's walkers run while a runs, not after it
-            g = [e for e in w if e[3].startswith("k_carr_guess")]
+            g = [e for e in w if e[3].startswith("k_walk_carr")]
             if not g:
                 continue
             g0 = g[0][0]

@@ -10,8 +10,8 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_carr_guess" in r["Kernel_Name"]]
-i0, i1 = idx[-3], idx[-2]
+idx = [i for i, r in enumerate(rows) if "k_publish" in r["Kernel_Name"]]  # (the last kernel of a call)
+i0, i1 = idx[-3] + 1, idx[-2] + 1
 t0 = int(rows[i0]["Start_Timestamp"])
 prev_end = t0
 for r in rows[i0:i1]:
