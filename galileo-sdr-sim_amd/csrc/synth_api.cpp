@@ -530,9 +530,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     //   rec_mode  the form of the resampled windows its code step takes (rw_mode_of) if its pattern thresholds are more than a bin
     //             apart from each other (k_synth's fast body needs that), else 0
     //   rec_g     ... and k_synth_g in that form: thresholds also a bin away from 0 and 1 (its group-start phase is approximate), and
-    //             a carrier step in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries per group (the table's
-    //             extension behind a wrap), and a phase that moves: a carrier that stands still ON an index boundary would have
-    //             every one of its groups listed for the exact replay
+    //             a carrier step of 0 or in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries per group (the
+    //             table's extension behind a wrap), and a phase that either moves or stands still for good: one that creeps past an
+    //             index boundary would have thousands of groups in a row listed for the exact replay
     std::vector<uint8_t> rec_mode((size_t)E * S, 0), rec_g((size_t)E * S, 0);
     double cs2_max = 0.0;  // largest code step of the batch, half chips per sample
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); h->rw_e0.assign(S, 0.0); }
@@ -570,7 +570,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             }
             cur_prn[s] = r.prn;
             const double ad = std::fabs(r.f_carr * delt);
-            const bool carr_ok = ad >= 9.094947017729282e-13 && 511.0 * ad * 16.0 <= 120.0;
+            // (a step of exactly zero is fine: the phase of the whole epoch is the checkpoint's, k_synth_g's loader lanes know its
+            // index exactly; a step below 2^-40 that is not zero creeps over index boundaries for thousands of groups on end)
+            const bool carr_ok = ad == 0.0 || (ad >= 9.094947017729282e-13 && 511.0 * ad * 16.0 <= 120.0);
             const double cs2 = 2.0 * (r.f_code * delt);
             cs2_max = std::max(cs2_max, cs2);
             const int mode = rw_mode_of(cs2);
@@ -614,6 +616,18 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     for (int m = 2; m <= 3; ++m)
         if (g_count[m] > g_count[g_mode]) g_mode = m;
     const long long n_grec = g_count[g_mode];
+    // epochs in which some record is not fit for k_synth_g in that form: the accumulating exact-replay launch behind it costs about
+    // what a whole k_synth_g launch costs PER EPOCH IT HAS WORK IN (its blocks run the slow body at this chunk length: measured 1.0 ms
+    // over 1199 epochs for one channel, tools/gated_cost.py), the other epochs' blocks leave at once
+    int n_exact_epochs = 0;
+    for (int e = 0; e < E; ++e) {
+        bool any = false;
+        for (int k = 0; k < nact_all[e] && !any; ++k) {
+            const size_t i = (size_t)e * S + act_all[(size_t)e * S + k];
+            any = !(rec_g[i] && rec_mode[i] == g_mode);
+        }
+        n_exact_epochs += any ? 1 : 0;
+    }
     if (state_in) {
         for (int s = 0; s < S; ++s)
             if (state_in[s].prn > 0 && !(std::fabs(state_in[s].carr_phase) < 1.0))
@@ -628,8 +642,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     // Doppler with the phase on the 1 / 1300 lattice of 2 x 1.023 / 2.6, a synthetic input -- lists a percent of its groups, and
     // k_repair_g then costs more than the exact-replay kernel; the next 8 batches of the handle take that one)
     if (h->g_holdoff > 0) h->g_holdoff -= 1;
-    // (the majority of the records must be fit for it: every exact launch behind it reads and writes the whole output once more)
-    bool fam_g = n_grec > 0 && 2 * n_grec >= n_records && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
+    // (... so splitting pays while fewer than half of the epochs have such records: k_synth alone takes 1.6 x k_synth_g's time)
+    bool fam_g = n_grec > 0 && 2 * n_exact_epochs <= E && R <= 0 && !(h->cfg.flags & GAL_CFG_EXACT_REPLAY) &&
                  nact_max > 0 && h->g_holdoff == 0 &&
                  (double)N * cs2_max / (2.0 * GAL_CODE_LEN) + 4.0 < (double)kGroupSyms &&
                  (double)E * (double)((N + kGroupChunk - 1) / kGroupChunk) * 64.0 < 4294967296.0;

@@ -585,6 +585,15 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         // and list every group of the epoch)
         r.yc = onl ? x + x : 0.5;
         r.pm = onl ? u2d(d2u(lp) ^ ((uint64_t)dsgnl << 32)) : 0.25;
+        if (onl && dabsl == 0.0) {
+            // a carrier that stands still (step exactly 0: `p += 0; p -= (long)p` leaves every phase of the epoch at the checkpoint's):
+            // the table index of all its samples is the reference's own expression on that phase, known EXACTLY here, so the group
+            // gets a phase in the middle of that entry -- no sample of it is ever undecided, even with the phase ON an index boundary
+            // (rounds 2-4 kept such batches off this kernel for that).  Entry = k + 512 for k >= 0, k + 511 below (SG_LUT_N layout).
+            // (on the mirrored phase, like every other: a step of -0.0 selects the conjugate table, whose entry for -k is LUT[k])
+            const int k = (int)(511.0 * r.pm);  // :509, before the & 511
+            r.pm = ((double)(k >= 0 ? k : k - 1) + 0.5) * (1.0 / 511.0);
+        }
         r.s = sl;
         r.dabs = dabsl;
         if (lane < NCH) {

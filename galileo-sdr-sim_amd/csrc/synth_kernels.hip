@@ -312,6 +312,27 @@ __global__ void k_walk_carr(DevPlan P, int first)
         seg_end = seg_end > A ? A : seg_end;
         const int n = (int)(seg_end - cur);
         const double d = P.dstep[ec * P.S + s];
+        if (d == 0.0) {
+            // a carrier that stands still: `p += 0; p -= (long)p` leaves the phase alone (it is never -0.0: gal_synth_plan), no wrap, no
+            // binade crossing.  A channel without Doppler has its anchor at the chain root, so every leg of it comes through here once
+            // per epoch in front of it (M-SYN12 with one such channel: 1 ms of walker chain, one dependent load per epoch): the
+            // still epochs behind this one are skipped eight at a time
+            long long e2 = (long long)ec + 1;
+            const long long eA = A / P.N;  // the epoch the leg lies in
+            while (e2 + 8 <= eA) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = P.dstep[(size_t)(e2 + q) * P.S + s];
+                bool still = true;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) still = still && v[q] == 0.0;
+                if (!still) break;
+                e2 += 8;
+            }
+            const long long skip_to = e2 * P.N;
+            cur = skip_to < A ? skip_to : A;
+            continue;
+        }
         const WalkOut o = carr_walk_track(p, d, 1.0 / __builtin_fabs(d), n, n, n, [](int, double) {});
         if (o.last_w >= 0) {
             lw = cur + o.last_w;

@@ -41,27 +41,36 @@ def test_group_kernel_negative_tiny_and_zero_phase(pkg):
 
 def test_group_kernel_gates(pkg):
     """The gate is per RECORD (channel-epoch), as the reference treats channels independently (src/galileo-sdr.cpp:487-534): a
-    carrier that stands still (every group of the channel sitting on an index boundary would be listed) or a carrier step beyond the
-    table's extension behind a wrap (60 kHz at 2.6 MS/s) takes that channel's records to an accumulating exact-replay launch behind
-    k_synth_g, the other channels stay on it (rounds 2-4: one such record sent the whole batch to the exact-replay kernel).  What
-    still keeps a whole batch there: a sample rate outside every form of the resampled windows, and records the group kernel cannot
-    take being the majority."""
+    carrier that creeps (a step below 2^-40 cycles per sample that is not zero: thousands of groups in a row within the rounding
+    drift of an index boundary) or a carrier step beyond the table's extension behind a wrap (60 kHz at 2.6 MS/s) takes that
+    channel's records to an accumulating exact-replay launch behind k_synth_g, the other channels stay on it (rounds 2-4: one such
+    record sent the whole batch to the exact-replay kernel).  A carrier that stands STILL (step exactly zero) stays on k_synth_g: its
+    loader lanes know the table index of the whole epoch exactly -- also with the phase ON an index boundary.  What still keeps a
+    whole batch on the exact-replay kernel: a sample rate outside every form of the resampled windows, and records the group kernel
+    cannot take in more than half of the epochs (the exact launch costs a k_synth_g launch per epoch it has work in)."""
     p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=4, n_slots=8, samples_per_epoch=52000, seed=314)
     q = p.copy()
     q["f_carr"][1:, 2] = 0.0
-    _, _, stats = _compare(pkg, q, 52000)
-    assert stats["kernel_family"] == 1 and stats["exact_records"] == 2
-    q = p.copy()
-    q["f_carr"][:, 1] = 60000.0
-    _, _, stats = _compare(pkg, q, 52000)
-    assert stats["kernel_family"] == 1 and stats["exact_records"] == 3
-    q["f_carr"][:, 1] = 30000.0  # 16 x 511 x 30e3 / 2.6e6 = 94 entries per group: inside
+    q["f_carr"][:, 3] = -0.0   # (the conjugate table's side of it)
+    q["carr_phase0"][0, 3] = 0.0  # ON an index boundary for good
+    q["carr_phase0"][0, 1] = -0.3
+    q["f_carr"][:, 1] = 0.0    # a negative phase standing still
     _, _, stats = _compare(pkg, q, 52000)
     assert stats["kernel_family"] == 1 and stats["exact_records"] == 0
     q = p.copy()
-    q["f_carr"][:, :3] = 0.0  # three of four channels stand still: the majority -- the whole batch on the exact-replay kernel
+    q["f_carr"][2:, 2] = 1e-9
+    _, _, stats = _compare(pkg, q, 52000)
+    assert stats["kernel_family"] == 1 and stats["exact_records"] == 1
+    q = p.copy()
+    q["f_carr"][0, 1] = 60000.0
+    _, _, stats = _compare(pkg, q, 52000)
+    assert stats["kernel_family"] == 1 and stats["exact_records"] == 1
+    q["f_carr"][:, 1] = 60000.0  # in every epoch: the whole batch on the exact-replay kernel
     _, _, stats = _compare(pkg, q, 52000)
     assert stats["kernel_family"] == 0 and stats["exact_records"] == 0
+    q["f_carr"][:, 1] = 30000.0  # 16 x 511 x 30e3 / 2.6e6 = 94 entries per group: inside
+    _, _, stats = _compare(pkg, q, 52000)
+    assert stats["kernel_family"] == 1 and stats["exact_records"] == 0
     r = pkg.workloads.make_synthetic(n_epochs=2, n_chan=4, n_slots=8, samples_per_epoch=50000, sample_rate=4.0e6, seed=3)
     _, _, stats = _compare(pkg, r, 50000, rate=4.0e6)
     assert stats["kernel_family"] == 0
@@ -71,18 +80,18 @@ def test_group_kernel_mixed_batches(pkg):
     """More of the per-record gate: 14 channels of which 3 are not fit for the group kernel in SOME epochs (two launches of it and
     one exact launch whose blocks leave at once in the epochs that have nothing for them), a channel that changes sides mid-batch, a
     listed group (k_repair_g replays ALL channels of its epoch, the exact launch's among them), page flips and code wraps on both
-    sides, a run split in two calls; and the CBOC mode with one still carrier."""
+    sides, a run split in two calls; and the CBOC mode with one creeping and one still carrier."""
     n = 52000
-    p = pkg.workloads.make_synthetic(n_epochs=7, n_chan=14, n_slots=16, samples_per_epoch=n, seed=2718)
-    p["f_carr"][2:5, 3] = 0.0          # stands still in epochs 2..4 only
-    p["f_carr"][:, 9] = -75000.0       # too fast throughout
-    p["f_carr"][5:, 12] = 1e-9         # below 2^-40 cycles per sample
+    p = pkg.workloads.make_synthetic(n_epochs=16, n_chan=14, n_slots=16, samples_per_epoch=n, seed=2718)
+    p["f_carr"][2:5, 3] = -2e-9        # creeps in epochs 2..4 only
+    p["f_carr"][:3, 9] = -75000.0      # too fast in the first three epochs
+    p["f_carr"][14:, 12] = 1e-9        # below 2^-40 cycles per sample at the end   (7 of the 16 epochs have such a record)
     p["f_code"][:, [3, 9, 12]] = 1.023e6 + p["f_carr"][:, [3, 9, 12]] * 0.0006493506493506494
     p["ibit0"][0, [3, 4]] = 499
     p["code_phase0"][0, [3, 4, 9]] = [4091.9, 4090.0, 4085.0]
     p["carr_phase0"][0, :6] = 0.0      # listed groups for certain
     _, _, stats = _compare(pkg, p, n)
-    assert stats["kernel_family"] == 1 and stats["exact_records"] == 3 + 7 + 2 and stats["repaired_groups"] >= 1
+    assert stats["kernel_family"] == 1 and stats["exact_records"] == 3 + 3 + 2 and stats["repaired_groups"] >= 1
     # split in two calls with the carried state
     ref_iq, ref_st = oracle_run(p, n, 2.6e6)
     with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) as eng:
@@ -90,16 +99,18 @@ def test_group_kernel_mixed_batches(pkg):
         q = p[3:].copy()
         q["flags"][0, :] = 0
         b, st_b, stats_b = eng.run_host(q, st_a)
-    assert np.array_equal(np.concatenate([a, b]), ref_iq) and stats_b["kernel_family"] == 1 and stats_b["exact_records"] == 2 + 4 + 2
+    # (the first call's three epochs all have one: it runs on the exact-replay kernel as a whole)
+    assert np.array_equal(np.concatenate([a, b]), ref_iq) and stats_b["kernel_family"] == 1 and stats_b["exact_records"] == 2 + 2
     act = ref_st["prn"] > 0
     assert np.array_equal(st_b["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
     c = pkg.workloads.make_synthetic(n_epochs=3, n_chan=5, n_slots=16, samples_per_epoch=n, seed=1618)
-    c["f_carr"][:, 2] = 0.0
-    c["f_code"][:, 2] = 1.023e6
+    c["f_carr"][1, 2] = 3e-9
+    c["f_code"][1, 2] = 1.023e6
+    c["f_carr"][:, 4] = 0.0  # (and one that stands still: stays on the group kernel)
     ref_c, _ = oracle_run(c, n, 2.6e6, cboc=True)
     with pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0, flags=pkg.synth.GAL_CFG_CBOC) as eng:
         iq, _, stats = eng.run_host(c)
-    assert np.array_equal(iq, ref_c) and stats["kernel_family"] == 1 and stats["exact_records"] == 3
+    assert np.array_equal(iq, ref_c) and stats["kernel_family"] == 1 and stats["exact_records"] == 1
 
 
 @pytest.mark.parametrize("rate,want", [(25e6, 2), (16e6, 2), (40e6, 2), (8e6, 3), (12.5e6, 3)])
