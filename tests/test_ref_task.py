@@ -3,8 +3,8 @@ from the reference's own text with its own flags -- no stand-in header or librar
 so the md5 of what it writes is the reference's answer, produced here.  CPU tests: the recorded golden md5s are reproduced by it,
 and the repository's front-end -> oracle chain equals it on scenarios that no recorded md5 covers.  GPU test: the product CLI's
 file equals the reference program's file byte for byte, both run on the same command line (the binary travels to the GPU box with
-oracle/_ref/; /root/reference is not needed at run time).  tools/ref_task_goldens.py (all nine goldens, profiles/r04_ref_task_md5.log)
-and tools/ref_task_fuzz.py (random scenarios, profiles/r04_ref_task_fuzz.log) are the long forms."""
+oracle/_ref/; /root/reference is not needed at run time).  tools/ref_task_goldens.py (all nine goldens, profiles/archive/r04_ref_task_md5.log)
+and tools/ref_task_fuzz.py (random scenarios, profiles/archive/r04_ref_task_fuzz.log) are the long forms."""
 import hashlib
 import json
 import os

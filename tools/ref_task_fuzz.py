@@ -9,9 +9,9 @@ the reference directly -- no recorded md5 in between.  CPU only; needs /root/ref
     python tools/ref_task_fuzz.py [n_cases] [seed] [jobs] [--cli]
 
 --cli (on the GPU box; the binary travels there with oracle/_ref/): the other side is the PRODUCT -- the galileo-sdr-sim CLI, front-end ->
-HIP -> file, on the same command line -- instead of front-end -> oracle; output of the round's run: profiles/r04_ref_task_fuzz_cli.log.
+HIP -> file, on the same command line -- instead of front-end -> oracle; output of the round's run: profiles/archive/r04_ref_task_fuzz_cli.log.
 --odd: the corners of the command line too -- -t or -l left out, fractional durations and seconds, the ends of the coordinate ranges,
-starts at the edges of the file's span (profiles/r04_ref_task_fuzz_odd.log).
+starts at the edges of the file's span (profiles/archive/r04_ref_task_fuzz_odd.log).
 --record F: besides comparing, write every case with the reference's md5 / byte count to the JSON file F (made HERE, where the reference
 runs in parallel); --replay F --cli: on the GPU box, take the reference's answers from F instead of running the reference there (it binds
 a fixed UDP port, so it runs one instance at a time without network namespaces): only the product runs (r04_ref_task_replay_cli.log).
@@ -19,7 +19,7 @@ a fixed UDP port, so it runs one instance at a time without network namespaces):
 
 A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
 exits with status 1 there too).  A case in which a satellite in view runs out of ephemeris is the reference's undefined behaviour
-(it indexes its vector with -1; seen: it never finishes) and is counted apart.  Output of the round's run: profiles/r04_ref_task_fuzz.log.  Test infrastructure.
+(it indexes its vector with -1; seen: it never finishes) and is counted apart.  Output of the round's run: profiles/archive/r04_ref_task_fuzz.log.  Test infrastructure.
 """
 import hashlib
 import multiprocessing as mp

@@ -8,11 +8,11 @@ Appendix A's stand-in headers; the judges' scratch builds); this run reproduces 
     python tools/ref_task_goldens.py --hip [names...]      (GPU box: oracle/_ref/ref_task_hip instead -- the reference's program with
                                                             its per-sample loop replaced by INTEGRATION.md section B's patch and linked
                                                             against libgalsynth.so; output of the round's run:
-                                                            profiles/r04_ref_task_hip_md5.log)
+                                                            profiles/archive/r04_ref_task_hip_md5.log)
 
 --O2: additionally builds oracle/_ref/ref_task_O2 (the same recipe with -O2 appended) and runs G8 through it: the reference's
 answer changes with the optimisation level there, and the recorded `md5_reference_O2` is that build's.
-Output of the round's run: profiles/r04_ref_task_md5.log.
+Output of the round's run: profiles/archive/r04_ref_task_md5.log.
 """
 import hashlib
 import json
