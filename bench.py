@@ -616,6 +616,9 @@ def main():
             "n_gpus": world,
             **({"rehearsal": "all %d ranks on GPU %d, backend %s: launch-path check, NOT a scaling measurement" % (
                 world, local_rank, backend)} if os.environ.get("GAL_BENCH_DEVICE") and world > 1 else {}),
+            **({"sink": "none: every rank synthesises into its own HBM (the engine).  With a file sink behind it (galileo-sdr-sim --sites) each "
+                        "rank is bounded by its device->host link and the host's page cache, 1.9-2.3 G samples/s per process on this "
+                        "host (DESIGN.md sections 6 and 7), and an aggregate over ranks measures the host, not the engine"} if world > 1 else {}),
             **({"ranks": per_rank, "report_backend": report_backend,
                 # walker chain + synthesis per step, slowest rank over the mean: what the split leaves on the table (strong split:
                 # shard.epoch_range cuts the ranges so that walk(prefix + range) + synth(range) is level)
