@@ -76,7 +76,8 @@ void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hipStream_t st
 void galk_touch(hipStream_t st);
 void galk_launch_walk_code(const DevPlan *P, hipStream_t st);
 void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
-void galk_launch_carr_scan(const DevPlan *P, hipStream_t st);
+void galk_launch_carr_scan(const DevPlan *P, uint32_t tag, hipStream_t st);
+size_t galk_scanm_status_bytes(int S, int legs);
 void galk_launch_verify_carr(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state, uint32_t *h_flag, uint32_t seq, hipStream_t st);
@@ -253,6 +254,7 @@ struct gal_synth {
     int *h_ctr = nullptr;  // pinned: [CTR_COUNT] counters, [CTR_COUNT] spare, then the completion flag (k_publish)
     uint32_t *h_flag = nullptr;  // = (uint32_t *)(h_ctr + 2 * CTR_COUNT): sequence number of the last batch whose record is complete
     uint32_t seq = 0;            // sequence number of the batch in flight
+    uint32_t scan_tag = 0;       // tag of the last multi-block stitch launched (k_scanm's look-back records carry it)
     int64_t legs_walked = 0, legs_translated = 0, n_fallbacks = 0;  // last finish(): carrier legs walked / translated
     std::vector<int64_t> act_prefix;  // [E + 1] active records in the epochs before e (a first walker pass walks W legs of each)
     int64_t first_pass_legs = 0;      // legs walked by the first passes of the batch in flight (every active leg; not counted on the device)
@@ -966,6 +968,8 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
         HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
         HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
+        // (the multi-block stitch's look-back records: none may carry a tag this handle is still going to hand out)
+        if (multi_scan) HIP_TRY(hipMemsetAsync(base + o_scanm, 0, galk_scanm_status_bytes(S, (int)LEGS), st_up));
         HIP_TRY(hipStreamSynchronize(st_up));
     }
     h->nact_max = nact_max;
@@ -1096,7 +1100,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->first_pass_legs = h->act_prefix[h->Pw.E] * h->P.W;
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, ws);  // (the first one also resets the batch's counters)
-        galk_launch_carr_scan(P, ws);
+        galk_launch_carr_scan(P, ++h->scan_tag, ws);
     }
     // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the carrier chain:
     // they run on a second stream beside it and join before k_synth.  (Enqueued after the carrier passes: every launch
@@ -1230,7 +1234,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
                             ctr_walk[CTR_PASSES], ctr_walk[CTR_UNVERIFIED]);
             for (int k = 0; k < 2; ++k) {
                 galk_launch_walk_carr(P, 0, st);
-                galk_launch_carr_scan(P, st);
+                galk_launch_carr_scan(P, ++h->scan_tag, st);
             }
             HIP_TRY(hipMemcpyAsync(ctr_walk, P->ctr, CTR_COUNT * sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -1264,7 +1268,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
                 return fail(GAL_E_CHAIN, "carrier walk did not converge in %d passes", ctr_walk[CTR_PASSES]);
             for (int k = 0; k < 2; ++k) {
                 galk_launch_walk_carr(&Pw, first, st);
-                galk_launch_carr_scan(&Pw, st);
+                galk_launch_carr_scan(&Pw, ++h->scan_tag, st);
                 if (first) h->first_pass_legs += h->act_prefix[h->Pw.E] * h->P.W;
                 first = 0;
             }

@@ -498,7 +498,18 @@ struct DMap {
     double c[4];  // else result = D + c[residue(D)]
 };
 
-__device__ __forceinline__ double dmap_apply(const DMap &f, double D) { return f.isconst ? f.K : D + f.c[d_residue(D)]; }
+// (bit masks, not c[r] and not a chain of selects, which the compiler turns back into c[r]: a register array indexed by a lane's
+// value lives in scratch memory, and these maps sit on the latency path of the stitch kernels)
+__device__ __forceinline__ double dmap_pick(const DMap &f, int r)
+{
+    const long long b0 = __double_as_longlong(f.c[0]), b1 = __double_as_longlong(f.c[1]), b2 = __double_as_longlong(f.c[2]),
+                    b3 = __double_as_longlong(f.c[3]);
+    const long long lo = (r & 1) ? b1 : b0, hi = (r & 1) ? b3 : b2;
+    const long long m = -(long long)((r >> 1) & 1);
+    return __longlong_as_double((hi & m) | (lo & ~m));
+}
+
+__device__ __forceinline__ double dmap_apply(const DMap &f, double D) { return f.isconst ? f.K : D + dmap_pick(f, d_residue(D)); }
 
 __device__ __forceinline__ DMap dmap_combine(const DMap &a, const DMap &b)  // a then b
 {
@@ -515,7 +526,7 @@ __device__ __forceinline__ DMap dmap_combine(const DMap &a, const DMap &b)  // a
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const double mid = (double)m * GAL_U52 + a.c[m];
-        r.c[m] = a.c[m] + b.c[d_residue(mid)];
+        r.c[m] = a.c[m] + dmap_pick(b, d_residue(mid));
     }
     return r;
 }
@@ -802,352 +813,342 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
 }
 
 // ---- The same stitch as k_carr_scan for LONG batches, in 256-thread blocks.  k_carr_scan needs 16 waves and 72 KB of
-// LDS on ONE CU; beside a running k_synth (3 x 168 VGPRs per SIMD, 96 KB of LDS per CU) that means waiting for a CU to
-// drain completely, and with 2999 epochs the walker chain of the next step then takes longer than the synthesis it is
-// supposed to hide behind (2.9 ms against 2.5 ms).  Here the legs of a slot are spread over B blocks of 256 threads
-// (one wave per SIMD: such a block starts as soon as ONE synthesis block retires), SCANM_K legs per thread (one: the
-// apply phase translates legs on the spot, 33 read-modify-writes each -- round 2 had four with the translations elsewhere); what the
-// single block did with two block-wide scans is done with block-local scans plus a serial fold of the (few) block
-// totals in front of each block -- three short launches instead of one long one, the same sequential statement.
+// LDS on ONE CU; beside a running synthesis kernel (every SIMD's register file full, most of the LDS) that means waiting for a CU
+// to drain completely, and with 2999 epochs the walker chain of the next step then takes longer than the synthesis it is supposed
+// to hide behind.  Here the legs of a slot are spread over B blocks of 256 threads (one wave per SIMD: such a block starts as soon
+// as ONE synthesis block retires), one leg per thread, and what the single block does with two block-wide scans is done with
+// block-local scans plus a LOOK-BACK over the blocks in front, inside ONE launch (round 5; rounds 2-4: three launches -- claims,
+// fold, apply -- with the block totals handed over through kernel boundaries).  A block publishes the aggregate of its legs as
+// soon as its local scan is done; then its threads fetch the aggregates of ALL blocks in front of it, one record per thread (each
+// waits until that record carries this launch's tag), and the waves fold them in order -- both the claim chain ("the last one
+// that speaks") and the fold (segmented AND + D map) are associative, so this is the sequential statement.  No block waits for
+// another's PREFIX, only for aggregates, which every block publishes before it waits for anything: no chain of waits.  Which
+// legs a block takes is decided by a TICKET it draws when it starts, not by blockIdx: a block only ever waits for blocks with a
+// lower ticket, and those are running or done -- no assumption about the order in which the hardware dispatches a grid over the
+// XCDs.  Records carry the launch's tag, so nothing has to be cleared between passes.
+//   What it costs (tools/scanm_stamps.py, 1199 epochs: 38 blocks per slot, 608 in all, 80 us alone on the device): the two
+// exchanges are 15-25 us each -- an agent-scope store and the loads that wait for it cross the fabric between the XCDs, 2-3 us
+// a trip and four trips per exchange -- which is what the two kernel boundaries cost before; the checkpoint shifts at the end
+// are 17 us (80 MB read + written); the scans themselves 1 + 4 us.
 #define SCANM_THREADS 256
-#define SCANM_K 1
 
-struct ScanM {  // scratch of the multi-block stitch, per slot: G = B * SCANM_THREADS thread records, B block records
-    int B, G;
-    int *t1_kind; long long *t1_w; double *t1_r;      // [S][G] block-local inclusive claim scan
-    int *b1_kind; long long *b1_w; double *b1_r;      // [S][B] block totals
-    int *t2_fv, *t2_v, *t2_ic; double *t2_K, *t2_c;   // [S][G] (+ [4] for c) block-local inclusive fold scan
-    int *b2_fv, *b2_v, *b2_ic; double *b2_K, *b2_c;   // [S][B]
+struct ScanM {  // look-back records of the multi-block stitch: [S][B] each
+    int B;
+    uint32_t tag;                                     // of this launch (non-zero)
+    int nap;                                          // 64-cycle naps between two looks at a record that is not there yet
+    uint32_t *cnt;                                    // [S] tickets drawn so far (B per launch and slot)
+    uint32_t *st1, *st2;                              // tag of the launch whose claim / fold aggregate the record holds
+    int *a1_kind; long long *a1_w; double *a1_r;      // claims: the block's last speaker
+    int *a2_f; double *a2_K, *a2_c;                   // fold: f = fv | v << 1 | isconst << 2; c: [4]
 };
 
-__device__ __forceinline__ void scanm_range(const DevPlan &P, int g, int *i0, int *i1)
-{
-    const int a = g * SCANM_K;
-    *i0 = a < P.LEGS ? a : P.LEGS;
-    *i1 = a + SCANM_K < P.LEGS ? a + SCANM_K : P.LEGS;
-}
-
-// phase A: claim summary of my legs + block-local "last one that speaks" scan
-__global__ __launch_bounds__(SCANM_THREADS) void k_scanm_claims(DevPlan P, ScanM M)
-{
-    GAL_WALK_SETPRIO();
-    if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    __shared__ int s_kind[SCANM_THREADS];
-    __shared__ long long s_w[SCANM_THREADS];
-    __shared__ double s_r[SCANM_THREADS];
-    const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    const int g = b * SCANM_THREADS + t;
-    const double start0 = P.state_in[s].carr_phase;
-    int i0, i1;
-    scanm_range(P, g, &i0, &i1);
-    ClaimState mine = {0, 0, 0.0};
-    for (int i = i0; i < i1; ++i) {
-        const LegRec L = leg_load(P, s, i, start0);
-        if (!L.act) {
-            mine.kind = 2;
-        } else {
-            if (L.root) {
-                mine.kind = 1;
-                mine.w = L.A;
-                mine.r = L.known;
-            }
-            if (L.hw) {
-                mine.kind = 1;
-                mine.w = L.cw;
-                mine.r = L.cr;
-            }
-        }
-    }
-    s_kind[t] = mine.kind;
-    s_w[t] = mine.w;
-    s_r[t] = mine.r;
-    __syncthreads();
-    for (int off = 1; off < SCANM_THREADS; off <<= 1) {
-        int k2 = 0;
-        long long w2 = 0;
-        double r2 = 0.0;
-        const bool take = t >= off && s_kind[t] == 0;
-        if (take) {
-            k2 = s_kind[t - off];
-            w2 = s_w[t - off];
-            r2 = s_r[t - off];
-        }
-        __syncthreads();
-        if (take) {
-            s_kind[t] = k2;
-            s_w[t] = w2;
-            s_r[t] = r2;
-        }
-        __syncthreads();
-    }
-    const size_t o = (size_t)s * M.G + g;
-    M.t1_kind[o] = s_kind[t];
-    M.t1_w[o] = s_w[t];
-    M.t1_r[o] = s_r[t];
-    if (t == SCANM_THREADS - 1) {
-        const size_t ob = (size_t)s * M.B + b;
-        M.b1_kind[ob] = s_kind[t];
-        M.b1_w[ob] = s_w[t];
-        M.b1_r[ob] = s_r[t];
-    }
-}
-
-// claim carry in front of block b: the last block before it whose total says anything.  The totals are staged through
-// LDS by the whole block (one record per thread, all loads in flight together), then one thread walks them: a serial
-// walk over global memory costs a round trip per block total, which is what tied the stitch to few, fat blocks.
-struct ScanCarryLds {
-    int kind[SCANM_THREADS];
-    long long w[SCANM_THREADS];
-    double r[SCANM_THREADS];
+struct FoldRec {
+    int fv, v;
+    DMap m;
 };
 
-__device__ __forceinline__ void scanm_claim_carry(const ScanM &M, int s, int b, int t, ScanCarryLds &L, ClaimState *out)
+__device__ __forceinline__ FoldRec fold_identity()
 {
-    ClaimState c = {0, 0, 0.0};
-    for (int base = 0; base < b; base += SCANM_THREADS) {
-        const int bb = base + t;
-        if (bb < b) {
-            const size_t ob = (size_t)s * M.B + bb;
-            L.kind[t] = M.b1_kind[ob];
-            L.w[t] = M.b1_w[ob];
-            L.r[t] = M.b1_r[ob];
-        }
-        __syncthreads();
-        if (t == 0) {
-            const int n = b - base < SCANM_THREADS ? b - base : SCANM_THREADS;
-            for (int k = 0; k < n; ++k)
-                if (L.kind[k] != 0) {
-                    c.kind = L.kind[k];
-                    c.w = L.w[k];
-                    c.r = L.r[k];
-                }
-        }
-        __syncthreads();
-    }
-    if (t == 0) *out = c;
-    __syncthreads();
+    FoldRec r;
+    r.fv = 0; r.v = 1;
+    r.m.isconst = 0; r.m.K = 0.0; r.m.c[0] = r.m.c[1] = r.m.c[2] = r.m.c[3] = 0.0;
+    return r;
 }
 
-__device__ __forceinline__ ClaimState scanm_lc0(const ScanM &M, int s, int b, int t, const ClaimState &carry)
+__device__ __forceinline__ FoldRec fold_combine(const FoldRec &a, const FoldRec &b)  // a then b
 {
-    ClaimState lc = carry;
-    if (t > 0) {
-        const size_t o = (size_t)s * M.G + (size_t)b * SCANM_THREADS + t - 1;
-        if (M.t1_kind[o] != 0) {
-            lc.kind = M.t1_kind[o];
-            lc.w = M.t1_w[o];
-            lc.r = M.t1_r[o];
-        }
-    }
-    return lc;
+    FoldRec r;
+    r.fv = a.fv | b.fv;
+    r.v = b.fv ? b.v : (a.v & b.v);
+    r.m = dmap_combine(a.m, b.m);
+    return r;
 }
 
-// phase B: fold my legs (segmented AND + D map) + block-local inclusive scan of the folds
-__global__ __launch_bounds__(SCANM_THREADS) void k_scanm_fold(DevPlan P, ScanM M)
+template <class T>
+__device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Every word of a record is written and read with agent-scope atomics (sc1: past the XCD's own L2), so record traffic needs no
+// cache maintenance -- an agent-scope FENCE here would write back / invalidate the XCD's whole L2 in every wave of every block
+// (measured: the fused kernel slower than the three launches it replaces).  What is needed is order: payload before tag on the
+// writer's side, tag before payload on the reader's -- the memory counter drained, nothing moved across by the compiler.
+#define SCANM_ORDER() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+#ifdef GAL_TEST_HOOKS
+// where k_scanm's time goes (tools/scanm_stamps.py): the 100 MHz wall clock at nine points of every block
+#define SCANM_NSTAMP 9
+#define SCANM_STAMP_BLOCKS 4096
+__device__ unsigned long long g_scanm_stamp[SCANM_STAMP_BLOCKS * SCANM_NSTAMP];  // [block][stage]: plain stores, nothing shared
+#define SCANM_STAMP(i)                                                                             \
+    do {                                                                                           \
+        const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x;                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  /* (pins the stamp: nothing in flight across it) */ \
+        if (threadIdx.x == 0 && lin_ < SCANM_STAMP_BLOCKS) g_scanm_stamp[lin_ * SCANM_NSTAMP + (i)] = wall_clock64(); \
+        asm volatile("" ::: "memory");                                                             \
+    } while (0)
+#else
+#define SCANM_STAMP(i) do { } while (0)
+#endif
+
+// wait until record `o` carries this launch's tag (the block that writes it drew its ticket before the one that waits: it is
+// running or done)
+__device__ __forceinline__ void scanm_wait(const uint32_t *st, size_t o, uint32_t tag, int nap)
+{
+    while (ld_agent(st + o) != tag)
+        for (int n = 0; n < nap; ++n) __builtin_amdgcn_s_sleep(1);
+    SCANM_ORDER();
+}
+
+// Wave-wide inclusive scans of the two chains by lane shuffles (six steps, no LDS round trips, no barriers), and the step across
+// a block's four waves: each wave's total through LDS, one barrier.  This kernel runs once per batch, every CU executes its code
+// cold, and tools/scanm_stamps.py shows the time going where code is executed for the FIRST time, whatever it does (a block
+// with nothing in front of it spends 11 us in a look-back of two barriers when the look-back's code is new, 1 us when the
+// block-local scan has already fetched it): what counts is the number of instruction-cache lines on the path.  So the scans
+// are real functions (__noinline__), called for the block's own legs and again for the aggregates of the blocks in front, and
+// their loops stay rolled.
+__device__ __forceinline__ ClaimState claim_shfl_up(const ClaimState &c, int off)
+{
+    ClaimState a;
+    a.kind = __shfl_up(c.kind, off);
+    a.w = __shfl_up(c.w, off);
+    a.r = __shfl_up(c.r, off);
+    return a;
+}
+
+__device__ __forceinline__ ClaimState claim_wave_scan(ClaimState c, int lane)  // "the last one that speaks", inclusive
+{
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) {
+        const ClaimState a = claim_shfl_up(c, off);
+        if (lane >= off && c.kind == 0) c = a;
+    }
+    return c;
+}
+
+__device__ __forceinline__ FoldRec fold_shfl_up(const FoldRec &r, int off)
+{
+    FoldRec a;
+    const int f = __shfl_up(r.fv | (r.v << 1) | (r.m.isconst << 2), off);
+    a.fv = f & 1; a.v = (f >> 1) & 1; a.m.isconst = (f >> 2) & 1;
+    a.m.K = __shfl_up(r.m.K, off);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a.m.c[m] = __shfl_up(r.m.c[m], off);
+    return a;
+}
+
+__device__ __forceinline__ FoldRec fold_wave_scan(FoldRec r, int lane)
+{
+#pragma unroll 1
+    for (int off = 1; off < 64; off <<= 1) {
+        const FoldRec a = fold_shfl_up(r, off);
+        if (lane >= off) r = fold_combine(a, r);
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
 {
     GAL_WALK_SETPRIO();
     if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    __shared__ int s_fv[SCANM_THREADS], s_v[SCANM_THREADS], s_ic[SCANM_THREADS];
-    __shared__ double s_K[SCANM_THREADS], s_c[4][SCANM_THREADS];
-    __shared__ ClaimState s_carry;
-    const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    const int g = b * SCANM_THREADS + t;
-    const double start0 = P.state_in[s].carr_phase;
-    int i0, i1;
-    scanm_range(P, g, &i0, &i1);
-    __shared__ ScanCarryLds s_stage;
-    scanm_claim_carry(M, s, b, t, s_stage, &s_carry);
-    {
-        ClaimState lc = scanm_lc0(M, s, b, t, s_carry);
-        int allok = 1, fv = 0, isconst = 0;
-        double D4[4] = {0.0, GAL_U52, 2.0 * GAL_U52, 3.0 * GAL_U52};
-        for (int i = i0; i < i1; ++i) {
-            const LegRec L = leg_load(P, s, i, start0);
-            const LegOp o = leg_op(P, s, L, lc);
-            if (!o.act) {
-                allok = 0;
-                fv = 1;
-            } else {
-                if (o.root) {
-                    allok = 1;
-                    fv = 1;
-                }
-                allok &= o.link_ok ? 1 : 0;
-            }
-            if (!o.act || o.root || (o.hw && !o.same)) isconst = 1;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, D4[m]);
-        }
-        s_fv[t] = fv;
-        s_v[t] = allok;
-        s_ic[t] = isconst;
-        s_K[t] = D4[0];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) s_c[m][t] = D4[m] - (double)m * GAL_U52;
-    }
+    constexpr int NW = SCANM_THREADS / 64;
+    __shared__ ClaimState s_ct[NW];   // the waves' totals, claim chain / fold
+    __shared__ FoldRec s_ft[NW];
+    __shared__ ClaimState s_carry1;   // what the blocks in front amount to
+    __shared__ FoldRec s_carry2;
+    __shared__ int s_unver, s_rewalk, s_shifts, s_last, s_ticket;
+    const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_ticket = (int)(atomicAdd(&M.cnt[s], 1u) % (uint32_t)M.B);  // (every launch draws exactly B per slot, or none)
     __syncthreads();
-    for (int off = 1; off < SCANM_THREADS; off <<= 1) {
-        const bool has = t >= off;
-        int afv = 0, av = 1;
-        DMap a, bb;
-        a.isconst = 0; a.K = 0.0; a.c[0] = a.c[1] = a.c[2] = a.c[3] = 0.0;
-        if (has) {
-            afv = s_fv[t - off];
-            av = s_v[t - off];
-            a.isconst = s_ic[t - off];
-            a.K = s_K[t - off];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) a.c[m] = s_c[m][t - off];
-        }
-        const int bfv = s_fv[t], bv = s_v[t];
-        bb.isconst = s_ic[t];
-        bb.K = s_K[t];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) bb.c[m] = s_c[m][t];
-        __syncthreads();
-        if (has) {
-            const DMap r = dmap_combine(a, bb);
-            s_fv[t] = afv | bfv;
-            s_v[t] = bfv ? bv : (av & bv);
-            s_ic[t] = r.isconst;
-            s_K[t] = r.K;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) s_c[m][t] = r.c[m];
-        }
-        __syncthreads();
-    }
-    const size_t o = (size_t)s * M.G + g;
-    M.t2_fv[o] = s_fv[t];
-    M.t2_v[o] = s_v[t];
-    M.t2_ic[o] = s_ic[t];
-    M.t2_K[o] = s_K[t];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) M.t2_c[o * 4 + m] = s_c[m][t];
-    if (t == SCANM_THREADS - 1) {
-        const size_t ob = (size_t)s * M.B + b;
-        M.b2_fv[ob] = s_fv[t];
-        M.b2_v[ob] = s_v[t];
-        M.b2_ic[ob] = s_ic[t];
-        M.b2_K[ob] = s_K[t];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) M.b2_c[ob * 4 + m] = s_c[m][t];
-    }
-}
-
-// phase C: replay my legs with the true carries and apply (sweep 3 of k_carr_scan)
-__global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM M)
-{
-    GAL_WALK_SETPRIO();
-    if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    __shared__ int s_unver, s_rewalk, s_shifts, s_last;
-    const int s = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
-    const int g = b * SCANM_THREADS + t;
+    const int b = s_ticket;
+    const int i = b * SCANM_THREADS + t;  // my leg
+    const bool in = i < P.LEGS;
+    const size_t ob = (size_t)s * M.B + b;
     if (t == 0) {
         s_unver = 0;
         s_rewalk = 0;
         s_shifts = 0;
     }
-    __syncthreads();
+    SCANM_STAMP(0);
     const double start0 = P.state_in[s].carr_phase;
-    int i0, i1;
-    scanm_range(P, g, &i0, &i1);
-    // carries in front of my block: the totals of the blocks before it, staged through LDS and folded by thread 0
-    __shared__ ClaimState s_carry;
-    __shared__ int s_cfv, s_cv, s_cic;
-    __shared__ double s_cK, s_cc[4];
-    __shared__ ScanCarryLds s_stage;
-    __shared__ int s_bfv[SCANM_THREADS], s_bv[SCANM_THREADS], s_bic[SCANM_THREADS];
-    __shared__ double s_bK[SCANM_THREADS], s_bc[SCANM_THREADS][4];
-    scanm_claim_carry(M, s, b, t, s_stage, &s_carry);
+    LegRec L;
+    L.act = false; L.root = false; L.dirty = false; L.hw = false; L.tdir = 0; L.A = 0; L.aw = 0; L.cw = -1; L.ar = 0.0; L.cr = 0.0; L.known = 0.0;
+    if (in) L = leg_load(P, s, i, start0);
+    SCANM_STAMP(1);
+
+    // ---- phase 1: the claim chain.  My leg's word, the block's "last one that speaks" scan, the block's aggregate out, the
+    // claim state in front of the block in
+    ClaimState lc = {0, 0, 0.0};  // (becomes: the claim state in front of MY leg)
     {
-        int cfv = 0, cv = 1;
-        DMap cm;
-        cm.isconst = 0; cm.K = 0.0; cm.c[0] = cm.c[1] = cm.c[2] = cm.c[3] = 0.0;
-        for (int base = 0; base < b; base += SCANM_THREADS) {
-            const int bb = base + t;
-            if (bb < b) {
-                const size_t ob = (size_t)s * M.B + bb;
-                s_bfv[t] = M.b2_fv[ob];
-                s_bv[t] = M.b2_v[ob];
-                s_bic[t] = M.b2_ic[ob];
-                s_bK[t] = M.b2_K[ob];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) s_bc[t][m] = M.b2_c[ob * 4 + m];
+        ClaimState mine = {0, 0, 0.0};
+        if (in) {
+            if (!L.act) {
+                mine.kind = 2;
+            } else {
+                if (L.root) { mine.kind = 1; mine.w = L.A; mine.r = L.known; }
+                if (L.hw) { mine.kind = 1; mine.w = L.cw; mine.r = L.cr; }
             }
+        }
+        const ClaimState inc = claim_wave_scan(mine, lane);
+        if (lane == 63) s_ct[wv] = inc;
+        lc = claim_shfl_up(inc, 1);
+        if (lane == 0) lc.kind = 0;
+    }
+    __syncthreads();
+    {
+        ClaimState wp = {0, 0, 0.0};  // the waves in front of mine, within the block
+#pragma unroll 1
+        for (int w2 = 0; w2 < NW; ++w2)
+            if (w2 < wv && s_ct[w2].kind != 0) wp = s_ct[w2];
+        if (lc.kind == 0) lc = wp;
+    }
+    SCANM_STAMP(2);
+    if (t == 0 && b + 1 < M.B) {  // the block's aggregate out, for the blocks behind
+        ClaimState agg = {0, 0, 0.0};
+#pragma unroll 1
+        for (int w2 = 0; w2 < NW; ++w2)
+            if (s_ct[w2].kind != 0) agg = s_ct[w2];
+        st_agent(M.a1_kind + ob, agg.kind);
+        st_agent(M.a1_w + ob, agg.w);
+        st_agent(M.a1_r + ob, agg.r);
+        SCANM_ORDER();
+        st_agent(M.st1 + ob, M.tag);
+    }
+    {
+        // ... and the aggregates of the blocks in front in: one record per thread, scanned by the waves as above
+        ClaimState carry = {0, 0, 0.0};
+        for (int base = 0; base < b; base += SCANM_THREADS) {
+            __syncthreads();  // (s_ct: everybody has read the previous round's totals)
+            const int q = base + t;
+            ClaimState rec = {0, 0, 0.0};
+            if (q < b) {
+                const size_t oq = (size_t)s * M.B + q;
+                scanm_wait(M.st1, oq, M.tag, M.nap);
+                rec.kind = ld_agent(M.a1_kind + oq);
+                rec.w = ld_agent(M.a1_w + oq);
+                rec.r = ld_agent(M.a1_r + oq);
+            }
+            rec = claim_wave_scan(rec, lane);
+            if (lane == 63) s_ct[wv] = rec;
             __syncthreads();
             if (t == 0) {
-                const int n = b - base < SCANM_THREADS ? b - base : SCANM_THREADS;
-                for (int k = 0; k < n; ++k) {
-                    const int bfv = s_bfv[k], bv = s_bv[k];
-                    DMap bm;
-                    bm.isconst = s_bic[k];
-                    bm.K = s_bK[k];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) bm.c[m] = s_bc[k][m];
-                    const DMap r = dmap_combine(cm, bm);
-                    cv = bfv ? bv : (cv & bv);
-                    cfv = cfv | bfv;
-                    cm = r;
-                }
+#pragma unroll 1
+                for (int w2 = 0; w2 < NW; ++w2)
+                    if (s_ct[w2].kind != 0) carry = s_ct[w2];
             }
-            __syncthreads();
         }
-        if (t == 0) {
-            s_cfv = cfv; s_cv = cv; s_cic = cm.isconst; s_cK = cm.K;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) s_cc[m] = cm.c[m];
-        }
+        if (t == 0) s_carry1 = carry;
     }
     __syncthreads();
-    // prefix in front of my legs = (carry of my block) then (local inclusive scan of the thread before me)
-    int pfv = s_cfv, pv = s_cv;
-    DMap pm;
-    pm.isconst = s_cic;
-    pm.K = s_cK;
+    SCANM_STAMP(3);
+    if (lc.kind == 0) lc = s_carry1;
+
+    // ---- phase 2: the fold (segmented AND of the links, D map evaluated on the four residues)
+    LegOp o;
+    o.act = false; o.root = false; o.have = false; o.link_ok = false; o.hw = false; o.same = false; o.tdir = 0; o.nw = 0; o.base = 0.0; o.G = 0.0;
+    FoldRec pre;  // (becomes: the fold of everything in front of MY leg)
+    {
+        FoldRec f = fold_identity();
+        if (in) {
+            ClaimState lcc = lc;
+            o = leg_op(P, s, L, lcc);
+            int allok = 1, fv = 0;
+            if (!o.act) {
+                allok = 0;
+                fv = 1;
+            } else {
+                if (o.root) fv = 1;
+                allok = o.link_ok ? 1 : 0;
+            }
+            double D4[4] = {0.0, GAL_U52, 2.0 * GAL_U52, 3.0 * GAL_U52};
 #pragma unroll
-    for (int m = 0; m < 4; ++m) pm.c[m] = s_cc[m];
-    if (t > 0) {
-        const size_t o = (size_t)s * M.G + g - 1;
-        const int bfv = M.t2_fv[o], bv = M.t2_v[o];
-        DMap bm;
-        bm.isconst = M.t2_ic[o];
-        bm.K = M.t2_K[o];
+            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, D4[m]);
+            f.fv = fv;
+            f.v = allok;
+            f.m.isconst = (!o.act || o.root || (o.hw && !o.same)) ? 1 : 0;
+            f.m.K = D4[0];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) bm.c[m] = M.t2_c[o * 4 + m];
-        const DMap r = dmap_combine(pm, bm);
-        pv = bfv ? bv : (pv & bv);
-        pfv = pfv | bfv;
-        pm = r;
+            for (int m = 0; m < 4; ++m) f.m.c[m] = D4[m] - (double)m * GAL_U52;
+        }
+        const FoldRec inc = fold_wave_scan(f, lane);
+        if (lane == 63) s_ft[wv] = inc;
+        pre = fold_shfl_up(inc, 1);
+        if (lane == 0) pre = fold_identity();
     }
-    ClaimState lc = scanm_lc0(M, s, b, t, s_carry);
-    int allok = pfv ? pv : 0;  // nothing is verified before the first root
-    double D = pm.isconst ? pm.K : pm.c[0];  // the prefix map applied to D = 0
+    __syncthreads();
+    {
+        FoldRec wp = fold_identity();
+#pragma unroll 1
+        for (int w2 = 0; w2 < NW; ++w2)
+            if (w2 < wv) wp = fold_combine(wp, s_ft[w2]);
+        pre = fold_combine(wp, pre);
+    }
+    SCANM_STAMP(4);
+    if (t == 0 && b + 1 < M.B) {
+        FoldRec agg = s_ft[0];
+#pragma unroll 1
+        for (int w2 = 1; w2 < NW; ++w2) agg = fold_combine(agg, s_ft[w2]);
+        st_agent(M.a2_f + ob, agg.fv | (agg.v << 1) | (agg.m.isconst << 2));
+        st_agent(M.a2_K + ob, agg.m.K);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) st_agent(M.a2_c + ob * 4 + m, agg.m.c[m]);
+        SCANM_ORDER();
+        st_agent(M.st2 + ob, M.tag);
+    }
+    {
+        FoldRec carry = fold_identity();
+        for (int base = 0; base < b; base += SCANM_THREADS) {
+            __syncthreads();
+            const int q = base + t;
+            FoldRec rec = fold_identity();
+            if (q < b) {
+                const size_t oq = (size_t)s * M.B + q;
+                scanm_wait(M.st2, oq, M.tag, M.nap);
+                const int fl = ld_agent(M.a2_f + oq);
+                rec.fv = fl & 1; rec.v = (fl >> 1) & 1; rec.m.isconst = (fl >> 2) & 1;
+                rec.m.K = ld_agent(M.a2_K + oq);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) rec.m.c[m] = ld_agent(M.a2_c + oq * 4 + m);
+            }
+            rec = fold_wave_scan(rec, lane);
+            if (lane == 63) s_ft[wv] = rec;
+            __syncthreads();
+            if (t == 0) {
+#pragma unroll 1
+                for (int w2 = 0; w2 < NW; ++w2) carry = fold_combine(carry, s_ft[w2]);
+            }
+        }
+        if (t == 0) s_carry2 = carry;
+    }
+    __syncthreads();
+
+    SCANM_STAMP(5);
+    // ---- phase 3: my leg with the true carries (sweep 3 of k_carr_scan), translations on the spot
+    pre = fold_combine(s_carry2, pre);
+    int allok = pre.fv ? pre.v : 0;                          // nothing is verified before the first root
+    double D = pre.m.isconst ? pre.m.K : pre.m.c[0];         // the prefix map applied to D = 0
     int unver = 0, rewalk = 0, shifts = 0;
     TrRec tr = {0.0, 0.0, 0, 0, 0, 0};
-    for (int i = i0; i < i1; ++i) {
-        const LegRec L = leg_load(P, s, i, start0);
-        const LegOp o = leg_op(P, s, L, lc);
+    if (in) {
         if (!o.act) {
             allok = 0;
-            D = 0.0;
-            continue;
+        } else {
+            if (o.root) {
+                allok = 1;
+                D = 0.0;
+            }
+            allok &= o.link_ok ? 1 : 0;
+            const double nr = o.base + D;
+            stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts, &tr);
         }
-        if (o.root) {
-            allok = 1;
-            D = 0.0;
-        }
-        allok &= o.link_ok ? 1 : 0;
-        const double nr = o.base + D;
-        D = leg_d_out(o, D);
-        stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts, &tr);
     }
+    SCANM_STAMP(6);
     if (unver) atomicAdd(&s_unver, unver);
     if (rewalk) atomicAdd(&s_rewalk, rewalk);
     if (shifts) atomicAdd(&s_shifts, shifts);
     // The checkpoint shifts of the block's translated legs, done by the whole block: thread t takes checkpoint t % 32 (+ 32,
     // + 64 ...) of leg t / 32 (+ 8, + 16 ...), so a wave touches two runs of 256 contiguous bytes per access instead of 64
     // cache lines (one leg per lane, as the walker kernel did it in round 2: 16x the traffic, 77 us of the chain)
-    static_assert(SCANM_K == 1, "the cooperative translation below assumes one leg per thread");
     __shared__ double s_dl[SCANM_THREADS], s_dl2[SCANM_THREADS];
     __shared__ long long s_tp[SCANM_THREADS], s_A[SCANM_THREADS];
     __shared__ size_t s_base[SCANM_THREADS];
@@ -1173,7 +1174,9 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm_apply(DevPlan P, ScanM 
         }
     }
     __syncthreads();
+    SCANM_STAMP(7);
     stitch_publish(P, t, (int)(gridDim.x * gridDim.y), s_unver, s_rewalk, s_shifts, &s_last);
+    SCANM_STAMP(8);
 }
 
 // Page in force at the start of each epoch, src/galileo-sdr.cpp:497-506 + src/channel.cpp:88: the page
@@ -2376,39 +2379,50 @@ extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t s
     hipLaunchKernelGGL(k_walk_carr, dim3((n + 63) / 64), dim3(64), 0, st, *P, first);
 }
 
-extern "C" int galk_scanm_blocks(int legs)
+#ifdef GAL_TEST_HOOKS
+extern "C" int galk_scanm_stamps(unsigned long long *out, int reset)  // out: SCANM_STAMP_BLOCKS x SCANM_NSTAMP words
 {
-    return (legs + SCANM_THREADS * SCANM_K - 1) / (SCANM_THREADS * SCANM_K);
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scanm_stamp), sizeof(g_scanm_stamp)) != hipSuccess) return -1;
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_scanm_stamp)) != hipSuccess || hipMemset(d, 0, sizeof(g_scanm_stamp)) != hipSuccess) return -1;
+    }
+    return 0;
 }
+#endif
 
-// scratch: the multi-block stitch's per-thread and per-block records (bytes for S slots; see ScanM)
+extern "C" int galk_scanm_blocks(int legs) { return (legs + SCANM_THREADS - 1) / SCANM_THREADS; }
+
+// scratch: the multi-block stitch's look-back records (bytes for S slots; see ScanM).  The ticket counters and the two status arrays come
+// first: gal_synth_plan clears them once (galk_scanm_status_bytes), after that the launches' tags keep the passes apart.
+extern "C" size_t galk_scanm_status_bytes(int S, int legs) { return 256 + ((size_t)S * galk_scanm_blocks(legs) * 4 + 255) / 256 * 256 * 2; }
 extern "C" size_t galk_scanm_bytes(int S, int legs)
 {
-    const size_t B = (size_t)galk_scanm_blocks(legs), G = B * SCANM_THREADS;
-    return (size_t)S * (G * (4 + 8 + 8 + 4 + 4 + 4 + 8 + 32) + B * (4 + 8 + 8 + 4 + 4 + 4 + 8 + 32)) + 4096;
+    const size_t SB = (size_t)S * galk_scanm_blocks(legs);
+    return galk_scanm_status_bytes(S, legs) + ((SB * 4 + 255) / 256 * 256) * 2 + ((SB * 8 + 255) / 256 * 256) * 3 + ((SB * 32 + 255) / 256 * 256) + 4096;
 }
 
-extern "C" void galk_launch_carr_scan(const DevPlan *P, hipStream_t st)
+extern "C" void galk_launch_carr_scan(const DevPlan *P, uint32_t tag, hipStream_t st)
 {
     if (P->scanm == nullptr) {  // short batches: one 1024-thread block per slot
         hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P);
     } else {
         ScanM M;
         M.B = galk_scanm_blocks(P->LEGS);
-        M.G = M.B * SCANM_THREADS;
-        const size_t SG = (size_t)P->S * M.G, SB = (size_t)P->S * M.B;
+        M.tag = tag ? tag : 1u;
+        M.nap = 1;
+#ifdef GAL_TEST_HOOKS
+        if (const char *e = getenv("GAL_SCANM_NAP")) M.nap = atoi(e);
+#endif
+        const size_t SB = (size_t)P->S * M.B;
         char *p = (char *)P->scanm;
         auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return q; };
-        M.t1_w = (long long *)take(SG * 8); M.t1_r = (double *)take(SG * 8); M.t2_K = (double *)take(SG * 8);
-        M.t2_c = (double *)take(SG * 32);
-        M.b1_w = (long long *)take(SB * 8); M.b1_r = (double *)take(SB * 8); M.b2_K = (double *)take(SB * 8);
-        M.b2_c = (double *)take(SB * 32);
-        M.t1_kind = (int *)take(SG * 4); M.t2_fv = (int *)take(SG * 4); M.t2_v = (int *)take(SG * 4); M.t2_ic = (int *)take(SG * 4);
-        M.b1_kind = (int *)take(SB * 4); M.b2_fv = (int *)take(SB * 4); M.b2_v = (int *)take(SB * 4); M.b2_ic = (int *)take(SB * 4);
-        const dim3 grid(M.B, P->S), blk(SCANM_THREADS);
-        hipLaunchKernelGGL(k_scanm_claims, grid, blk, 0, st, *P, M);
-        hipLaunchKernelGGL(k_scanm_fold, grid, blk, 0, st, *P, M);
-        hipLaunchKernelGGL(k_scanm_apply, grid, blk, 0, st, *P, M);
+        M.cnt = (uint32_t *)take(256);  // (S <= 64)
+        M.st1 = (uint32_t *)take(SB * 4); M.st2 = (uint32_t *)take(SB * 4);
+        M.a1_kind = (int *)take(SB * 4); M.a2_f = (int *)take(SB * 4);
+        M.a1_w = (long long *)take(SB * 8); M.a1_r = (double *)take(SB * 8); M.a2_K = (double *)take(SB * 8);
+        M.a2_c = (double *)take(SB * 32);
+        hipLaunchKernelGGL(k_scanm, dim3(M.B, P->S), dim3(SCANM_THREADS), 0, st, *P, M);
     }
 }
 
