@@ -103,7 +103,7 @@ GAL_HD Batch nco_batch(double x, double d, int n_max, double cap, double inv_ad)
 // emitted from the closed form] [one genuine step unless the walk is over].
 // carr_walk with wrap tracking: additionally reports the LAST wrap inside the walk -- the local sample
 // index right after the wrapping step and the residual phase there -- which is what the speculative
-// stitcher (synth_kernels.hip: k_walk_carr / k_carr_scan) uses as a leg's hand-over state: right after a
+// stitcher (synth_kernels.hip: k_walk_carr / k_scanm) uses as a leg's hand-over state: right after a
 // wrap every phase is a multiple of 2^-52, so differences between neighbouring trajectories survive all
 // later roundings (binade crossings coarsen the grid only up to 2^-53).
 struct WalkOut {
@@ -379,7 +379,7 @@ GAL_HD CodeEnd code_walk(double x, int ibit, double cstep, double inv_c, int N, 
 // records the MARGIN, the smallest distance of a visited state to a binade boundary or to 4092 -- and (b) no rounding is a tie
 // whose resolution depends on the parity of x / ulp, which delta can flip only in [2048, 4096) and only if the step is a
 // multiple of 2^-42 (code_tie_prone: such epochs -- one in ~4000 -- are not translated, their legs are walked one after the other).
-// The stitch (code_leg_accept) is the carrier chain's (synth_kernels.hip: k_carr_scan) in small: the legs of an epoch sit in
+// The stitch (code_leg_accept) is the carrier chain's (synth_kernels.hip: k_scanm) in small: the legs of an epoch sit in
 // neighbouring lanes, leg k looks at the VERIFIED claim of leg k - 1.
 struct CodeTrack {
     double x;        // pre-check state after the last sample

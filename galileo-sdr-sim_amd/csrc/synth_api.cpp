@@ -129,7 +129,6 @@ void init_tables()
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
 constexpr size_t kRunHostStagedBytes = 32u << 20;  // gal_synth_run_host: batches up to here land in pinned memory of the handle
-constexpr int kScanSingleBlockLegs = 4096;  // up to here one 1024-thread block per slot stitches the carrier legs
 constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
 constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = chunk length of its batches (synth_group.hip: SG_CHUNK)
 constexpr int kGroupSyms = 64;      // ... symbol masks per channel and epoch (SG_SYMS)
@@ -254,7 +253,8 @@ struct gal_synth {
     int *h_ctr = nullptr;  // pinned: [CTR_COUNT] counters, [CTR_COUNT] spare, then the completion flag (k_publish)
     uint32_t *h_flag = nullptr;  // = (uint32_t *)(h_ctr + 2 * CTR_COUNT): sequence number of the last batch whose record is complete
     uint32_t seq = 0;            // sequence number of the batch in flight
-    uint32_t scan_tag = 0;       // tag of the last multi-block stitch launched (k_scanm's look-back records carry it)
+    uint32_t scan_tag = 0;       // tag of the last stitch launched (k_scanm's look-back records carry it)
+    size_t scanm_off = ~(size_t)0, scanm_clear = 0;  // where the stitch's records lie in the arena, as last cleared
     int64_t legs_walked = 0, legs_translated = 0, n_fallbacks = 0;  // last finish(): carrier legs walked / translated
     std::vector<int64_t> act_prefix;  // [E + 1] active records in the epochs before e (a first walker pass walks W legs of each)
     int64_t first_pass_legs = 0;      // legs walked by the first passes of the batch in flight (every active leg; not counted on the device)
@@ -808,14 +808,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t g_groups = (size_t)E * (size_t)((N + 15) / 16);
     const size_t g_cap = std::min<size_t>((size_t)kGroupListMin + g_groups / 200, (size_t)1 << 30);
     const size_t o_gflist = take(fam_g ? g_cap * 4 : 16);
-    // long batches stitch their carrier legs with the multi-block kernels (synth_kernels.hip: ScanM)
-    size_t single_legs = (size_t)kScanSingleBlockLegs;
-#ifdef GAL_TEST_HOOKS
-    // lets the randomised soak (small batches) run the long-batch stitcher: GAL_SCAN_SINGLE_LEGS=0
-    if (const char *env = getenv("GAL_SCAN_SINGLE_LEGS")) single_legs = (size_t)atol(env);
-#endif
-    const bool multi_scan = LEGS > single_legs;
-    const size_t o_scanm = multi_scan ? take(galk_scanm_bytes(S, (int)LEGS)) : 0;
+    const size_t o_scanm = take(galk_scanm_bytes(S, (int)LEGS));  // the stitch's look-back records (synth_kernels.hip: ScanM)
 
     const size_t total = off;
     if (total > h->arena_bytes) {
@@ -825,6 +818,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         if (hipMalloc(&h->arena, total) != hipSuccess)
             return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", total);
         h->arena_bytes = total;
+        h->scanm_off = ~(size_t)0;  // (new memory: the stitch's records have to be cleared)
     }
     if (up_bytes > h->h_up_bytes) {
         if (h->h_up) hipHostFree(h->h_up);
@@ -879,7 +873,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.ver_mod = 1; P.ver_rem = 0;
     P.marg = (double *)(base + o_marg); P.shift = (double *)(base + o_shift); P.tpos = (long long *)(base + o_tpos);
     P.tdir = (int8_t *)(base + o_tdir);
-    P.scanm = multi_scan ? (void *)(base + o_scanm) : nullptr;
+    P.scanm = (void *)(base + o_scanm);
     P.translate = 1;
     P.tr_e0 = 0;
     P.tr_e1 = E;
@@ -968,8 +962,14 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
         HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
         HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
-        // (the multi-block stitch's look-back records: none may carry a tag this handle is still going to hand out)
-        if (multi_scan) HIP_TRY(hipMemsetAsync(base + o_scanm, 0, galk_scanm_status_bytes(S, (int)LEGS), st_up));
+        // (the stitch's tickets and look-back records: no word there may look like a tag this handle is still going to hand out.
+        // Its own records never do -- tags only grow -- so this is for a region that held something else: a new layout)
+        const size_t scanm_clear = galk_scanm_status_bytes(S, (int)LEGS);
+        if (h->scanm_off != o_scanm || h->scanm_clear != scanm_clear) {
+            HIP_TRY(hipMemsetAsync(base + o_scanm, 0, scanm_clear, st_up));
+            h->scanm_off = o_scanm;
+            h->scanm_clear = scanm_clear;
+        }
         HIP_TRY(hipStreamSynchronize(st_up));
     }
     h->nact_max = nact_max;
@@ -1048,7 +1048,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->range_ne = n_epochs;
     // TRANSLATED carrier legs are covered by k_synth's replay check, which works by induction from the chain root
     // and therefore only vouches for epochs it actually replays.  Outside the executed range a leg is accepted
-    // through a genuine walk + bitwise stitch only (k_carr_scan: tr_e0 / tr_e1), so the carrier state a range
+    // through a genuine walk + bitwise stitch only (k_scanm: tr_e0 / tr_e1), so the carrier state a range
     // starts from never rests on an unchecked translation.
     // (the walker kernels take the plan by value; k_synth's device copy does not use these fields)
     // The walkers see the plan cut to [0, first_epoch + n_epochs): the carrier chain never restarts, so the epochs in

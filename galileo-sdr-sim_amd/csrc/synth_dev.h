@@ -67,7 +67,7 @@ struct DevPlan {
     uint8_t *risk;       // 1: the leg was accepted by a translation that used more than 1/256 of its binade margin: k_verify_carr
                          // re-walks such a leg in every batch, whatever the rotation says
     int ver_mod, ver_rem;  // k_verify_carr re-walks the legs i = ver_rem (mod ver_mod) of the executed epochs (1, 0: every leg)
-    void *scanm;         // scratch of the multi-block stitch (long batches), null: single-block k_carr_scan
+    void *scanm;         // scratch of the stitch: tickets and look-back records (synth_kernels.hip: ScanM)
     int translate;       // 1 normal; 0: always re-walk (the all-walked fallback); 2: GAL_TEST_HOOKS builds only
     int tr_e0, tr_e1;    // legs of epochs outside [tr_e0, tr_e1) are never translated (gal_synth_execute_range)
     int cp_e0;           // the walkers emit chunk checkpoints from this epoch on only (gal_synth_execute_range: epochs in

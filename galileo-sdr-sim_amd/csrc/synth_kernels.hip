@@ -10,7 +10,7 @@
 //                  checkpoint (phase, symbol index, page-flip flag) every R samples           [nco_walk.h]
 //   k_pages        which page is in force at each epoch start (pages change only when a symbol counter
 //                  wraps inside the sample loop, :497-506)                [both on the second walker stream]
-//   k_carr_guess / k_walk_carr / k_carr_scan (long batches: k_scanm_claims / _fold / _apply), normally ONE pass
+//   k_walk_carr / k_scanm, normally ONE pass
 //                  the carrier chain runs unbroken across epochs, so it is evaluated speculatively on LEGS
 //                  (8 per epoch): a leg is walked from its anchor = the last wrap event before it (first
 //                  guess: drift-compensated ideal arithmetic); the stitcher accepts a leg only when its
@@ -198,12 +198,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // gal_synth_plan on the host since round 5, synth_api.cpp: carrier_guesses; rounds 1-4: a kernel here, k_carr_guess.)
 __device__ __forceinline__ int d_residue_u52(double D) { return (int)((long long)(D * 4503599627370496.0) & 3LL); }
 
-// TRANSLATED acceptance of a leg (called by the stitchers, k_carr_scan / k_scanm_apply, for a leg whose anchor is the
+// TRANSLATED acceptance of a leg (called by the stitcher, k_scanm, for a leg whose anchor is the
 // same wrap event as before with a residual that moved by `dl`, a multiple of 2^-52 smaller than the leg's binade
 // margin): a walk from the new anchor would visit the same binades step by step, so every state it produces is the old
 // one plus the shift, bit for bit (nco_walk.h: binade_margin; ties: WalkOut::tdir) -- the leg's 32 checkpoints, end
 // phase and claim are shifted in place instead of walking it again.  k_synth's replay check covers it.
-struct TrRec {       // a translation whose checkpoint updates are left to the caller (k_scanm_apply: the block does them together)
+struct TrRec {       // a translation whose checkpoint updates are left to the caller (k_scanm: the block does them together)
     double dl, dl2;  // shift before / from the tie step on
     long long tp, A; // global sample index right after the tie step; of the leg's first sample
     size_t base;     // element offset of the leg's first checkpoint in cp_p
@@ -430,8 +430,8 @@ __global__ void k_verify_carr(DevPlan P)
     if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
 }
 
-// k_carr_scan: one 1024-thread block per slot stitches the legs.  Sequential statement (what the three
-// block-wide sweeps below compute; walk_host.cpp::galwalk_spec_wrap runs the same statement on the host):
+// k_scanm stitches the legs of a slot.  Sequential statement (what its three phases compute; walk_host.cpp::galwalk_spec_wrap
+// runs the same statement on the host):
 //     chain state: last claim (lc_w, lc_r), its pending correction D, allok
 //     for each leg i:   root      -> (lc_w, lc_r) = (first sample, given phase), D = 0, allok = true
 //                       link_ok   =  anchor_i bitwise == (lc_w, lc_r)  and the leg was walked from it
@@ -580,8 +580,7 @@ __device__ __forceinline__ double leg_d_out(const LegOp &o, double D)
     return tie_flip(o.G + D, o.tdir);
 }
 
-// What the stitch does to ONE leg once the true carries in front of it are known (sweep 3 of k_carr_scan, phase C of the
-// multi-block stitch): verified, or re-anchored at the predicted true value `nr` of the claim in front of it -- and then
+// What the stitch does to ONE leg once the true carries in front of it are known (phase 3 of k_scanm): verified, or re-anchored at the predicted true value `nr` of the claim in front of it -- and then
 // either TRANSLATED on the spot (same wrap event, only its residual moved, and the move is provably itinerary-preserving:
 // translate_leg) or marked for another walk.  (Round 2 left the translations to the next walker pass: one more kernel and
 // a skipped stitch behind it in the chain k_synth waits for.)
@@ -645,180 +644,14 @@ __device__ __forceinline__ void stitch_publish(const DevPlan &P, const int t, co
     }
 }
 
-#define SCAN_THREADS 1024
-__global__ __launch_bounds__(SCAN_THREADS) void k_carr_scan(DevPlan P)
-{
-    GAL_WALK_SETPRIO();  // latency-bound: win issue arbitration against a co-running k_synth
-    if (P.ctr[CTR_UNVERIFIED] == 0) return;
-    __shared__ int s_kind[SCAN_THREADS];
-    __shared__ long long s_w[SCAN_THREADS];
-    __shared__ double s_r[SCAN_THREADS];
-    __shared__ int s_fv[SCAN_THREADS], s_v[SCAN_THREADS], s_ic[SCAN_THREADS];
-    __shared__ double s_K[SCAN_THREADS], s_c[4][SCAN_THREADS];
-    __shared__ int s_unver, s_rewalk, s_shifts, s_last;
-    const int s = blockIdx.x;
-    const int t = threadIdx.x;
-    if (t == 0) {
-        s_unver = 0;
-        s_rewalk = 0;
-        s_shifts = 0;
-    }
-    const double start0 = P.state_in[s].carr_phase;
-    const int K = (P.LEGS + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int i0 = t * K;
-    const int i1 = i0 + K < P.LEGS ? i0 + K : P.LEGS;
-
-    // ---- sweep 1: where does the claim chain stand after my legs (if they say anything at all)?
-    ClaimState mine = {0, 0, 0.0};
-    for (int i = i0; i < i1; ++i) {
-        const LegRec L = leg_load(P, s, i, start0);
-        if (!L.act) {
-            mine.kind = 2;
-        } else {
-            if (L.root) {
-                mine.kind = 1;
-                mine.w = L.A;
-                mine.r = L.known;
-            }
-            if (L.hw) {
-                mine.kind = 1;
-                mine.w = L.cw;
-                mine.r = L.cr;
-            }
-        }
-    }
-    s_kind[t] = mine.kind;
-    s_w[t] = mine.w;
-    s_r[t] = mine.r;
-    __syncthreads();
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // inclusive "last one that speaks" scan
-        int k2 = 0;
-        long long w2 = 0;
-        double r2 = 0.0;
-        const bool take = t >= off && s_kind[t] == 0;
-        if (take) {
-            k2 = s_kind[t - off];
-            w2 = s_w[t - off];
-            r2 = s_r[t - off];
-        }
-        __syncthreads();
-        if (take) {
-            s_kind[t] = k2;
-            s_w[t] = w2;
-            s_r[t] = r2;
-        }
-        __syncthreads();
-    }
-    ClaimState lc0 = {0, 0, 0.0};
-    if (t > 0) {
-        lc0.kind = s_kind[t - 1];
-        lc0.w = s_w[t - 1];
-        lc0.r = s_r[t - 1];
-    }
-
-    // ---- sweep 2: fold my legs: allok (segmented AND) and the D map (evaluated on the four residues)
-    {
-        ClaimState lc = lc0;
-        int allok = 1, fv = 0, isconst = 0;
-        double D4[4] = {0.0, GAL_U52, 2.0 * GAL_U52, 3.0 * GAL_U52};
-        for (int i = i0; i < i1; ++i) {
-            const LegRec L = leg_load(P, s, i, start0);
-            const LegOp o = leg_op(P, s, L, lc);
-            if (!o.act) {
-                allok = 0;
-                fv = 1;
-            } else {
-                if (o.root) {
-                    allok = 1;
-                    fv = 1;
-                }
-                allok &= o.link_ok ? 1 : 0;
-            }
-            if (!o.act || o.root || (o.hw && !o.same)) isconst = 1;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) D4[m] = leg_d_out(o, D4[m]);
-        }
-        s_fv[t] = fv;
-        s_v[t] = allok;
-        s_ic[t] = isconst;
-        s_K[t] = D4[0];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) s_c[m][t] = D4[m] - (double)m * GAL_U52;
-    }
-    __syncthreads();
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {  // inclusive scan: segmented AND + D-map composition
-        const bool has = t >= off;
-        int afv = 0, av = 1;
-        DMap a, b;
-        a.isconst = 0; a.K = 0.0; a.c[0] = a.c[1] = a.c[2] = a.c[3] = 0.0;
-        if (has) {
-            afv = s_fv[t - off];
-            av = s_v[t - off];
-            a.isconst = s_ic[t - off];
-            a.K = s_K[t - off];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) a.c[m] = s_c[m][t - off];
-        }
-        const int bfv = s_fv[t], bv = s_v[t];
-        b.isconst = s_ic[t];
-        b.K = s_K[t];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) b.c[m] = s_c[m][t];
-        __syncthreads();
-        if (has) {
-            const DMap r = dmap_combine(a, b);
-            s_fv[t] = afv | bfv;
-            s_v[t] = bfv ? bv : (av & bv);
-            s_ic[t] = r.isconst;
-            s_K[t] = r.K;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) s_c[m][t] = r.c[m];
-        }
-        __syncthreads();
-    }
-
-    // ---- sweep 3: replay my legs with the true carries and apply
-    {
-        ClaimState lc = lc0;
-        int allok = 0;  // nothing is verified before the first root
-        double D = 0.0;
-        if (t > 0) {
-            allok = s_fv[t - 1] ? s_v[t - 1] : 0;
-            D = s_ic[t - 1] ? s_K[t - 1] : s_c[0][t - 1];  // the prefix map applied to D = 0
-        }
-        int unver = 0, rewalk = 0, shifts = 0;
-        for (int i = i0; i < i1; ++i) {
-            const LegRec L = leg_load(P, s, i, start0);
-            const LegOp o = leg_op(P, s, L, lc);
-            if (!o.act) {
-                allok = 0;
-                D = 0.0;
-                continue;
-            }
-            if (o.root) {
-                allok = 1;
-                D = 0.0;
-            }
-            allok &= o.link_ok ? 1 : 0;
-            const double nr = o.base + D;
-            D = leg_d_out(o, D);
-            stitch_apply_leg(P, s, i, L, o, allok, nr, unver, rewalk, shifts);
-        }
-        if (unver) atomicAdd(&s_unver, unver);
-        if (rewalk) atomicAdd(&s_rewalk, rewalk);
-        if (shifts) atomicAdd(&s_shifts, shifts);
-    }
-    __syncthreads();
-    stitch_publish(P, t, (int)gridDim.x, s_unver, s_rewalk, s_shifts, &s_last);
-}
-
-// ---- The same stitch as k_carr_scan for LONG batches, in 256-thread blocks.  k_carr_scan needs 16 waves and 72 KB of
-// LDS on ONE CU; beside a running synthesis kernel (every SIMD's register file full, most of the LDS) that means waiting for a CU
-// to drain completely, and with 2999 epochs the walker chain of the next step then takes longer than the synthesis it is supposed
-// to hide behind.  Here the legs of a slot are spread over B blocks of 256 threads (one wave per SIMD: such a block starts as soon
-// as ONE synthesis block retires), one leg per thread, and what the single block does with two block-wide scans is done with
-// block-local scans plus a LOOK-BACK over the blocks in front, inside ONE launch (round 5; rounds 2-4: three launches -- claims,
-// fold, apply -- with the block totals handed over through kernel boundaries).  A block publishes the aggregate of its legs as
+// ---- The stitch, in 256-thread blocks, one leg per thread.  (Rounds 2-4 had a 1024-thread block per slot for batches up to 512
+// epochs, k_carr_scan: 16 waves and 72 KB of LDS on ONE CU -- beside a running synthesis kernel that means waiting for a CU to
+// drain completely -- with 10-step scans through LDS; tools/stitch_ab.sh, one handle: 0.189 -> 0.179 ms per step at 1 epoch,
+// 0.451 -> 0.419 at 128, 0.880 -> 0.731 at 512 with this kernel in its place.)  The legs of a slot are spread over B blocks (one
+// wave per SIMD: such a block starts as soon as ONE synthesis block retires); a batch of up to 32 epochs has B = 1 and none of what
+// follows.  What a single block would do with two block-wide scans is done with block-local scans plus a LOOK-BACK over the blocks
+// in front, inside ONE launch (rounds 2-4, long batches: three launches -- claims, fold, apply -- with the block totals handed
+// over through kernel boundaries).  A block publishes the aggregate of its legs as
 // soon as its local scan is done; then its threads fetch the aggregates of ALL blocks in front of it, one record per thread (each
 // waits until that record carries this launch's tag), and the waves fold them in order -- both the claim chain ("the last one
 // that speaks") and the fold (segmented AND + D map) are associative, so this is the sequential statement.  No block waits for
@@ -836,6 +669,7 @@ struct ScanM {  // look-back records of the multi-block stitch: [S][B] each
     int B;
     uint32_t tag;                                     // of this launch (non-zero)
     int nap;                                          // 64-cycle naps between two looks at a record that is not there yet
+    int lpb;                                          // legs per block: SCANM_THREADS (GAL_TEST_HOOKS: fewer, so that small batches have many blocks)
     uint32_t *cnt;                                    // [S] tickets drawn so far (B per launch and slot)
     uint32_t *st1, *st2;                              // tag of the launch whose claim / fold aggregate the record holds
     int *a1_kind; long long *a1_w; double *a1_r;      // claims: the block's last speaker
@@ -958,11 +792,13 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
     __shared__ FoldRec s_carry2;
     __shared__ int s_unver, s_rewalk, s_shifts, s_last, s_ticket;
     const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) s_ticket = (int)(atomicAdd(&M.cnt[s], 1u) % (uint32_t)M.B);  // (every launch draws exactly B per slot, or none)
-    __syncthreads();
-    const int b = s_ticket;
-    const int i = b * SCANM_THREADS + t;  // my leg
-    const bool in = i < P.LEGS;
+    if (M.B > 1) {
+        if (t == 0) s_ticket = (int)atomicAdd(&M.cnt[s], 1u);  // (back to 0 at the end of the launch: below)
+        __syncthreads();
+    }
+    const int b = M.B > 1 ? s_ticket : 0;
+    const int i = b * M.lpb + t;  // my leg
+    const bool in = t < M.lpb && i < P.LEGS;
     const size_t ob = (size_t)s * M.B + b;
     if (t == 0) {
         s_unver = 0;
@@ -1123,7 +959,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
     __syncthreads();
 
     SCANM_STAMP(5);
-    // ---- phase 3: my leg with the true carries (sweep 3 of k_carr_scan), translations on the spot
+    // ---- phase 3: my leg with the true carries, translations on the spot
     pre = fold_combine(s_carry2, pre);
     int allok = pre.fv ? pre.v : 0;                          // nothing is verified before the first root
     double D = pre.m.isconst ? pre.m.K : pre.m.c[0];         // the prefix map applied to D = 0
@@ -1176,6 +1012,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
     __syncthreads();
     SCANM_STAMP(7);
     stitch_publish(P, t, (int)(gridDim.x * gridDim.y), s_unver, s_rewalk, s_shifts, &s_last);
+    if (s_last && t < P.S) M.cnt[t] = 0;  // (the last block through: every block has drawn its ticket)
     SCANM_STAMP(8);
 }
 
@@ -2391,9 +2228,22 @@ extern "C" int galk_scanm_stamps(unsigned long long *out, int reset)  // out: SC
 }
 #endif
 
-extern "C" int galk_scanm_blocks(int legs) { return (legs + SCANM_THREADS - 1) / SCANM_THREADS; }
+// legs per block of the stitch (GAL_TEST_HOOKS: GAL_SCAN_BLOCK_LEGS = 1 ... 256 gives the small batches of the randomised soaks
+// many blocks per slot, i.e. the look-back)
+static int scanm_lpb()
+{
+#ifdef GAL_TEST_HOOKS
+    if (const char *e = getenv("GAL_SCAN_BLOCK_LEGS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= SCANM_THREADS) return v;
+    }
+#endif
+    return SCANM_THREADS;
+}
 
-// scratch: the multi-block stitch's look-back records (bytes for S slots; see ScanM).  The ticket counters and the two status arrays come
+extern "C" int galk_scanm_blocks(int legs) { return (legs + scanm_lpb() - 1) / scanm_lpb(); }
+
+// scratch: the stitch's look-back records (bytes for S slots; see ScanM).  The ticket counters and the two status arrays come
 // first: gal_synth_plan clears them once (galk_scanm_status_bytes), after that the launches' tags keep the passes apart.
 extern "C" size_t galk_scanm_status_bytes(int S, int legs) { return 256 + ((size_t)S * galk_scanm_blocks(legs) * 4 + 255) / 256 * 256 * 2; }
 extern "C" size_t galk_scanm_bytes(int S, int legs)
@@ -2404,26 +2254,23 @@ extern "C" size_t galk_scanm_bytes(int S, int legs)
 
 extern "C" void galk_launch_carr_scan(const DevPlan *P, uint32_t tag, hipStream_t st)
 {
-    if (P->scanm == nullptr) {  // short batches: one 1024-thread block per slot
-        hipLaunchKernelGGL(k_carr_scan, dim3(P->S), dim3(SCAN_THREADS), 0, st, *P);
-    } else {
-        ScanM M;
-        M.B = galk_scanm_blocks(P->LEGS);
-        M.tag = tag ? tag : 1u;
-        M.nap = 1;
+    ScanM M;
+    M.lpb = scanm_lpb();
+    M.B = galk_scanm_blocks(P->LEGS);
+    M.tag = tag ? tag : 1u;
+    M.nap = 1;
 #ifdef GAL_TEST_HOOKS
-        if (const char *e = getenv("GAL_SCANM_NAP")) M.nap = atoi(e);
+    if (const char *e = getenv("GAL_SCANM_NAP")) M.nap = atoi(e);
 #endif
-        const size_t SB = (size_t)P->S * M.B;
-        char *p = (char *)P->scanm;
-        auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return q; };
-        M.cnt = (uint32_t *)take(256);  // (S <= 64)
-        M.st1 = (uint32_t *)take(SB * 4); M.st2 = (uint32_t *)take(SB * 4);
-        M.a1_kind = (int *)take(SB * 4); M.a2_f = (int *)take(SB * 4);
-        M.a1_w = (long long *)take(SB * 8); M.a1_r = (double *)take(SB * 8); M.a2_K = (double *)take(SB * 8);
-        M.a2_c = (double *)take(SB * 32);
-        hipLaunchKernelGGL(k_scanm, dim3(M.B, P->S), dim3(SCANM_THREADS), 0, st, *P, M);
-    }
+    const size_t SB = (size_t)P->S * M.B;
+    char *p = (char *)P->scanm;
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return q; };
+    M.cnt = (uint32_t *)take(256);  // (S <= 64)
+    M.st1 = (uint32_t *)take(SB * 4); M.st2 = (uint32_t *)take(SB * 4);
+    M.a1_kind = (int *)take(SB * 4); M.a2_f = (int *)take(SB * 4);
+    M.a1_w = (long long *)take(SB * 8); M.a1_r = (double *)take(SB * 8); M.a2_K = (double *)take(SB * 8);
+    M.a2_c = (double *)take(SB * 32);
+    hipLaunchKernelGGL(k_scanm, dim3(M.B, P->S), dim3(SCANM_THREADS), 0, st, *P, M);
 }
 
 extern "C" void galk_launch_pages(const DevPlan *P, hipStream_t st)

@@ -160,7 +160,7 @@ void galwalk_code_brute(double x, int ibit, double c, int N, int R, double *cpx,
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------
-// Host emulation of the WRAP-ANCHORED leg pipeline (what the GPU runs: k_walk_carr / k_carr_scan).
+// Host emulation of the WRAP-ANCHORED leg pipeline (what the GPU runs: k_walk_carr / k_scanm).
 // A leg is walked from its ANCHOR = the last wrap event at or before its first sample, (omega, r) with
 // "phase before global sample omega is r" (or the chain root), through to its own end; it reports the
 // last wrap it saw (its CLAIM) or "none".  The stitcher accepts a leg only if its anchor is bitwise the
@@ -174,7 +174,7 @@ int galwalk_spec_wrap(int E, int W, int L, int N, const int *prn, const uint32_t
 {
     // R > 0: checkpoints every R samples inside each leg go to cp_out[leg * (L / R) + c] (L % R == 0);
     // translate != 0: legs whose anchor residual merely moved are shifted instead of walked again
-    // (synth_kernels.hip: k_walk_carr dirty == 2 / k_carr_scan sweep 3)
+    // (synth_kernels.hip: k_walk_carr dirty == 2 / k_scanm phase 3)
     const int LEGS = E * W;
     const int Lc = R > 0 ? L / R : 0;
     const bool use_eff = getenv("GALWALK_NO_EFF") == nullptr;

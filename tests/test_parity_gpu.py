@@ -794,16 +794,18 @@ def test_m_dyn_full_size_properties(pkg):
     assert np.array_equal(ref_st["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
 
 
-def test_long_batch_stitcher_on_small_batches(pkg, monkeypatch):
-    """Batches with more than 4096 carrier legs per slot are stitched by the multi-block kernels (k_scanm_*) instead of
-    the single-block k_carr_scan -- the same sequential statement.  The full-size tests cover it at 1199 / 2999 epochs;
-    here the fault-injection build forces it onto small random batches (channels coming and going, idle epochs, sign
-    changes, tie-prone steps), where every corner of the stitch is hit quickly."""
-    monkeypatch.setenv("GAL_SCAN_SINGLE_LEGS", "0")  # honoured by the GAL_TEST_HOOKS build only
+@pytest.mark.parametrize("block_legs", [8, 3])
+def test_long_batch_stitcher_on_small_batches(pkg, monkeypatch, block_legs):
+    """A batch with more than 256 carrier legs per slot (32 epochs) is stitched by several blocks per slot that exchange
+    their aggregates inside the launch (k_scanm: tickets, look-back).  The full-size tests cover it at 1199 / 2999 epochs;
+    here the fault-injection build gives a block 8 (3) legs instead of 256, so that small random batches (channels coming
+    and going, idle epochs, sign changes, tie-prone steps) hit every corner of the exchange quickly -- with 3 legs a block
+    ends inside an epoch and the "big" cases need more than one round of 256 records in the look-back."""
+    monkeypatch.setenv("GAL_SCAN_BLOCK_LEGS", str(block_legs))  # honoured by the GAL_TEST_HOOKS build only
     from fuzz_cases import random_case
 
     rng = np.random.default_rng(77)
-    for c in range(60):
+    for c in range(60 if block_legs == 8 else 30):
         p, n_samp, rate, chunk = random_case(pkg, rng, big=(c % 15 == 14))
         with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=p.shape[1], device=0, chunk_samples=chunk,
                              test_hooks=True) as eng:

@@ -218,7 +218,7 @@ def _chain_truth(W, p, d, N):
 
 
 def test_wrap_anchored_stitching_as_on_gpu(W):
-    """The scheme the GPU runs (k_walk_carr / k_carr_scan): legs anchored at the last wrap, claims stitched by
+    """The scheme the GPU runs (k_walk_carr / k_scanm): legs anchored at the last wrap, claims stitched by
     the sequential statement (nthreads=0) and by the block-parallel three-sweep form (nthreads=256).  Both must
     reproduce the sequential chain exactly and converge in a handful of passes -- also for channels sweeping
     through zero Doppler, where leg-boundary speculation needed hundreds of passes."""

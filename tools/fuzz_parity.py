@@ -3,7 +3,7 @@
 (slots, channels, epoch length, sample rate, chunking, Doppler incl. tiny / zero / sign flips / few-bit steps,
 channels appearing, vanishing and being re-allocated, symbol counters near the page flip, code phases near the
 wrap).  Test infrastructure: uses the oracle as the checker.   python tools/fuzz_parity.py [n_cases] [seed] [big]
-GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_SINGLE_LEGS=0: the long-batch stitcher on every batch).
+GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_BLOCK_LEGS=8: many blocks per slot in the carrier stitch of every batch, i.e. its look-back).
 GAL_FUZZ_CBOC=1 runs the opt-in CBOC(6,1,1/11) mode against the checker's CBOC loop.
 GAL_FUZZ_GROUP=1 draws batches the default kernel of the reference geometry (k_synth_g + k_repair_g) can take, and reports how
 many it took and how many 16-sample groups were replayed exactly."""

@@ -11,8 +11,8 @@ echo "### product build: fuzz_parity.py $((20000*k)) 301 / $((600*k)) 302 big"
 timeout 1500 python tools/fuzz_parity.py $((20000*k)) 301 2>&1 | tail -1
 timeout 1500 python tools/fuzz_parity.py $((600*k)) 302 big 2>&1 | tail -1
 echo "### hooks build, long-batch stitcher forced: fuzz_parity.py $((3000*k)) 303 / $((150*k)) 304 big"
-GAL_FUZZ_HOOKS=1 GAL_SCAN_SINGLE_LEGS=0 timeout 900 python tools/fuzz_parity.py $((3000*k)) 303 2>&1 | tail -1
-GAL_FUZZ_HOOKS=1 GAL_SCAN_SINGLE_LEGS=0 timeout 900 python tools/fuzz_parity.py $((150*k)) 304 big 2>&1 | tail -1
+GAL_FUZZ_HOOKS=1 GAL_SCAN_BLOCK_LEGS=8 timeout 900 python tools/fuzz_parity.py $((3000*k)) 303 2>&1 | tail -1
+GAL_FUZZ_HOOKS=1 GAL_SCAN_BLOCK_LEGS=8 timeout 900 python tools/fuzz_parity.py $((150*k)) 304 big 2>&1 | tail -1
 echo "### CBOC: fuzz_parity.py $((4000*k)) 305 / $((150*k)) 306 big"
 GAL_FUZZ_CBOC=1 timeout 900 python tools/fuzz_parity.py $((4000*k)) 305 2>&1 | tail -1
 GAL_FUZZ_CBOC=1 timeout 900 python tools/fuzz_parity.py $((150*k)) 306 big 2>&1 | tail -1

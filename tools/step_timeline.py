@@ -18,7 +18,7 @@ def main():
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qcol], n.split("(")[0].replace("void ", "")))
     ev.sort()
     synth = [e for e in ev if e[3].startswith("k_synth")]
-    walkers = [e for e in ev if e[3].startswith(("k_walk", "k_scanm", "k_carr_scan", "k_pages"))]
+    walkers = [e for e in ev if e[3].startswith(("k_walk", "k_scanm", "k_pages"))]
     qs = sorted(set(e[2] for e in synth))
     out = {"gap": [], "walk": [], "wait": [], "synth": [], "cycle": []}
     for q in qs:
