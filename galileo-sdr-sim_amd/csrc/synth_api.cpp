@@ -701,11 +701,14 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     if (R < 4) R = 4;
     const int nchunks = (N + R - 1) / R;
     const int tiles = (nchunks + 63) / 64;
-    // carrier-walk legs: ~8 per epoch so that (legs x channels) fills the chip.  A batch of a few epochs (one-epoch calls:
-    // INTEGRATION.md option B) is latency, not throughput: its walk and its verification are as long as ONE leg, so it gets
-    // up to 32 shorter ones (one-epoch call: k_walk_carr / k_verify_carr 124 / 121 -> 38 / 36 us, tools/trace_epoch.sh)
-    int legs = 8;
-    if (E * 8 < 256) legs = std::min(32, 256 / E);
+    // carrier-walk legs per epoch.  The walk and the verification of a batch take as long as ONE leg (a lane's dependent chain of
+    // closed-form steps), whatever the batch's length, so a batch that does not fill the chip with 8 legs per epoch gets shorter
+    // ones: 32 up to 256 epochs, 16 up to 512 (same box, bench.py --epochs E, one handle / two: 32 epochs 0.357 / 0.219 ms per step
+    // with 8 legs, 0.215 / 0.129 with 32; 128 epochs 0.442 / 0.254 -> 0.295 / 0.182; 256 epochs 0.542 / 0.329 -> 0.400 / 0.300;
+    // 512 epochs 0.714 / 0.493 -> 0.622 / 0.477 with 16, 0.626 / 0.512 with 32; 1199 epochs: 16 legs cost the pipelined step
+    // 15 % -- profiles/r05s_walk_legs_ab.log, r05c_walk_ab.log).  One-epoch calls (INTEGRATION.md option B): k_walk_carr /
+    // k_verify_carr 124 / 121 -> 38 / 36 us with 32 legs (round 4).
+    int legs = E <= 256 ? 32 : E <= 512 ? 16 : 8;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_WALK_LEGS")) legs = atoi(env) > 0 ? atoi(env) : legs;
 #endif
