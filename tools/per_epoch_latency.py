@@ -8,7 +8,8 @@ from __graft_entry__ import load_pkg
 pkg = load_pkg()
 p = pkg.workloads.make_synthetic(n_epochs=300, n_chan=9, n_slots=16, samples_per_epoch=260000, seed=3)
 chunk = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-with pkg.SynthEngine(samples_per_epoch=260000, n_slots=16, device=0, chunk_samples=chunk) as eng:
+with pkg.SynthEngine(samples_per_epoch=260000, n_slots=16, device=0, chunk_samples=chunk,
+                     test_hooks=bool(os.environ.get("GAL_LAT_HOOKS"))) as eng:  # (GAL_LAT_HOOKS=1: the GAL_TEST_HOOKS build, for A/B of its knobs)
     st = None
     eng.run_host(p[:1])
     t = time.perf_counter()
