@@ -52,11 +52,13 @@ static double rw_threshold_gap(double s)
     return g;
 }
 // Form of the resampled windows a code step of cs2 half chips per sample takes (k_synth<.., RW>, k_synth_g<.., MODE>): 1 = holds
-// (the reference's 2.6 MS/s), 2 = at most two advances per 16 samples (from 15.4 MS/s), 3 = at most four (from 7.7 MS/s), 0 = none.
+// (the reference's 2.6 MS/s), 2 = at most two advances per 16 samples (from 15.4 MS/s), 3 = at most four (from 7.7 MS/s), 4 = any
+// pattern of holds (2.77 .. 7.7 MS/s; k_synth_g only: k_synth runs its classic windows there), 0 = none.
 // ONE definition for gal_synth_plan's gate and for gal_synth_create's choice of the code objects to load up front.
 static int rw_mode_of(double cs2)
 {
-    return (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3 : 0;
+    return (cs2 >= 0.74 && cs2 < 0.9999) ? 1 : (cs2 >= 0.0083 && cs2 <= 0.133) ? 2 : (cs2 > 0.133 && cs2 <= 0.266) ? 3
+           : (cs2 > 0.266 && cs2 < 0.74) ? 4 : 0;
 }
 static constexpr double kRwMinGap = 1.0 / 128.0 + 4e-6;
 // the CBOC mode keeps two bin tables per channel (chip holds, BOC(6,1) half-period parity) of 64 bins each
@@ -605,7 +607,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     // in the form most of them have, the others go to an accumulating exact-replay launch behind it (classic windows)
     int rw_mode = 0;
     bool rw_ok = nact_max > 0;
-    long long g_count[4] = {0, 0, 0, 0}, n_records = 0;
+    long long g_count[5] = {0, 0, 0, 0, 0}, n_records = 0;
     for (int e = 0; e < E; ++e)
         for (int k = 0; k < nact_all[e]; ++k) {
             const size_t i = (size_t)e * S + act_all[(size_t)e * S + k];
@@ -615,7 +617,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             if (rec_g[i]) g_count[rec_mode[i]] += 1;
         }
     int g_mode = 1;
-    for (int m = 2; m <= 3; ++m)
+    for (int m = 2; m <= 4; ++m)
         if (g_count[m] > g_count[g_mode]) g_mode = m;
     const long long n_grec = g_count[g_mode];
     // epochs in which some record is not fit for k_synth_g in that form: the accumulating exact-replay launch behind it costs about
@@ -911,7 +913,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
     // k_synth_g: the form its records have; k_synth alone: its fast body if EVERY record has the same form (CBOC: form 1 only --
     // rec_mode is 0 for the others), else classic windows
-    P.rw = fam_g ? g_mode : (rw_ok ? rw_mode : 0);
+    P.rw = fam_g ? g_mode : (rw_ok && rw_mode <= 3 ? rw_mode : 0);
 #ifdef GAL_TEST_HOOKS
     // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)

@@ -86,7 +86,9 @@ __device__ __forceinline__ double sg_f64(const uint32_t lo, const uint32_t hi) {
 // they go to memory; amb: the smallest fraction word the lane has seen; undec: lanes with an undecided chip pattern.
 // MODE: the form of the resampled window (k_synth's RW): 1 = the window advances every sample except at <= 4 HOLDS (code step 0.74 ..
 // 1 half chips per sample: the reference's 2.6 MS/s), 2 = it advances at <= 2 samples of the group (code step <= 0.133: 15.4 MS/s and
-// above), 3 = at <= 4 samples (<= 0.266: 7.7 .. 15.4 MS/s)
+// above), 3 = at <= 4 samples (<= 0.266: 7.7 .. 15.4 MS/s), 4 = ANY pattern of holds (round 5: what lies between, 2.77 .. 7.7 MS/s) --
+// sample u reads field u - h(u) of the window, h(u) = the holds up to u, through a four-stage shift network (shifts of 8, 4, 2, 1
+// fields where the bits of h say so); the masks of the stages are made with the patterns (build below)
 // SIG: 0 = BOC(1,1) as the reference generates it; 1 = the opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC; hold form only): a second
 // pattern look-up per group -- the PARITY of the BOC(6,1) half period of every sample, k_synth's rw_phase_a6 / b6 -- two chip words
 // (the (B - C) and the (B + C) factor of every sample), 8-byte table entries (TA[k], TB[k]) and two multiply-adds per sample
@@ -186,6 +188,12 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
                 XB[q] = (J0 + q) < nact ? (lo1 | (sb & (lo1 << 1))) : 0u;  // (an idle position's all-zero row has B == C everywhere)
             } else if constexpr (MODE == 1) {
                 X[q] = rw_spread(window_signed(W), M[q]);
+            } else if constexpr (MODE == 4) {
+                uint32_t x = window_signed(W);
+                x = gal_bfi(M[q].w, x << 16, x);
+                x = gal_bfi(M[q].z, x << 8, x);
+                x = gal_bfi(M[q].y, x << 4, x);
+                X[q] = gal_bfi(M[q].x, x << 2, x);
             } else {  // field 0 everywhere, field 1 from the first advance on, field 2 from the second, ...
                 const uint32_t w = window_signed(W);
                 uint32_t x = gal_bfi(M[q].x, sg_rep(w, 1), sg_rep(w, 0));
@@ -519,6 +527,26 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         Thi = Thi > 1.0 ? 1.0 : Thi;
         const double f = 0.5 * (Tlo + Thi);
         uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+        if constexpr (MODE == 4) {
+            // The shift network of a pattern: sample u reads field u - h(u) of the window, h(u) = u - floor(f + u s) (f < 1) the holds
+            // up to u.  Read from the output back to the window, sample u's value comes from position p0 = u, p1 = p0 - (h & 1),
+            // p2 = p1 - (h & 2), p3 = p2 - (h & 4), p3 - (h & 8) = u - h(u): stage k (applied to the window in the order 3, 2, 1, 0)
+            // shifts the field AT p_k by 2^k fields iff bit k of h is set.  Two samples whose paths meet read the same field of
+            // the window (if p_k(u) = p_k(u'), u < u', but the fields differ by d > 0, then floor(h(u') / 2^k) - floor(h(u) / 2^k)
+            // = -d although h(u') >= h(u)), so the masks never ask two things of one position.
+            for (int u = 0; u <= 15; ++u) {
+                const int hld = u - (int)__builtin_floor(f + (double)u * s);
+                int pp = u;
+                m0 |= (hld & 1) ? 3u << (2 * pp) : 0u;
+                pp -= hld & 1;
+                m1 |= (hld & 2) ? 3u << (2 * pp) : 0u;
+                pp -= hld & 2;
+                m2 |= (hld & 4) ? 3u << (2 * pp) : 0u;
+                pp -= hld & 4;
+                m3 |= (hld & 8) ? 3u << (2 * pp) : 0u;
+            }
+            if (j >= nact) m0 = m1 = m2 = m3 = 0u;
+        } else {
         int d = 0;
         double gp = 0.0;  // floor(f), f < 1
         for (int u = 1; u <= 15; ++u) {
@@ -533,6 +561,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         if (j >= nact) m0 = m1 = m2 = m3 = 0u;
         else if (d > (MODE == 2 ? 2 : 4)) s_rwbad = 1;  // more holds / advances than the masks carry (the host's gate excludes it):
                                                         // every group is listed
+        }
         s_pat[t] = make_uint4(m0, m1, m2, m3);
     }
     __syncthreads();
@@ -897,7 +926,7 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
 #define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m, 0>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
                                                   : launch_synth_g_t<false, m, 0>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
     switch (P->rw) {
-        SG_MODE_CASE(1) SG_MODE_CASE(2) SG_MODE_CASE(3)
+        SG_MODE_CASE(1) SG_MODE_CASE(2) SG_MODE_CASE(3) SG_MODE_CASE(4)
     default: return -3;
     }
 #undef SG_MODE_CASE

@@ -118,10 +118,12 @@ typedef struct gal_synth_stats {
     int32_t chunks_per_epoch;
     float   ms_walk;            /* device time of the walker kernels, last execute (0 if timing disabled)      */
     float   ms_synth;           /* device time of the synthesis kernel, last execute                           */
-    int32_t window_mode;        /* fast body of the synthesis kernel: 1 / 2 / 3 resampled windows (one chip-pattern look-up per
-                                   16 samples; 1: 0.74 <= 2 f_code / fs < 1, as at the reference's 2.6 MS/s; 2: 2 f_code / fs
-                                   <= 0.133, sample rates from 15.4 MS/s; 3: <= 0.266, from 7.7 MS/s; all need well
-                                   separated pattern thresholds), 0 per-sample window index (any rate).  Same bits either way.
+    int32_t window_mode;        /* fast body of the synthesis kernel: 1 / 2 / 3 / 4 resampled windows (one chip-pattern look-up
+                                   per 16 samples; 1: 0.74 <= 2 f_code / fs < 1, as at the reference's 2.6 MS/s; 2: 2 f_code / fs
+                                   <= 0.133, sample rates from 15.4 MS/s; 3: <= 0.266, from 7.7 MS/s; 4: what lies between,
+                                   2.77 .. 7.7 MS/s (kernel_family 1 only); all need well separated pattern thresholds --
+                                   a rate at which 2 f_code / fs is within 1e-3 of a fraction with a denominator up to 15,
+                                   e.g. 4.092 MS/s, has none), 0 per-sample window index (any rate).  Same bits either way.
                                                                                                                             */
     int32_t synth_runs;         /* synthesis launches the last batch took: 1, or 2 when gal_synth_finish() had to repeat
                                    it (carrier chain not complete when the kernel was started, or the replay check failed) */
@@ -129,9 +131,9 @@ typedef struct gal_synth_stats {
                                    group per lane, start states in closed form from the chunk's exact checkpoint, groups whose
                                    chip pattern or table index hangs on the rounding history replayed exactly afterwards -- the
                                    default wherever gal_synth_plan's gate admits the batch: automatic chunking, every code step
-                                   in one form of the resampled windows (window_mode 1, 2 or 3: the reference's 2.6 MS/s, and
-                                   from 7.7 MS/s up) with well separated thresholds, every carrier step in [2^-40, 0.0147]
-                                   cycles per sample; BOC(1,1) in all three forms, the CBOC mode in form 1                  */
+                                   in one form of the resampled windows (window_mode 1 ... 4: any rate from 2.05 MS/s up) with
+                                   well separated thresholds, every carrier step 0 or in [2^-40, 0.0147] cycles per sample;
+                                   BOC(1,1) in all four forms, the CBOC mode in form 1                                      */
     int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
     float   ms_repair;          /* family 1: device time of that replay (k_repair_g, behind the synthesis kernel; not in ms_synth) */
     int32_t exact_records;      /* family 1: records (channel-epochs) of the batch that are not fit for the group kernel -- a carrier

@@ -10,7 +10,7 @@ RESTART = 1
 def random_case(pkg, rng, big=False, group=False):
     """group=True: batches the default kernel of the reference geometry can take (k_synth_g: rates in the hold form of the resampled
     windows, automatic chunking; zero / sub-2^-40 Doppler steps still send a batch to the exact-replay kernel)."""
-    rate = float(rng.choice([2.2e6, 2.4e6, 2.6e6, 2.6e6, 2.6e6, 2.76e6, 8e6, 16e6, 25e6, 25e6])) if group else float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 4.0e6, 4.092e6, 7.7e6, 8e6, 10e6, 12.5e6, 15.4e6, 16e6, 25e6, 25e6, 40e6]))
+    rate = float(rng.choice([2.2e6, 2.4e6, 2.6e6, 2.6e6, 2.6e6, 2.76e6, 3.0e6, 4.0e6, 5.0e6, 6.5e6, 8e6, 16e6, 25e6, 25e6])) if group else float(rng.choice([2.047e6, 2.0465e6, 2.3e6, 2.6e6, 2.6e6, 2.6e6, 2.75e6, 2.78e6, 3.3e6, 4.0e6, 4.092e6, 5.5e6, 7.0e6, 7.7e6, 8e6, 10e6, 12.5e6, 15.4e6, 16e6, 25e6, 25e6, 40e6]))
     n_slots = int(rng.choice([4, 8, 16, 16, 24, 40, 64]))
     if group and rng.random() < 0.7:
         n_slots = int(rng.choice([8, 16, 16, 16]))

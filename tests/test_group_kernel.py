@@ -71,8 +71,9 @@ def test_group_kernel_gates(pkg):
     q["f_carr"][:, 1] = 30000.0  # 16 x 511 x 30e3 / 2.6e6 = 94 entries per group: inside
     _, _, stats = _compare(pkg, q, 52000)
     assert stats["kernel_family"] == 1 and stats["exact_records"] == 0
-    r = pkg.workloads.make_synthetic(n_epochs=2, n_chan=4, n_slots=8, samples_per_epoch=50000, sample_rate=4.0e6, seed=3)
-    _, _, stats = _compare(pkg, r, 50000, rate=4.0e6)
+    # 4.092 MS/s: 2 samples per half chip exactly -- all 15 pattern thresholds on top of each other: no bin table can hold them
+    r = pkg.workloads.make_synthetic(n_epochs=2, n_chan=4, n_slots=8, samples_per_epoch=50000, sample_rate=4.092e6, seed=3)
+    _, _, stats = _compare(pkg, r, 50000, rate=4.092e6)
     assert stats["kernel_family"] == 0
 
 
@@ -127,6 +128,28 @@ def test_group_kernel_advance_forms_at_high_sample_rates(pkg, rate, want):
         assert stats["window_mode"] == want and stats["chunk_samples"] == 1024 and stats["repaired_groups"] >= 1
     else:
         assert rate not in (25e6, 8e6), stats               # these two qualify
+    _, _, stats = _compare(pkg, p, n, rate=rate, flags=EXACT)
+    assert stats["kernel_family"] == 0
+
+
+@pytest.mark.parametrize("rate", [2.8e6, 3.0e6, 3.2e6, 3.5e6, 3.8e6, 4.0e6, 4.5e6, 5.0e6, 5.5e6, 6.0e6, 6.5e6, 7.0e6, 7.5e6])
+def test_group_kernel_general_hold_form_between_the_others(pkg, rate):
+    """Code steps between 4/15 and 0.74 half chips per sample (2.77 .. 7.7 MS/s; rounds 2-4: the exact-replay kernel) -- 5 to 11
+    holds per group, in any order: window form 4, the spread through a four-stage shift network whose masks are made with the
+    patterns.  24 channels in two launches, page flips, code wraps inside a chunk, listed groups; 3.8 / 4.5 / 7.5 MS/s have
+    pattern thresholds closer than a bin (the step is within 1e-3 of 7/13, 5/11, 3/11) and stay on the exact-replay kernel."""
+    n = 40000
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=24, n_slots=24, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e5))
+    p["ibit0"][0, :4] = [499, 498, 0, 250]
+    p["code_phase0"][0, :3] = [4091.9, 4090.0, 4085.0]   # wraps within the first few hundred samples
+    p["code_phase0"][1, 3] = 6137.9                        # a pending wrap that lands mid-period
+    p["carr_phase0"][0, 5:8] = 0.0                          # listed groups for certain
+    _, _, stats = _compare(pkg, p, n, rate=rate)
+    if rate in (3.8e6, 4.5e6, 7.5e6):
+        assert stats["kernel_family"] == 0, stats
+    else:
+        assert stats["kernel_family"] == 1 and stats["window_mode"] == 4 and stats["chunk_samples"] == 1024, stats
+        assert stats["repaired_groups"] >= 1 and stats["exact_records"] == 0, stats
     _, _, stats = _compare(pkg, p, n, rate=rate, flags=EXACT)
     assert stats["kernel_family"] == 0
 
