@@ -160,3 +160,46 @@ def test_half_chips_adversarial_phases_next_to_the_thresholds():
     yc = np.mod(yc, 8184.0)
     bad, listed, worst, total = _code(yc, s)
     assert bad == 0 and listed >= n // 2, (bad, listed)
+
+
+def _network_masks(f, s):
+    """The four stage masks of window form 4 as synth_group.hip builds them with the patterns: sample u reads field u - h(u) of the
+    window, h(u) = u - floor(f + u s); read from the output back to the window its value passes p0 = u, p1 = p0 - (h & 1), p2 = p1 -
+    (h & 2), p3 = p2 - (h & 4), and stage k shifts the field AT p_k by 2^k fields iff bit k of h is set."""
+    m = [0, 0, 0, 0]
+    for u in range(16):
+        h = u - int(np.floor(f + u * s))
+        pp = u
+        for k in range(4):
+            if h & (1 << k):
+                m[k] |= 3 << (2 * pp)
+            pp -= h & (1 << k)
+    return m
+
+
+def test_window_form_4_shift_network_is_the_gather():
+    """Every pattern of every code step between 4/15 and 0.74 half chips per sample (and beyond: any step below 1): the four-stage
+    network -- bfi(M3, x << 16, x), bfi(M2, x << 8, x), bfi(M1, x << 4, x), bfi(M0, x << 2, x) -- puts field floor(f + u s) of the
+    window at sample u, for random windows."""
+    rng = np.random.default_rng(5)
+    bfi = lambda m, a, b: (m & a) | (~m & b & 0xFFFFFFFF)
+    n = 0
+    for s in np.concatenate([rng.uniform(0.2, 0.9999, 3000), 2.046 / np.array([2.8, 3.0, 3.5, 4.0, 4.092, 5.0, 6.5, 7.0, 7.69])]):
+        T = np.sort(1.0 - ((np.arange(1, 16) * s) % 1.0))
+        edges = np.concatenate([[0.0], T, [1.0]])
+        for lo, hi in zip(edges[:-1], edges[1:]):  # one pattern per interval between two thresholds
+            if hi - lo < 1e-9:
+                continue
+            f = 0.5 * (lo + hi)
+            m0, m1, m2, m3 = _network_masks(f, s)
+            w = int(rng.integers(0, 1 << 32))
+            x = w
+            x = bfi(m3, (x << 16) & 0xFFFFFFFF, x)
+            x = bfi(m2, (x << 8) & 0xFFFFFFFF, x)
+            x = bfi(m1, (x << 4) & 0xFFFFFFFF, x)
+            x = bfi(m0, (x << 2) & 0xFFFFFFFF, x)
+            for u in range(16):
+                g = int(np.floor(f + u * s))
+                assert (x >> (2 * u)) & 3 == (w >> (2 * g)) & 3, (s, f, u)
+            n += 1
+    assert n > 30000
