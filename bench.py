@@ -208,11 +208,14 @@ def leg_file_sink(pkg, seconds=120):
 
 def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams):
     """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
-    bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode), pipelined like the headline, on the
+    bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode; "syn12_4msps" = 12 SVs at 4 MS/s, a rate
+    between the reference's and config 4's: window form 4), pipelined like the headline, on the
     headline's two streams (new streams would get whatever hardware queues are left: DESIGN.md section 6)."""
     n_samp, rate, n_slots, n_chan = 260000, 2.6e6, 16, 12
     if workload in ("syn24", "syn24_full"):
         n_samp, rate, n_slots, n_chan = 2500000, 25e6, 24, 24
+    if workload == "syn12_4msps":
+        n_samp, rate = 400000, 4.0e6
     params = pkg.shard.rank_workload(0, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate,
                                      dyn_track=(workload == "dyn"))
     engines, outs = [], []
@@ -732,7 +735,9 @@ def main():
                                # per handle kept in HBM (sample indices beyond 2^32)
                                "syn24_full": leg_config(torch, pkg, "syn24_full", 5999, 3, local_rank, streams),
                                # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
-                               "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank, streams)}
+                               "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank, streams),
+                               # a sample rate between the window forms of rounds 2-4 (2.77 .. 7.7 MS/s): form 4
+                               "syn12_4msps": leg_config(torch, pkg, "syn12_4msps", 1199, 20, local_rank, streams)}
         line["x_realtime"] = round(value * 1e6 / rate, 2)
         print(json.dumps(line))
     if dist is not None:
