@@ -1,5 +1,5 @@
 #!/bin/bash
-# Randomised parity soak of the current tree (run on the GPU box): product build, long-batch stitcher forced (hooks build),
+# Randomised parity soak of the current tree (run on the GPU box): product build, the stitch with 8 / 3 legs per block (hooks build: its look-back under every small batch),
 # CBOC mode, end-to-end scenarios.   tools/soak_round.sh <tag> [scale]   -> gpurun_out/<tag>_fuzz_soak.log
 set -u
 tag=${1:-rXX}
@@ -10,9 +10,10 @@ mkdir -p gpurun_out
 echo "### product build: fuzz_parity.py $((20000*k)) 301 / $((600*k)) 302 big"
 timeout 1500 python tools/fuzz_parity.py $((20000*k)) 301 2>&1 | tail -1
 timeout 1500 python tools/fuzz_parity.py $((600*k)) 302 big 2>&1 | tail -1
-echo "### hooks build, long-batch stitcher forced: fuzz_parity.py $((3000*k)) 303 / $((150*k)) 304 big"
+echo "### hooks build, 8 / 3 legs per block of the stitch (look-back under every batch): fuzz_parity.py $((3000*k)) 303 / $((150*k)) 304 big / $((2000*k)) 307"
 GAL_FUZZ_HOOKS=1 GAL_SCAN_BLOCK_LEGS=8 timeout 900 python tools/fuzz_parity.py $((3000*k)) 303 2>&1 | tail -1
 GAL_FUZZ_HOOKS=1 GAL_SCAN_BLOCK_LEGS=8 timeout 900 python tools/fuzz_parity.py $((150*k)) 304 big 2>&1 | tail -1
+GAL_FUZZ_HOOKS=1 GAL_SCAN_BLOCK_LEGS=3 timeout 900 python tools/fuzz_parity.py $((2000*k)) 307 2>&1 | tail -1
 echo "### CBOC: fuzz_parity.py $((4000*k)) 305 / $((150*k)) 306 big"
 GAL_FUZZ_CBOC=1 timeout 900 python tools/fuzz_parity.py $((4000*k)) 305 2>&1 | tail -1
 GAL_FUZZ_CBOC=1 timeout 900 python tools/fuzz_parity.py $((150*k)) 306 big 2>&1 | tail -1
