@@ -437,14 +437,13 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     // code-object load now, not inside the first batch (the families this configuration can launch)
     galk_warm(nullptr, (cfg->flags & GAL_CFG_CBOC) ? 1 : 0, 2.0 * 1.023e6 / cfg->sample_rate);
     {
-        // k_synth_g's code object, if a batch of this configuration can take it: the plan's own gate (rw_mode_of; the CBOC mode
-        // exists in form 1 only) on the nominal code step and on the steps +-1e-4 around it (Doppler moves a channel's step by a
+        // k_synth_g's code object, if a batch of this configuration can take it: the plan's own gate (rw_mode_of) on the nominal code step and on the steps +-1e-4 around it (Doppler moves a channel's step by a
         // few 1e-6 of itself)
         const double ratio = 2.0 * 1.023e6 / cfg->sample_rate;
         bool g_possible = false;
         for (const double f : {1.0 - 1e-4, 1.0, 1.0 + 1e-4}) {
             const int m = rw_mode_of(ratio * f);
-            g_possible = g_possible || (m != 0 && (m == 1 || !(cfg->flags & GAL_CFG_CBOC)));
+            g_possible = g_possible || m != 0;
         }
         if (g_possible && !(cfg->flags & GAL_CFG_EXACT_REPLAY) && cfg->chunk_samples <= 0) galk_warm_g(nullptr);
     }
@@ -580,7 +579,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             const double cs2 = 2.0 * (r.f_code * delt);
             cs2_max = std::max(cs2_max, cs2);
             const int mode = rw_mode_of(cs2);
-            if (mode != 0 && !(cboc && mode != 1)) {  // (CBOC: the half-period parity pattern exists in the hold form only)
+            if (mode != 0) {
                 // (evaluated for every new step: the distance is not a continuous function of the step -- when some u s
                 // crosses an integer its threshold jumps from 0 to 1 -- so a cached value cannot be extrapolated)
                 if (cs2 != h->rw_s0[s]) {
@@ -911,9 +910,9 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 
     P.lut = h->d_lut; P.str = h->d_str;
     P.signal = (h->cfg.flags & GAL_CFG_CBOC) ? 1 : 0;
-    // k_synth_g: the form its records have; k_synth alone: its fast body if EVERY record has the same form (CBOC: form 1 only --
-    // rec_mode is 0 for the others), else classic windows
-    P.rw = fam_g ? g_mode : (rw_ok && rw_mode <= 3 ? rw_mode : 0);
+    // k_synth_g: the form its records have; k_synth alone: its fast body if EVERY record has the same form, else classic windows
+    // (k_synth's own fast body: forms 1-3 for BOC(1,1), form 1 for the CBOC mode)
+    P.rw = fam_g ? g_mode : (rw_ok && rw_mode <= (cboc ? 1 : 3) ? rw_mode : 0);
 #ifdef GAL_TEST_HOOKS
     // 0: classic windows (A/B runs); 11 / 12 / 13: force form 1 / 2 / 3 whatever the gate says (the kernel's own safety nets
     // -- undecidable bins, pattern overflow -- must then keep the output exact)

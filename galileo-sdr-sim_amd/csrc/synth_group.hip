@@ -179,9 +179,30 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
                 // fields (B != C, sign of C x secondary) per SAMPLE; the half chip of sample u is ic0 + u - (holds before u): its
                 // parity comes out of the hold masks.  X: the (B - C) factor of every sample as a signed 2-bit field; XB: the (B + C)
                 // factor, whose sign is bit 1 ^ 1 ^ parity(half chip) ^ parity(half period) (k_synth: rw_phase_c1_cboc / _d_cboc)
-                const uint32_t x = rw_spread(W, M[q]);
-                const uint32_t hp = (M[q].x ^ M[q].y ^ M[q].z ^ M[q].w) & 0xAAAAAAAAu;
-                const uint32_t hw = hp ^ 0x22222222u ^ (((uint32_t)ic0[q] & 1u) ? 0xAAAAAAAAu : 0u);
+                // (the spread of the RAW window, by the batch's form; the parity of sample u's half chip relative to ic0's: forms 1
+                // and 4 hold -- half chip ic0 + u - h(u), parity(h) out of the masks (form 1: nested, their XOR; form 4: stage 0 of
+                // the network sits at the output position) and 1 ^ parity(u) = 0x2222.. --, forms 2 and 3 advance -- half chip
+                // ic0 + a(u), parity(a) = the XOR of the nested masks, and the 1 is 0xAAAA..)
+                uint32_t x, hw;
+                if constexpr (MODE == 1) {
+                    x = rw_spread(W, M[q]);
+                    hw = ((M[q].x ^ M[q].y ^ M[q].z ^ M[q].w) & 0xAAAAAAAAu) ^ 0x22222222u;
+                } else if constexpr (MODE == 4) {
+                    x = gal_bfi(M[q].w, W << 16, W);
+                    x = gal_bfi(M[q].z, x << 8, x);
+                    x = gal_bfi(M[q].y, x << 4, x);
+                    x = gal_bfi(M[q].x, x << 2, x);
+                    hw = (M[q].x & 0xAAAAAAAAu) ^ 0x22222222u;
+                } else {
+                    x = gal_bfi(M[q].x, sg_rep(W, 1), sg_rep(W, 0));
+                    x = gal_bfi(M[q].y, sg_rep(W, 2), x);
+                    if constexpr (MODE == 3) {
+                        x = gal_bfi(M[q].z, sg_rep(W, 3), x);
+                        x = gal_bfi(M[q].w, sg_rep(W, 4), x);
+                    }
+                    hw = ((M[q].x ^ M[q].y ^ M[q].z ^ M[q].w) & 0xAAAAAAAAu) ^ 0xAAAAAAAAu;
+                }
+                hw ^= ((uint32_t)ic0[q] & 1u) ? 0xAAAAAAAAu : 0u;
                 X[q] = window_signed(x);
                 const uint32_t sb = x ^ hw ^ p6[q];
                 const uint32_t lo1 = ~x & 0x55555555u;  // B == C: this term is the one that is non-zero
@@ -276,7 +297,6 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
                uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
 {
     static_assert(NCH >= 1 && NCH <= SG_MAXCH, "1..12 channel positions per launch");
-    static_assert(SIG == 0 || MODE == 1, "CBOC: hold form of the resampled window only");
     // CBOC keeps two bin tables per channel (chip holds, half-period parity) of 64 bins each, as in k_synth
     constexpr int BINS = SIG ? CB_BINS : RW_BINS, BPITCH = SIG ? CB_BIN_PITCH : RW_BIN_PITCH;
     __shared__ uint32_t s_str[NCH * SG_STR_PITCH];
@@ -919,9 +939,13 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
     if (P->R != SG_CHUNK) return -2;
     const SynGeom G = sg_geom(P, e0, ne);
     if (P->signal == 1) {
-        if (P->rw != 1) return -3;
-        return accumulate ? launch_synth_g_t<true, 1, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G)
-                          : launch_synth_g_t<false, 1, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+#define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
+                                                  : launch_synth_g_t<false, m, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G);
+        switch (P->rw) {
+            SG_MODE_CASE(1) SG_MODE_CASE(2) SG_MODE_CASE(3) SG_MODE_CASE(4)
+        default: return -3;
+        }
+#undef SG_MODE_CASE
     }
 #define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m, 0>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
                                                   : launch_synth_g_t<false, m, 0>(P, Pd, nch, act, nact, iq, e0, ne, st, G);

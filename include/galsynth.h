@@ -133,7 +133,7 @@ typedef struct gal_synth_stats {
                                    default wherever gal_synth_plan's gate admits the batch: automatic chunking, every code step
                                    in one form of the resampled windows (window_mode 1 ... 4: any rate from 2.05 MS/s up) with
                                    well separated thresholds, every carrier step 0 or in [2^-40, 0.0147] cycles per sample;
-                                   BOC(1,1) in all four forms, the CBOC mode in form 1                                      */
+                                   BOC(1,1) and the CBOC mode in all four forms                                              */
     int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
     float   ms_repair;          /* family 1: device time of that replay (k_repair_g, behind the synthesis kernel; not in ms_synth) */
     int32_t exact_records;      /* family 1: records (channel-epochs) of the batch that are not fit for the group kernel -- a carrier

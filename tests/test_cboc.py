@@ -121,10 +121,14 @@ def test_cboc_both_bodies_on_the_same_batch(pkg, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rate,mode", [(2.2e6, 1), (2.4e6, 1), (2.6e6, 1), (2.76e6, 1), (2.1e6, 0), (2.5e6, 0), (4.0e6, 0), (25e6, 0)])
+@pytest.mark.parametrize("rate,mode", [(2.2e6, 1), (2.4e6, 1), (2.6e6, 1), (2.76e6, 1), (2.1e6, 0), (2.5e6, 0), (3.0e6, 0), (5.0e6, 0),
+                                       (40e6, 0), (3.2e6, 4), (4.0e6, 4), (5.5e6, 4), (6.0e6, 4), (8e6, 3), (10e6, 3), (12.5e6, 3),
+                                       (16e6, 2), (20e6, 2), (25e6, 2), (30e6, 2)])
 def test_cboc_resampled_window_gate_and_rates(pkg, rate, mode):
     """The host enables the resampled-window body only where BOTH threshold sets (chip holds: step s; half-period parity:
-    step 6 s) keep more than a bin (1/64) between neighbours; elsewhere the classic body runs.  Same bits everywhere."""
+    step 6 s) keep more than a bin (1/64) between neighbours; elsewhere the classic body runs.  Same bits everywhere.
+    Round 5: the mode runs on every window form of k_synth_g (rounds 3-4: the hold form of the reference's rate only) --
+    the parity of a sample's half chip comes out of the hold masks (forms 1, 4) or the advance masks (2, 3)."""
     n = int(rate / 50)
     p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=7, n_slots=8, samples_per_epoch=n, sample_rate=rate, seed=int(rate) % 977)
     p["ibit0"][0, 0] = 499

@@ -324,6 +324,31 @@ def test_group_kernel_epoch_ranges_of_one_plan(pkg):
             assert np.array_equal(np.concatenate(parts), ref_iq), world
 
 
+@pytest.mark.parametrize("rate,want", [(25e6, 2), (16e6, 2), (8e6, 3), (12.5e6, 3), (4.0e6, 4), (6.0e6, 4), (3.2e6, 4)])
+def test_group_kernel_cboc_mode_in_every_window_form(pkg, rate, want):
+    """The CBOC mode on the advance forms (2, 3) and on the general hold form (4) of k_synth_g: 14 channels in two launches, page flips,
+    code wraps inside a chunk, a pending wrap, listed groups -- against the checker's CBOC loop and against the exact-replay kernel."""
+    CBOC = pkg.synth.GAL_CFG_CBOC
+    n = 40000
+    p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=14, n_slots=16, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e5) + 3)
+    p["ibit0"][0, :4] = [499, 498, 0, 250]
+    p["code_phase0"][0, :3] = [4091.9, 4090.0, 4085.0]
+    p["code_phase0"][1, 3] = 6137.9
+    p["carr_phase0"][0, 5:8] = 0.0
+    ref_iq, ref_st = oracle_run(p, n, rate, cboc=True)
+    for flags in (CBOC, CBOC | EXACT):
+        with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=16, device=0, flags=flags) as eng:
+            iq, st, stats = eng.run_host(p)
+        assert stats["chain_mismatch"] == 0, stats
+        if flags & EXACT:
+            assert stats["kernel_family"] == 0
+        else:
+            assert stats["kernel_family"] == 1 and stats["window_mode"] == want and stats["repaired_groups"] >= 1, stats
+        assert np.array_equal(iq, ref_iq), (rate, flags)
+        act = ref_st["prn"] > 0
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+
+
 @pytest.mark.parametrize("n_chan", [1, 4, 7, 12, 16])
 def test_group_kernel_cboc_mode(pkg, n_chan):
     """The opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC; not the reference's signal: the checker's CBOC loop defines it) on k_synth_g: a
