@@ -63,10 +63,12 @@ void usage(const char *prog)
            "  -t <date,time>   Scenario start time YYYY/MM/DD,hh:mm:ss\n"
            "  -d <duration>    Duration [sec]\n"
            "  -I <x>           Disable ionospheric delay\n"
-           "  -T <date,time>   Overwrite TOC and TOE of every record to the start time (use `now` for the current time): the\n"
-           "                   navigation file becomes valid at any start, as the option is meant to (include/galscen.h)\n"
-           "  --ref-T          with -T: what the reference, built with its own flags, does instead -- -t without its range check\n"
-           "                   and the UTC reference time overwritten, NO record shifted (an empty sky outside the file's span)\n"
+           "  -T <date,time>   As the reference runs it: -t without its range check, UTC reference time overwritten (use `now` for\n"
+           "                   the current time).  The same bytes as the reference program for the same command line: its loop that\n"
+           "                   would shift TOC / TOE never runs, so a start outside the file's span gives an empty sky (warned about)\n"
+           "  --shift-toe      with -T: what the option sets out to do -- TOC and TOE of every record shifted to the start time, the\n"
+           "                   navigation file becomes valid at any start (include/galscen.h: time_overwrite 2; not the reference's bytes)\n"
+           "  --ref-T          with -T: the explicit spelling of the default (kept for round 5's command lines)\n"
            "  -P <port>        UDP port for run-time position updates lat,lon,hgt as 3 doubles (0 = off; default: 7533 on\n"
            "                   the loopback interface; a port given here is bound on all interfaces, as the reference's)\n"
            "  -r               Pace the output to real time (one 0.1 s epoch per 0.1 s)\n"
@@ -498,7 +500,8 @@ int main(int argc, char *argv[])
         printf("ERROR: Galileo ephemeris/nav_msg file is not specified.\n");
         exit(1);
     }
-    // plain -T shifts TOC / TOE (time_overwrite 2; --shift-toe says so explicitly); --ref-T asks for the reference as built (1)
+    // plain -T is the reference as built (time_overwrite 1: the same command line gives the same bytes; ADVICE r5 -- round 5 had it
+    // shift, and every replay of a reference command line had to add --ref-T); --shift-toe asks for the shift of TOC / TOE (2)
     if ((shift_toe || ref_T) && !sc.time_overwrite) {
         printf("ERROR: %s needs -T <date,time>.\n", ref_T ? "--ref-T" : "--shift-toe");
         exit(1);
@@ -507,7 +510,7 @@ int main(int argc, char *argv[])
         printf("ERROR: --shift-toe and --ref-T exclude each other.\n");
         exit(1);
     }
-    if (sc.time_overwrite) sc.time_overwrite = ref_T ? 1 : 2;
+    if (sc.time_overwrite) sc.time_overwrite = shift_toe ? 2 : 1;
     if (sitesfile[0]) {
         // several listeners cannot share a port: the sites run without the position listener unless -P names a base port, in
         // which case site k (in file order) listens on port + k

@@ -315,7 +315,7 @@ int gal_scen_open(const gal_scen_cfg_t *cfg, gal_scen_t **out)
         if (in_view == 0)
             fprintf(stderr, "WARNING: no satellite in view at the start time -T let through%s: the IQ will be all zero\n",
                     cfg->time_overwrite == 1 ? " (time_overwrite 1 = the reference as built: no ephemeris record is shifted; "
-                                               "2 / plain -T shifts TOC and TOE to the start time)" : "");
+                                               "2 / --shift-toe shifts TOC and TOE to the start time)" : "");
     }
     s->grx.sec = s->grx.sec + kEpochDt;
     s->iumd = 1;

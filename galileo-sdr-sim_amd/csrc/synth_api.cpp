@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,6 +82,7 @@ void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st);
 void galk_launch_carr_scan(const DevPlan *P, uint32_t tag, hipStream_t st);
 size_t galk_scanm_status_bytes(int S, int legs);
 void galk_launch_verify_carr(const DevPlan *P, hipStream_t st);
+void galk_launch_verify_code(const DevPlan *P, hipStream_t st);
 void galk_launch_pages(const DevPlan *P, hipStream_t st);
 void galk_launch_publish(const DevPlan *P, int *h_ctr, void *h_state, uint32_t *h_flag, uint32_t seq, hipStream_t st);
 int galk_scanm_blocks(int legs);
@@ -136,10 +138,10 @@ constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = c
 constexpr int kGroupSyms = 64;      // ... symbol masks per channel and epoch (SG_SYMS)
 constexpr int kGroupListMin = 1 << 16;  // ... least capacity of the undecided-group list (a 120 s batch lists ~2000 of 19.5 M groups);
                                         // a plan's list holds 0.5 % of its groups + this
-constexpr int kVerifyRotation = 8;  // k_verify_carr re-walks every eighth leg position per batch (GAL_CFG_VERIFY_ALL: all of them).  Same box,
-                                    // M-SYN12, pipelined step / one handle / k_synth_g beside it (profiles/r05f_verify_ab.log): none 0.974 /
-                                    // 1.230 / 0.842 ms; every leg 1.010 / 1.297 / 0.890; every 4th 0.985 / 1.258 / 0.865; 8th 0.979 / 1.238 /
-                                    // 0.846; 16th 0.976 / 1.234 / 0.845
+constexpr int kVerifyRotation = 8;  // GAL_CFG_VERIFY_SAMPLED: k_verify_carr / k_verify_code re-walk every eighth leg position per batch (default:
+                                    // all of them).  Same box, M-SYN12, pipelined step / one handle / k_synth_g beside it, carrier legs only
+                                    // (profiles/r05f_verify_ab.log): none 0.974 / 1.230 / 0.842 ms; every leg 1.010 / 1.297 / 0.890; every 4th
+                                    // 0.985 / 1.258 / 0.865; 8th 0.979 / 1.238 / 0.846; 16th 0.976 / 1.234 / 0.845
 constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + stitch (which translates on the spot), one spare --
                                     // no-op launches in front of k_synth when the chain is complete after one, as it normally
                                     // is; a handle whose last batch got by with one enqueues one (gal_synth_finish iterates and
@@ -220,6 +222,7 @@ struct gal_synth {
     hipStream_t walk_stream = nullptr;
     hipEvent_t ev_walk = nullptr;
     hipEvent_t ev_ver = nullptr;  // k_verify_carr done (k_synth_g batches)
+    hipEvent_t ev_verc = nullptr; // k_verify_code done (k_synth_g batches; second walker stream)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
 
@@ -286,9 +289,9 @@ extern "C" {
 #ifdef GAL_TEST_HOOKS
 // libgalsynth_hooks.so: the same sources with the fault-injection hooks of the repair-path tests compiled in
 // (GAL_WALK_LEGS / GAL_WALK_TRANSLATE / GAL_WALK_PASSES environment variables).  Never shipped, never benchmarked.
-const char *gal_synth_version(void) { return "galsynth 0.3 (gfx950, HIP) +testhooks"; }
+const char *gal_synth_version(void) { return "galsynth 0.4 (gfx950, HIP) +testhooks"; }
 #else
-const char *gal_synth_version(void) { return "galsynth 0.3 (gfx950, HIP)"; }
+const char *gal_synth_version(void) { return "galsynth 0.4 (gfx950, HIP)"; }
 #endif
 const char *gal_synth_last_error(void) { return g_err; }
 
@@ -387,6 +390,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ver, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_verc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     // (coherent = fine-grained: k_publish writes both from the device while the host polls the flag behind h_ctr)
@@ -465,6 +469,9 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         return fail(GAL_E_DEVICE, "kernel launch failed on device %d: %s", dev, hipGetErrorString(hipGetLastError()));
     }
     create_stage("code objects loaded, streams used");
+#ifdef GAL_TEST_HOOKS
+    if (const char *env = getenv("GAL_SCAN_TAG0")) h->scan_tag = (uint32_t)strtoul(env, nullptr, 0);  // the tag wrap, within reach of a test
+#endif
     *out = h;
     return GAL_OK;
 }
@@ -488,6 +495,7 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_walk) hipEventDestroy(h->ev_walk);
     if (h->ev_ver) hipEventDestroy(h->ev_ver);
+    if (h->ev_verc) hipEventDestroy(h->ev_verc);
     if (h->walk_stream) hipStreamDestroy(h->walk_stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -844,7 +852,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         const int cls = (int)std::floor(period / R + 0.5);
         P.cls = (cls >= 2 && std::fabs(period - (double)cls * R) < 0.01 && nchunks % cls == 0) ? cls : 1;
     }
-    P.W = W; P.Lc = Lc; P.LEGS = (int)LEGS;
+    P.W = W; P.Lc = Lc; P.LEGS = (int)LEGS; P.LEGS_all = (int)LEGS;
     {
         // the code chain of an epoch in legs (k_walk_code): 4 side by side in a long batch -- 88 + <= 13 dependent closed-form steps
         // per lane instead of 351 --, 16 where a batch of a few epochs is all latency
@@ -999,6 +1007,7 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
         DevPlan Pv = h->Pw;
         if (h->stats.synth_runs > 1) Pv.ver_mod = 1, Pv.ver_rem = 0;
         galk_launch_verify_carr(&Pv, h->stream);
+        galk_launch_verify_code(&Pv, h->stream);
     }
     if (h->nact_max == 0) {  // nothing is transmitted in this batch: the reference's loop stores zeros (:536-537)
         HIP_TRY(hipMemsetAsync(iq, 0, (size_t)h->range_ne * (size_t)h->P.N * 4u, h->stream));
@@ -1065,9 +1074,10 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     h->Pw.tr_e0 = first_epoch;
     h->Pw.tr_e1 = first_epoch + n_epochs;
     h->Pw.cp_e0 = first_epoch;
-    // k_verify_carr (k_synth_g batches): an eighth of the leg positions per batch, rotating with the handle's batch count, plus the
-    // legs whose translation was not overwhelmingly inside its margin; GAL_CFG_VERIFY_ALL: every leg (synth_kernels.hip)
-    h->Pw.ver_mod = (h->cfg.flags & GAL_CFG_VERIFY_ALL) ? 1 : kVerifyRotation;
+    // k_verify_carr / k_verify_code (k_synth_g batches): every leg of both chains (default); GAL_CFG_VERIFY_SAMPLED: an eighth of the leg
+    // positions per batch, rotating with the handle's batch count, plus the carrier legs whose translation was not overwhelmingly
+    // inside its margin (synth_kernels.hip)
+    h->Pw.ver_mod = (h->cfg.flags & GAL_CFG_VERIFY_SAMPLED) ? kVerifyRotation : 1;
 #ifdef GAL_TEST_HOOKS
     if (const char *env = getenv("GAL_VERIFY_MOD")) h->Pw.ver_mod = atoi(env) > 0 ? atoi(env) : h->Pw.ver_mod;  // timing experiments
 #endif
@@ -1102,6 +1112,12 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     if (const char *env = getenv("GAL_WALK_PASSES")) n_passes = atoi(env) > 0 ? atoi(env) : n_passes;
 #endif
     h->first_pass_legs = h->act_prefix[h->Pw.E] * h->P.W;
+    if (h->scan_tag > 0xFFF00000u) {
+        // the stitch's 32-bit launch tags are about to wrap (2 per batch: after ~2^31 batches of one handle): records of old launches
+        // would then carry tags that are handed out again -- clear the status words once and start over
+        HIP_TRY(hipMemsetAsync((char *)h->P.scanm, 0, h->scanm_clear, ws));
+        h->scan_tag = 0;
+    }
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, ws);  // (the first one also resets the batch's counters)
         galk_launch_carr_scan(P, ++h->scan_tag, ws);
@@ -1130,6 +1146,9 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
         if (verify_beside) {
             galk_launch_verify_carr(P, ws);
             HIP_TRY(hipEventRecord(h->ev_ver, ws));
+            // ... and the code checkpoints, on the second walker stream behind the code walk that wrote them (ev_aux is recorded)
+            galk_launch_verify_code(P, h->aux_stream);
+            HIP_TRY(hipEventRecord(h->ev_verc, h->aux_stream));
         }
     }
     HIP_TRY(hipStreamWaitEvent(st, h->ev_aux, 0));
@@ -1137,7 +1156,10 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     int rc = enqueue_synth(h, (uint32_t *)iq_dev, !verify_beside && !no_verify);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev[2], st));
-    if (verify_beside) HIP_TRY(hipStreamWaitEvent(st, h->ev_ver, 0));
+    if (verify_beside) {
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_ver, 0));
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_verc, 0));
+    }
     // counters (walker passes + replay check) and the end-of-batch state, behind the synthesis: nothing in front of
     // k_synth that it does not need (finish()'s repair paths fetch both again)
     h->seq += 1;
@@ -1159,9 +1181,14 @@ static void copy_stats(const gal_synth *h, void *stats, size_t stats_bytes)
     if (stats) memcpy(stats, &h->stats, std::min(stats_bytes, sizeof(gal_synth_stats_t)));
 }
 
+// The un-sized symbols are what binaries compiled against the 0.2 header call (0.3 and later headers turn the names into macros over
+// the _n entry points): they fill the OLDEST published struct -- 40 bytes, up to synth_runs -- and nothing behind it.
+static constexpr size_t kStatsBytesV02 = 40;
+static_assert(offsetof(gal_synth_stats_t, kernel_family) == kStatsBytesV02, "gal_synth_stats_t 0.2 ends in front of kernel_family");
+
 int gal_synth_finish(gal_synth_t *h, gal_chan_state_t *state_out, gal_synth_stats_t *stats)
 {
-    return gal_synth_finish_n(h, state_out, stats, sizeof(gal_synth_stats_t));
+    return gal_synth_finish_n(h, state_out, stats, kStatsBytesV02);
 }
 
 int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats, size_t stats_bytes)
@@ -1260,12 +1287,17 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
     }
     if (ctr_end[CTR_MISMATCH] != 0 && P->translate) {
         // The replay kernel found a checkpoint that genuine stepping does not reproduce.  The only unverified-
-        // by-walking inputs are the TRANSLATED legs: redo the carrier chain with every leg walked and verified
-        // bitwise, then the synthesis.  (Never observed; kept so that a flaw in the translation argument can
-        // cost time but not correctness.)
+        // by-walking inputs are the TRANSLATED legs of the two chains: redo both with every leg walked from its true anchor
+        // (the carrier's verified bitwise by the stitch), then the synthesis with every leg of both re-checked.  (Never observed
+        // outside the fault-injection hooks; kept so that a flaw in the translation argument costs time, not correctness -- which
+        // holds as long as every batch is fully verified: the default, see GAL_CFG_VERIFY_SAMPLED.)
         DevPlan Pw = *P;
         Pw.translate = 0;
         const int max_passes = h->cfg.max_walk_passes > 0 ? h->cfg.max_walk_passes : 64 + P->LEGS;
+        // (the code chain as well: its legs behind the first of an epoch are accepted by translation too -- k_walk_code with
+        // translate == 0 walks every leg from its true anchor --, and the pages hang on its flip flags)
+        galk_launch_walk_code(&Pw, st);
+        galk_launch_pages(&Pw, st);
         int first = 1;  // (the first walk of a chain resets the batch's counters)
         do {
             if (!first && ctr_walk[CTR_PASSES] >= max_passes)
@@ -1351,7 +1383,7 @@ int gal_synth_run_host(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n
                        const gal_chan_state_t *state_in, int16_t *iq_host, gal_chan_state_t *state_out,
                        gal_synth_stats_t *stats)
 {
-    return gal_synth_run_host_n(h, params, n_epochs, state_in, iq_host, state_out, stats, sizeof(gal_synth_stats_t));
+    return gal_synth_run_host_n(h, params, n_epochs, state_in, iq_host, state_out, stats, kStatsBytesV02);
 }
 
 int gal_synth_run_host_n(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,

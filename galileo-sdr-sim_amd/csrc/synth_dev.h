@@ -28,6 +28,8 @@ struct DevPlan {
     int W;        // carrier-walk legs per epoch
     int Lc;       // chunks per leg (leg length = Lc * R samples)
     int LEGS;     // E * W
+    int LEGS_all; // LEGS of the PLAN (gal_synth_execute_range cuts E and LEGS to the executed prefix; what is laid out once per plan --
+                  // the stitch's look-back records -- keeps the plan's strides whatever the cut)
     int Wc;       // code-walk legs per epoch (a power of two <= 64: the legs of an epoch are neighbouring lanes of one wave)
     int Lkc;      // chunks per code leg
     double delt;  // 1.0 / sample_rate, src/galileo-sdr.cpp:162

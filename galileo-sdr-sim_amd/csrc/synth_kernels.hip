@@ -62,7 +62,8 @@ using namespace galdev;
 #endif
 
 #ifdef GAL_TEST_HOOKS
-#define GAL_HOOK_BAD_LEG 5  // (slot 0, epoch 0, leg 5) receives a wrong translation when P.translate == 2
+#define GAL_HOOK_BAD_LEG 5  // (slot 0, epoch 0, leg 5) receives a wrong translation when P.translate == 2; P.translate == 3: code leg 1 of
+                            // (slot 0, epoch 0) does (k_walk_code)
 #endif
 
 #if GAL_TU_WALK
@@ -139,7 +140,16 @@ __global__ void k_walk_code(DevPlan P)
         prev.fl = __shfl_up(L.claim.fl, 1);
         if (k != step || !have) continue;
         double dl;
-        const int how = code_leg_accept(anc, prev, L.margin, tie, L.tpos, &dl);
+        int how = code_leg_accept(anc, prev, L.margin, tie, L.tpos, &dl);
+        // the all-walked fallback (gal_synth_finish after a checkpoint mismatch): no leg is accepted by translation, every one that
+        // was not walked from the true anchor is walked again from it
+        if (!P.translate && (how == 1 || how == 3)) how = 2;
+#ifdef GAL_TEST_HOOKS
+        if (P.translate == 3 && idx == 0 && k == 1 && (how == 0 || how == 1)) {  // (slot 0, epoch 0, code leg 1): a deliberately wrong shift
+            how = 1;
+            dl += 4.547473508864641e-13;  // 2^-41
+        }
+#endif
         if (how == 1) {
             shift = dl;
             shift_from = n0;
@@ -380,40 +390,16 @@ __global__ void k_walk_carr(DevPlan P, int first)
 // each checkpoint of the leg and the state it hands to the next leg must come out bit for bit (CTR_MISMATCH otherwise, which sends
 // gal_synth_finish into the all-walked fallback).  This is what k_synth's exact replay establishes on its way; k_synth_g
 // (synth_group.hip) never forms the exact phase, so batches that run it get this kernel on the walker stream, beside the synthesis.
-// WHICH legs (round 5): nearly every leg is accepted by TRANSLATION (a proof, with the leg's binade margin as
-// its hypothesis), and re-walking all of them in every batch cost a single handle 5.5 % of its step and the pipelined step 3.7 %
-// (k_synth_g 0.05 ms slower beside it, 25 M instructions; profiles/r05f_verify_ab.log).  Now: (a) the legs i = ver_rem (mod
-// ver_mod) -- an eighth per batch, rotating with the handle's batch count, so every leg position is re-walked every eighth batch
-// (at 8 legs per epoch: one leg of every epoch per batch); (b) in EVERY batch the legs whose translation used
-// more than 1/256 of their margin (P.risk; typical: 2^-26 of it); (c) GAL_CFG_VERIFY_ALL: every leg, as before.  Beside it,
-// k_repair_g walks ~20 000 randomly placed chunks of BOTH chains to their ends (code and carrier) and compares them with the next
-// checkpoint.  First nsel threads: the rotation's legs (compact: a wave = 64 selected legs of one slot); the threads behind them:
-// one per leg, for (b).
-__global__ void k_verify_carr(DevPlan P)
+// WHICH legs: EVERY leg of the executed epochs in every batch (ver_mod = 1) -- the default since round 6 (ADVICE r5 / VERDICT r5 item 3:
+// nearly every leg is accepted by TRANSLATION, DESIGN.md section 3 -- a proof, with the leg's binade margin as its hypothesis -- and a
+// product that re-checks a proof only now and then can hand out wrong samples with chain_mismatch == 0 should the proof ever fail).
+// GAL_CFG_VERIFY_SAMPLED (opt-in; round 5's default): (a) the legs i = ver_rem (mod ver_mod) -- an eighth per batch, rotating with
+// the handle's batch count, so every leg position is re-walked every eighth batch; (b) in EVERY batch the legs whose translation
+// used more than 1/256 of their margin (P.risk; typical: 2^-26 of it) -- first nsel threads: the rotation's legs (compact: a wave =
+// 64 selected legs of one slot); the threads behind them: one per eight legs, for (b).  What full verification costs (round 5, same
+// box, profiles/r05f_verify_ab.log): the pipelined step 0.979 -> 1.010 ms, a single handle's 1.238 -> 1.297.
+__device__ __forceinline__ void verify_carr_leg(const DevPlan &P, const int s, const int i)
 {
-    if (P.ctr[CTR_UNVERIFIED] != 0) return;  // chain not complete: gal_synth_finish iterates and launches this again
-    const int mod = P.ver_mod > 1 ? P.ver_mod : 1;
-    const int per_slot = (P.LEGS + mod - 1) / mod;
-    const int nsel = per_slot * P.S;
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int s, i;
-    if (t < nsel) {
-        s = t / per_slot;
-        i = (t - s * per_slot) * mod + P.ver_rem;
-        if (i >= P.LEGS) return;
-    } else {
-        // (b): eight legs' flags per thread; a set one is next to never seen (the thread then re-walks its first: a batch in
-        // which several of eight neighbours are risky is not a case the rotation is for -- GAL_CFG_VERIFY_ALL)
-        t -= nsel;
-        const int total = P.LEGS * P.S;
-        if (mod == 1 || t * 8 >= total) return;
-        int hit = -1;
-        for (int q = 0; q < 8 && t * 8 + q < total; ++q)
-            if (hit < 0 && P.risk[(size_t)t * 8 + q] && (t * 8 + q) % P.LEGS % mod != P.ver_rem) hit = t * 8 + q;
-        if (hit < 0) return;
-        s = hit / P.LEGS;
-        i = hit - s * P.LEGS;
-    }
     const int e = i / P.W, w = i - e * P.W;
     if (e < P.cp_e0) return;  // walked silently: no checkpoints
     const int idx = e * P.S + s;
@@ -427,6 +413,75 @@ __global__ void k_verify_carr(DevPlan P)
     int bad = 0;
     const WalkOut o = carr_walk_track(cpp[0], d, 1.0 / __builtin_fabs(d), n, P.R, 0, [&](int c, double v) { bad += cpp[c] != v; });
     bad += cpp[(n + P.R - 1) / P.R] != o.p;  // the next leg's first checkpoint, or the end-of-epoch state
+    if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
+}
+
+__global__ void k_verify_carr(DevPlan P)
+{
+    if (P.ctr[CTR_UNVERIFIED] != 0) return;  // chain not complete: gal_synth_finish iterates and launches this again
+    const int mod = P.ver_mod > 1 ? P.ver_mod : 1;
+    const int per_slot = (P.LEGS + mod - 1) / mod;
+    const int nsel = per_slot * P.S;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nsel) {
+        const int s = t / per_slot;
+        const int i = (t - s * per_slot) * mod + P.ver_rem;
+        if (i < P.LEGS) verify_carr_leg(P, s, i);
+        return;
+    }
+    // (b), sampled mode only: eight legs' flags per thread; a set one is next to never seen, and EVERY set one is re-walked (round 5
+    // re-walked the first of the eight only: ADVICE r5)
+    t -= nsel;
+    const int total = P.LEGS * P.S;
+    if (mod == 1 || t * 8 >= total) return;
+#pragma unroll 1
+    for (int q = 0; q < 8 && t * 8 + q < total; ++q) {
+        const int li = t * 8 + q;
+        if (!P.risk[li] || li % P.LEGS % mod == P.ver_rem) continue;
+        const int s = li / P.LEGS;
+        verify_carr_leg(P, s, li - s * P.LEGS);
+    }
+}
+
+// k_verify_code: the same for the CODE chain (round 6; ADVICE r5: on the k_synth_g family its checkpoints were only checked where
+// k_repair_g happened to walk, ~0.5 % of them per batch).  One lane per (slot, epoch, code leg) of the executed epochs -- k_walk_code's
+// layout --, the leg walked once more from its own first checkpoint, genuinely and in closed form (code_walk: no speculation, no
+// translation): every checkpoint of the leg, the state it hands to the next leg (or the end-of-epoch state) and -- leg 0 -- the epoch's
+// host-given start state must come out bit for bit, symbol counter and page-flip flag included.  By induction from the epoch's
+// start every code checkpoint of the batch is then what stepping src/galileo-sdr.cpp:491-507,528 sample by sample produces.
+// Sampled mode (GAL_CFG_VERIFY_SAMPLED): the legs (epoch * Wc + leg) = ver_rem (mod ver_mod).
+__global__ void k_verify_code(DevPlan P)
+{
+    const int Wc = P.Wc;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.E * P.S * Wc) return;
+    const int k = t & (Wc - 1);
+    const int se = t / Wc;
+    const int s = se / P.E;
+    const int e = se - s * P.E;
+    if (e < P.cp_e0) return;  // epochs in front of the executed range carry no checkpoints
+    const int idx = e * P.S + s;
+    if (P.prn[idx] <= 0) return;
+    const int mod = P.ver_mod > 1 ? P.ver_mod : 1;
+    if (mod > 1 && (e * Wc + k) % mod != P.ver_rem) return;
+    const int Lk = P.Lkc;
+    const int n0 = k * Lk * P.R;
+    if (n0 >= P.N) return;
+    int n1 = (k + 1) * Lk * P.R;
+    n1 = n1 > P.N ? P.N : n1;
+    const double *cpx = P.cp_x + (size_t)idx * P.CP1 + (size_t)k * Lk;
+    const uint32_t *cpi = P.cp_ib + (size_t)idx * P.CP1 + (size_t)k * Lk;
+    const double c = P.cstep[idx];
+    const uint32_t w0 = cpi[0];
+    const int fl0 = (int)(w0 >> 16);
+    int bad = 0;
+    if (k == 0) bad += d2u(cpx[0]) != d2u(P.x0[idx]) || w0 != (uint32_t)P.ib0[idx];
+    const CodeEnd end = code_walk(cpx[0], (int)(w0 & 0xffffu), c, 1.0 / c, n1 - n0, P.R, [&](int ci, double x, int ib, int fl) {
+        bad += d2u(cpx[ci]) != d2u(x) || cpi[ci] != ((uint32_t)ib | ((uint32_t)(fl | fl0) << 16));
+    });
+    const int nck = (n1 - n0 + P.R - 1) / P.R;  // the next leg's first checkpoint, or the end-of-epoch state
+    bad += d2u(cpx[nck]) != d2u(end.x) || cpi[nck] != ((uint32_t)end.ibit | ((uint32_t)(end.flipped | fl0) << 16));
+    if (n1 >= P.N) bad += P.flip_in[idx] != (uint8_t)(end.flipped | fl0);  // what k_pages reads
     if (bad) atomicAdd(&P.ctr[CTR_MISMATCH], bad);
 }
 
@@ -665,8 +720,11 @@ __device__ __forceinline__ void stitch_publish(const DevPlan &P, const int t, co
 // are 17 us (80 MB read + written); the scans themselves 1 + 4 us.
 #define SCANM_THREADS 256
 
-struct ScanM {  // look-back records of the multi-block stitch: [S][B] each
-    int B;
+struct ScanM {  // look-back records of the multi-block stitch: [S][Bs] each
+    int B;                                            // blocks per slot of THIS launch (the executed prefix's legs)
+    int Bs;                                           // record stride = blocks per slot of the PLAN: the sub-arrays keep their places whatever
+                                                      // range of the plan a launch covers (laid out from the cut plan, a second
+                                                      // range moved the status words over former payload words that nobody clears)
     uint32_t tag;                                     // of this launch (non-zero)
     int nap;                                          // 64-cycle naps between two looks at a record that is not there yet
     int lpb;                                          // legs per block: SCANM_THREADS (GAL_TEST_HOOKS: fewer, so that small batches have many blocks)
@@ -799,7 +857,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
     const int b = M.B > 1 ? s_ticket : 0;
     const int i = b * M.lpb + t;  // my leg
     const bool in = t < M.lpb && i < P.LEGS;
-    const size_t ob = (size_t)s * M.B + b;
+    const size_t ob = (size_t)s * M.Bs + b;
     if (t == 0) {
         s_unver = 0;
         s_rewalk = 0;
@@ -858,7 +916,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
             const int q = base + t;
             ClaimState rec = {0, 0, 0.0};
             if (q < b) {
-                const size_t oq = (size_t)s * M.B + q;
+                const size_t oq = (size_t)s * M.Bs + q;
                 scanm_wait(M.st1, oq, M.tag, M.nap);
                 rec.kind = ld_agent(M.a1_kind + oq);
                 rec.w = ld_agent(M.a1_w + oq);
@@ -938,7 +996,7 @@ __global__ __launch_bounds__(SCANM_THREADS) void k_scanm(DevPlan P, ScanM M)
             const int q = base + t;
             FoldRec rec = fold_identity();
             if (q < b) {
-                const size_t oq = (size_t)s * M.B + q;
+                const size_t oq = (size_t)s * M.Bs + q;
                 scanm_wait(M.st2, oq, M.tag, M.nap);
                 const int fl = ld_agent(M.a2_f + oq);
                 rec.fv = fl & 1; rec.v = (fl >> 1) & 1; rec.m.isconst = (fl >> 2) & 1;
@@ -2210,6 +2268,12 @@ extern "C" void galk_launch_verify_carr(const DevPlan *P, hipStream_t st)
     hipLaunchKernelGGL(k_verify_carr, dim3((n + 255) / 256), dim3(256), 0, st, *P);
 }
 
+extern "C" void galk_launch_verify_code(const DevPlan *P, hipStream_t st)
+{
+    const int n = P->E * P->S * P->Wc;
+    hipLaunchKernelGGL(k_verify_code, dim3((n + 63) / 64), dim3(64), 0, st, *P);
+}
+
 extern "C" void galk_launch_walk_carr(const DevPlan *P, int first, hipStream_t st)
 {
     const int n = P->LEGS * P->S;
@@ -2257,12 +2321,13 @@ extern "C" void galk_launch_carr_scan(const DevPlan *P, uint32_t tag, hipStream_
     ScanM M;
     M.lpb = scanm_lpb();
     M.B = galk_scanm_blocks(P->LEGS);
+    M.Bs = galk_scanm_blocks(P->LEGS_all > P->LEGS ? P->LEGS_all : P->LEGS);
     M.tag = tag ? tag : 1u;
     M.nap = 1;
 #ifdef GAL_TEST_HOOKS
     if (const char *e = getenv("GAL_SCANM_NAP")) M.nap = atoi(e);
 #endif
-    const size_t SB = (size_t)P->S * M.B;
+    const size_t SB = (size_t)P->S * M.Bs;
     char *p = (char *)P->scanm;
     auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) / 256 * 256; return q; };
     M.cnt = (uint32_t *)take(256);  // (S <= 64)

@@ -117,16 +117,17 @@ class Scenario:
         cfg.iono_enable = 1 if iono_enable else 0
         cfg.n_slots = int(n_slots)
         cfg.verbose = 1 if verbose else 0
-        # -T (galscen.h: time_overwrite).  True / 2: TOC and TOE of every record shifted to the start -- what the option sets out
-        # to do; "ref" / 1 (an int, not True): the reference as built with its own flags -- no record shifted, an empty sky outside
-        # the file's span (what tests and tools that replay the reference program's command lines ask for)
+        # -T (galscen.h: time_overwrite).  True / 1 / "ref": the reference as built with its own flags -- -t without the range check,
+        # no record shifted, an empty sky outside the file's span: the reference's bytes for the reference's command line (True == 1:
+        # the bool and the int mean the same).  "shift" / 2: TOC and TOE of every record shifted to the start -- what the
+        # option sets out to do (CLI: -T ... --shift-toe)
         if isinstance(time_overwrite, str):
-            if time_overwrite != "ref":
-                raise ValueError("time_overwrite: False, True, 'ref', 1 or 2")
-            cfg.time_overwrite = 1
-        elif isinstance(time_overwrite, bool):
-            cfg.time_overwrite = 2 if time_overwrite else 0
+            if time_overwrite not in ("ref", "shift"):
+                raise ValueError("time_overwrite: False, True, 'ref', 'shift', 1 or 2")
+            cfg.time_overwrite = 1 if time_overwrite == "ref" else 2
         else:
+            if int(time_overwrite) not in (0, 1, 2):
+                raise ValueError("time_overwrite: False, True, 'ref', 'shift', 1 or 2")
             cfg.time_overwrite = int(time_overwrite)
         cfg.udp_port = int(udp_port)
         cfg.strict_eph = 1 if strict_eph else 0

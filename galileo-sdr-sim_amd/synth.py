@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libgalsynth.so")
 HOOKS_LIB_PATH = os.path.join(PKG_DIR, "libgalsynth_hooks.so")
 GAL_CFG_SINGLE_STREAM = 1
 GAL_CFG_EXACT_REPLAY = 4  # always the exact-replay kernel (k_synth), also where k_synth_g could run
-GAL_CFG_VERIFY_ALL = 8  # k_synth_g batches: re-walk every translated carrier leg in every batch (default: a rotating eighth)
+GAL_CFG_VERIFY_ALL = 8  # accepted and ignored since 0.4: full verification is the default
+GAL_CFG_VERIFY_SAMPLED = 16  # k_synth_g batches: re-walk a rotating eighth of the leg positions of both chains per batch (default: every leg)
 GAL_CFG_CBOC = 2  # opt-in CBOC(6,1,1/11) sub-carrier (not in the reference; defined by the oracle's CBOC mode)
 
 GAL_CH_RESTART = 1

@@ -33,7 +33,8 @@ typedef struct gal_scen_cfg {
     int32_t n_slots;          /* channel slots per row; reference MAX_CHAN = 16                              */
     int32_t verbose;          /* print the reference's allocation lines to stderr (src/channel.cpp:101)      */
     int32_t time_overwrite;   /* -T (src/main.cpp:237-257, src/gnss-time.cpp:105-137).  The CLI's plain -T and the Python mirror's
-                                 time_overwrite=True mean 2 (what the option sets out to do); 1 is opt-in (--ref-T / "ref").
+                                 time_overwrite=True mean 1 (the reference's bytes for the reference's command line); 2 is opt-in
+                                 (--shift-toe / "shift").
                                  1 = what the reference, built with its
                                  own flags, does: the range check of -t is skipped and the UTC reference time (wnt, tot) is
                                  overwritten; NO ephemeris record is shifted (its loop bound `neph`, src/galileo-sdr.cpp:85,

@@ -101,11 +101,17 @@ typedef struct gal_synth_cfg {
                                     the default kernel of the reference geometry -- 16-sample groups from closed-form start
                                     states, undecided groups replayed exactly -- could run.  Same bits either way; this one is
                                     slower and carries the replay self-check (gal_synth_stats_t.kernel_family says which ran) */
-#define GAL_CFG_VERIFY_ALL 8u    /* batches of the default kernel (kernel_family 1): re-walk EVERY translated carrier leg in every batch
-                                    (round 4's behaviour; a single handle's step is 5 % longer for it).  Default: an eighth of the
-                                    leg positions per batch, rotating with the handle's batch count, plus every leg whose
-                                    translation used more than 1/256 of its margin, plus ~20 000 randomly placed chunks of both
-                                    chains walked to their ends by the repair kernel                       */
+#define GAL_CFG_VERIFY_ALL 8u    /* accepted and ignored: what it asked for is the default since 0.4 (see GAL_CFG_VERIFY_SAMPLED)     */
+#define GAL_CFG_VERIFY_SAMPLED 16u /* batches of the default kernel (kernel_family 1), which never forms an exact phase itself.  DEFAULT
+                                    (flag clear): every carrier leg and every code leg of the executed epochs is walked once more from
+                                    its own first checkpoint, genuinely, in every batch, and every checkpoint must come out bit for
+                                    bit (k_verify_carr, k_verify_code) -- what the exact-replay kernel establishes on its way.
+                                    Flag set (round 5's default; ~3-5 % less per step): an eighth of the leg positions of both
+                                    chains per batch, rotating with the handle's batch count -- every (epoch, leg) position of a
+                                    repeated plan is re-walked once per N = 8 batches --, plus every carrier leg whose translation
+                                    used more than 1/256 of its margin, plus the chunks k_repair_g walks to their ends.  A wrong
+                                    translation (a proof would have to be wrong) is then caught within 8 batches instead of in
+                                    the batch it happens in                                                  */
 #define GAL_CFG_SINGLE_STREAM 1u /* enqueue every kernel on the handle's stream (no internal high-priority walker
                                     streams): for callers that capture or serialise the stream themselves       */
 
@@ -141,9 +147,12 @@ typedef struct gal_synth_stats {
                                    crowd, another window form than the batch's -- and took an accumulating exact-replay launch
                                    behind it (0 in every scenario of the reference's geometry seen so far)                      */
 } gal_synth_stats_t;
-/* The struct only ever GROWS AT ITS END (0.2: 40 bytes, up to chain_mismatch .. ms_synth; 0.3: 56).  gal_synth_finish and
- * gal_synth_run_host are macros over the _n entry points below, which copy min(the caller's sizeof, the library's) bytes: a caller
- * compiled against an older header never gets more than its own struct holds.  gal_synth_stats_size() = the library's sizeof. */
+/* The struct only ever GROWS AT ITS END (0.2: 40 bytes, walk_passes .. synth_runs; 0.3 / 0.4: 56).  gal_synth_finish and
+ * gal_synth_run_host are function-like macros over the _n entry points below, which copy min(the caller's sizeof, the library's)
+ * bytes: a caller compiled against an older header never gets more than its own struct holds.  The plain SYMBOLS of those two
+ * names stay exported for binaries built against 0.2 and fill exactly those 40 bytes.  Caveat of the macros: the two names cannot
+ * be used as function pointers -- take &gal_synth_finish_n / &gal_synth_run_host_n (or define GAL_SYNTH_NO_SIZED_MACROS before
+ * including this header and get the 40-byte symbols).  gal_synth_stats_size() = the library's sizeof. */
 
 typedef struct gal_synth gal_synth_t;
 

@@ -93,10 +93,11 @@ def test_cli_realtime_pacing_and_live_position(tmp_path):
 
 @pytest.mark.gpu
 def test_cli_time_overwrite(pkg, tmp_path):
-    """-T <date,time>: TOC / TOE overwrite (src/main.cpp:237-257, src/gnss-time.cpp:105-137: what the option is meant to do, galscen.h
-    time_overwrite 2) through the whole CLI: a start two and a half years after the navigation file is an error with -t and a valid
-    run here, whose bytes are the oracle's on the front-end's rows.  -T --ref-T is the reference as built: an empty sky, with a
-    warning on stderr.  --ref-T / --shift-toe without -T are errors."""
+    """-T <date,time> (src/main.cpp:237-257, src/gnss-time.cpp:105-137) through the whole CLI.  Plain -T is the reference as built
+    (galscen.h time_overwrite 1; ADVICE r5: the same command line must give the reference's bytes): -t without the range check, so a
+    start two and a half years after the navigation file -- an error with -t -- runs with an empty sky and a warning on stderr;
+    --ref-T spells that default out.  -T --shift-toe is what the option sets out to do (time_overwrite 2): TOC / TOE shifted, a
+    valid run whose bytes are the oracle's on the front-end's rows.  --ref-T / --shift-toe without -T are errors."""
     import numpy as np
 
     from oracle_binding import oracle_run
@@ -106,20 +107,26 @@ def test_cli_time_overwrite(pkg, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 1 and "Invalid start time" in r.stderr
     out = tmp_path / "t.ishort"
-    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", when, "-d", "2", "-P", "0", "-o", str(out)],
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", when, "--shift-toe", "-d", "2", "-P", "0", "-o", str(out)],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "WARNING: no satellite" not in r.stderr, r.stderr
-    rows = pkg.Scenario(NAV, llh=(-6, 51, 100), start=when, duration_s=2, time_overwrite=True).all()
+    rows = pkg.Scenario(NAV, llh=(-6, 51, 100), start=when, duration_s=2, time_overwrite="shift").all()
     assert (rows["prn"] > 0).any()
     ref_iq, _ = oracle_run(rows, 260000, 2.6e6)
     assert np.array_equal(np.fromfile(str(out), dtype=np.int16), ref_iq)
-    first = out.read_bytes()
-    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", when, "--shift-toe", "-d", "2", "-P", "0", "-o", str(out)], capture_output=True, text=True)
-    assert r.returncode == 0 and out.read_bytes() == first  # (--shift-toe: the explicit spelling of the default)
-    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", when, "--ref-T", "-d", "2", "-P", "0", "-o", str(out)], capture_output=True, text=True)
+    for extra in ([], ["--ref-T"]):  # plain -T = the reference as built; --ref-T: its explicit spelling
+        r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", when] + extra + ["-d", "2", "-P", "0", "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "WARNING: no satellite in view" in r.stderr and "--shift-toe" in r.stderr
+        assert not np.fromfile(str(out), dtype=np.int16).any()  # as the reference: nothing in view, 19 epochs of zeros
+    # inside the file's span plain -T is -t: the same bytes
+    inside = "2022/02/20,12:00:00"
+    r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-T", inside, "-d", "2", "-P", "0", "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "WARNING: no satellite in view" in r.stderr
-    assert not np.fromfile(str(out), dtype=np.int16).any()  # as the reference: nothing in view, 19 epochs of zeros
+    rows = pkg.Scenario(NAV, llh=(-6, 51, 100), start=inside, duration_s=2, time_overwrite=True).all()
+    assert np.array_equal(rows, pkg.Scenario(NAV, llh=(-6, 51, 100), start=inside, duration_s=2, time_overwrite=1).all())  # True == 1
+    ref_iq, _ = oracle_run(rows, 260000, 2.6e6)
+    assert np.array_equal(np.fromfile(str(out), dtype=np.int16), ref_iq)
     for flag in ("--ref-T", "--shift-toe"):  # neither means anything without -T
         r = subprocess.run([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", flag, "-d", "2", "-P", "0", "-o", str(out)],
                            capture_output=True, text=True)

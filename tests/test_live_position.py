@@ -67,7 +67,7 @@ def test_malformed_datagrams_are_ignored(pkg):
 
 
 def test_time_overwrite_as_the_reference_does_it(pkg):
-    """-T as the reference, built with its own flags, runs it (galscen.h: time_overwrite 1, Python "ref", CLI --ref-T; checked against the reference program
+    """-T as the reference, built with its own flags, runs it (galscen.h: time_overwrite 1, Python True / "ref", CLI plain -T; checked against the reference program
     itself by tools/ref_task_fuzz.py and tests/test_ref_task.py): the range check of -t is skipped, the UTC reference time is
     overwritten, no record is shifted -- inside the file's span the rows are those of -t, outside it the sky is empty."""
     inside = pkg.Scenario(NAV, llh=(-6, 51, 100), start=START, duration_s=3, time_overwrite="ref").all()
@@ -79,7 +79,7 @@ def test_time_overwrite_as_the_reference_does_it(pkg):
 
 
 def test_time_overwrite_makes_the_file_valid_at_any_start(pkg):
-    """time_overwrite 2 (Python: True; CLI: plain -T), what the option is meant to do: a start far outside the file's span is an error
+    """time_overwrite 2 (Python: "shift"; CLI: -T ... --shift-toe), what the option is meant to do: a start far outside the file's span is an error
     with -t and fine here; the records are shifted by the start floored to 2 h minus the first TOC, so the satellites seen are
     those of the file's first hours, and the pages carry the new time."""
     with pytest.raises(pkg.GalScenError):

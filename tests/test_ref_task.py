@@ -69,8 +69,8 @@ def test_cli_file_equals_the_reference_programs_file(k, tmp_path):
     """Same command line into the reference program and into the product CLI (front-end -> HIP -> file): the same bytes."""
     ref_path, out = str(tmp_path / "r.bin"), str(tmp_path / "o.bin")
     _, ref_n, _, _ = run_ref_task(BIN, _args(k), ref_path)
-    # (--ref-T: the reference's -T as built -- the CLI's plain -T shifts TOC / TOE, which is what the option is meant to do)
-    r = subprocess.run([CLI, "-e", NAV] + _args(k).split() + (["--ref-T"] if k["T"] else []) + ["-P", "0", "-o", out], capture_output=True, text=True)
+    # (the very same arguments, -T included: plain -T is the reference as built)
+    r = subprocess.run([CLI, "-e", NAV] + _args(k).split() + ["-P", "0", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     a, b = np.fromfile(ref_path, dtype=np.int16), np.fromfile(out, dtype=np.int16)
     assert a.size * 2 == ref_n and a.any()
@@ -130,7 +130,7 @@ def test_front_end_and_oracle_reproduce_recorded_reference_answers(pkg, k):
 def test_cli_reproduces_recorded_reference_answers(k, tmp_path):
     args = _case_args(k)
     out = str(tmp_path / "o.bin")
-    r = subprocess.run([CLI, "-e", NAV] + args.split() + (["--ref-T"] if k["tovr"] else []) + ["-P", "0", "-o", out], capture_output=True, text=True)
+    r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     if "no ephemeris within an hour" in r.stderr:
         pytest.skip("ephemeris gap: the reference's behaviour is undefined there")

@@ -96,8 +96,8 @@ def run_case_cli(k, args, ref_md5, ref_n, rc):
     """The product's side of a case: the CLI on the reference's command line (-P 0: no position listener)."""
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         out = os.path.join(d, "o.bin")
-        # (--ref-T: the reference's -T as built; the CLI's plain -T shifts TOC / TOE)
-        r = subprocess.run([CLI, "-e", NAV] + args.split() + (["--ref-T"] if k.get("tovr") else []) + ["-P", "0", "-o", out], capture_output=True, text=True)
+        # (the very same arguments, -T included: plain -T is the reference as built)
+        r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True)
         if r.returncode != 0:
             if "Invalid start time" in r.stderr:
                 return dict(k=k, args=args, status="skipped", why=r.stderr.strip().splitlines()[-1], ref_n=ref_n, ref_rc=rc)
