@@ -206,7 +206,7 @@ def leg_file_sink(pkg, seconds=120):
     return out
 
 
-def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams):
+def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0):
     """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
     bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode; "syn12_4msps" = 12 SVs at 4 MS/s, a rate
     between the reference's and config 4's: window form 4), pipelined like the headline, on the
@@ -223,7 +223,7 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams):
         streams.append(torch.cuda.Stream())
     for _ in range(2):
         eng = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank,
-                              flags=pkg.synth.GAL_CFG_CBOC if workload == "cboc" else 0)
+                              flags=(pkg.synth.GAL_CFG_CBOC if workload == "cboc" else 0) | flags)
         eng.set_stream(streams[len(engines)].cuda_stream)
         eng.plan(params)
         engines.append(eng)
@@ -254,6 +254,74 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams):
     return {"value": round(value, 1), "unit": "Msamples/s", "x_realtime": round(value * 1e6 / rate, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "epochs": epochs, "channels": n_chan, "samples_per_epoch": n_samp, "steps": steps,
             "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3), "window_mode": stats[-1].get("window_mode")}
+
+
+def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms):
+    """the engine on FRESH parameters.  The headline re-executes one resident plan; no caller runs the same 120 s
+    twice -- the reference computes its parameters between epochs (src/galileo-sdr.cpp:450-479).  Here every step gets a scenario of
+    its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish: gal_synth_plan_async on the handle that
+    has just been finished -- validation, lists, the SoA split into pinned memory, the upload enqueued -- while the other handle's
+    batch runs on the device.  The parameter sets are made before the timed region (producing them is the front-end's job, f1).
+    The outputs of the last two steps -- two different seeds -- are then compared with the oracle, every int16 of every epoch."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import oracle_run
+
+    depth = len(engines)
+    warm = 2 * depth
+    n_sets = min(steps + warm, 64)  # (beyond 64 steps the seeds repeat, 64 steps apart: 3.4 MB of records each)
+    sets = [pkg.shard.rank_workload(1000 + k, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate)
+            for k in range(n_sets)]
+    which = [None] * depth
+
+    def run(first, n):
+        stats = []
+        inflight = [False] * depth
+        for k in range(n):
+            j = k % depth
+            if inflight[j]:
+                stats.append(engines[j].finish()[1])
+            engines[j].plan(sets[(first + k) % n_sets], wait=False)
+            engines[j].execute(outs[j].data_ptr())
+            which[j] = (first + k) % n_sets
+            inflight[j] = True
+        for k in range(n, n + depth):
+            j = k % depth
+            if inflight[j]:
+                stats.append(engines[j].finish()[1])
+                inflight[j] = False
+        return stats
+
+    run(0, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = run(warm, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(x["chain_mismatch"] == 0 for x in stats)
+    ms = dt / steps * 1e3
+    value = epochs * n_samp * steps / dt / 1e6
+
+    def check(j):
+        ref_iq, _ = oracle_run(sets[which[j]], n_samp, rate)
+        bad, piece = 0, 64 * n_samp * 2
+        for a in range(0, ref_iq.size, piece):
+            bad += int(np.count_nonzero(outs[j][a:a + piece].cpu().numpy() != ref_iq[a:a + piece]))
+        return {"seed": 1000 + which[j], "epochs_compared": epochs, "int16_different": bad,
+                "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}
+
+    with ThreadPoolExecutor(depth) as ex:  # ctypes releases the GIL inside the oracle
+        checks = list(ex.map(check, range(depth)))
+    return {"value": round(value, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "steps": steps, "distinct_parameter_sets": n_sets,
+            "plan_ms": round(sum(x["ms_plan"] for x in stats) / len(stats), 4),
+            "h2d_ms": round(sum(x["ms_h2d"] for x in stats) / len(stats), 4),
+            "ratio_to_resident_plan_step": round(ms / resident_ms, 4) if resident_ms else None,
+            "synth_runs_max": max(x.get("synth_runs", 1) for x in stats),
+            "output_equals_oracle": all(c["int16_different"] == 0 for c in checks), "oracle_checks": checks,
+            "what": "step = gal_synth_plan_async (new scenario: host validation + SoA split + upload enqueued) + execute + finish, %d handles; "
+                    "plan_ms = host time of the plan call, h2d_ms = device time of its upload, both per step" % depth}
 
 
 def profiled_kernel_ms(kind="bench"):
@@ -293,7 +361,7 @@ def measured_traffic():
         return None, None
 
 
-def measured_issue(kernel_ms):
+def measured_issue(kernel_ms, channel_samples):
     """What actually bounds k_synth_g: instruction issue, not HBM.  From the newest committed PMC summary
     (profiles/*_pmc_k_synth_all.json: SQ_INSTS_VALU, SQ_LDS_IDX_ACTIVE per launch): VALU wave-instructions x 4 cycles over the
     chip's 1024 SIMDs at the 2.4 GHz the device reports, and LDS array cycles over its 256 LDS units, against the LIVE kernel time.
@@ -310,7 +378,7 @@ def measured_issue(kernel_ms):
         out = {"bound": "valu issue", "valu_wave_instructions": int(valu), "cycles_per_instruction": 4, "simds": 1024, "clock_ghz": 2.4,
                "valu_ms": round(valu * 4 / 1024 / 2.4e9 * 1e3, 4), "kernel_ms": round(kernel_ms, 4),
                "frac": round(valu * 4 / 1024 / 2.4e9 * 1e3 / kernel_ms, 4),
-               "per_channel_sample": round(valu * 64 / (311.74e6 * 12), 3),
+               "per_channel_sample": round(valu * 64 / channel_samples, 3),
                "source": os.path.basename(files[-1]), "is_live": False}
         if "SQ_LDS_IDX_ACTIVE" in d:
             lds = float(d["SQ_LDS_IDX_ACTIVE"])
@@ -396,6 +464,7 @@ def main():
                     "(reported as preroll_steps).  A device that comes out of idle runs its first ~100 ms below its "
                     "sustained clocks, and W = 5 steps are 6 ms of work; 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fresh-plan", action="store_true", help="skip configs.fresh_plan (the same step with a new scenario planned every step)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed-for-headline legs (kernel + D2H, CLI file "
                     "sink, M-DYN, M-SYN24) that the default 1-GPU run reports under e2e / configs")
     args = ap.parse_args()
@@ -702,7 +771,8 @@ def main():
                 "avg_walk_ms": round(ms_walk / args.steps, 4),
                 "algorithmic_bytes_per_launch": 4 * samples_per_step,
                 # the bound that binds: issue slots (north_star's HBM-write fraction above stays the headline `frac`)
-                **({"issue": measured_issue(solo_ms)} if traffic is not None and measured_issue(solo_ms) else {}),
+                **({"issue": measured_issue(solo_ms, float(samples_per_step) * args.channels)}
+                   if traffic is not None and measured_issue(solo_ms, float(samples_per_step) * args.channels) else {}),
             },
         }
         default_run = (world == 1 and args.workload == "syn12" and args.epochs == 1199 and args.channels == 12 and not strong
@@ -721,6 +791,14 @@ def main():
                     print(json.dumps(line))
                     raise SystemExit("bench: the timed output differs from the oracle in %d int16 values of the first %d epochs"
                                      % (v["int16_different"], v["epochs_compared"]))
+        if world == 1 and args.workload in ("syn12", "dyn") and not strong and args.signal == "boc11" and not args.no_fresh_plan:
+            # the same step on FRESH parameters (plan + execute + finish, another scenario every step), on the headline's handles
+            line["configs"] = {"fresh_plan": leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, args.channels, args.epochs,
+                                                            args.steps, elapsed / args.steps * 1e3)}
+            line["config"]["plan_ms"] = line["configs"]["fresh_plan"]["plan_ms"]  # host time of one gal_synth_plan of this workload
+            if not line["configs"]["fresh_plan"]["output_equals_oracle"]:
+                print(json.dumps(line))
+                raise SystemExit("bench: a fresh-plan step's output differs from the oracle")
         if default_run and not args.no_extras:
             # untimed-for-headline legs (kernel-only above, kernel + D2H and the file sink here; configs 3/4)
             line["e2e"] = {"kernel_plus_d2h": leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp)}
@@ -729,7 +807,8 @@ def main():
             del outs[:], out
             torch.cuda.empty_cache()
             line["e2e"]["file_sink"] = leg_file_sink(pkg)
-            line["configs"] = {"dyn": leg_config(torch, pkg, "dyn", 2999, 24, local_rank, streams),
+            line["configs"] = {**line.get("configs", {}),
+                               "dyn": leg_config(torch, pkg, "dyn", 2999, 24, local_rank, streams),
                                "syn24": leg_config(torch, pkg, "syn24", 600, 8, local_rank, streams),
                                # BASELINE config 4 at its FULL size: 600 s x 25 MS/s x 24 SVs = 15.0 G samples, 60 GB of IQ
                                # per handle kept in HBM (sample indices beyond 2^32)
@@ -738,6 +817,13 @@ def main():
                                "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank, streams),
                                # a sample rate between the window forms of rounds 2-4 (2.77 .. 7.7 MS/s): form 4
                                "syn12_4msps": leg_config(torch, pkg, "syn12_4msps", 1199, 20, local_rank, streams)}
+            # the headline with the opt-in SAMPLED self-check (round 5's default: a rotating eighth of the leg positions per batch instead
+            # of every leg of both chains in every batch), same run, same box: what full verification costs the step
+            vs = leg_config(torch, pkg, "syn12", 1199, max(args.steps, 20), local_rank, streams, flags=pkg.synth.GAL_CFG_VERIFY_SAMPLED)
+            line["roofline"]["verify_sampled"] = {"ms_per_step": vs["ms_per_step"], "value": vs["value"], "unit": "Msamples/s",
+                                                  "steps": vs["steps"], "avg_kernel_ms": vs["avg_kernel_ms"],
+                                                  "what": "GAL_CFG_VERIFY_SAMPLED: every (epoch, leg) position re-walked once per 8 batches; "
+                                                          "the headline re-walks every leg of both chains in every batch"}
         line["x_realtime"] = round(value * 1e6 / rate, 2)
         print(json.dumps(line))
     if dist is not None:

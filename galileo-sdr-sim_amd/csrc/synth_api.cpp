@@ -163,51 +163,51 @@ static double guess_reduce(double x, double d)
     return x;
 }
 
-static void carrier_guesses(int E, int S, int N, const int *prn, const uint32_t *flags, const double *p0, const double *dstep,
-                            const gal_chan_state_t *state_in, double *pguess, long long *gss_w, double *gss_r)
-{
-    for (int s = 0; s < S; ++s) {
-        double run = 0.0;        // unreduced phase (fraction) after the epoch before, counted from the last restart
-        int kind = 0;            // last event before this epoch: 0 nothing yet, 1 defined (a wrap or a root), 2 chain broken (idle epoch)
-        long long ev_w = 0;
-        double ev_r = 0.0;
-        for (int e = 0; e < E; ++e) {
-            const size_t i = (size_t)e * S + s;
-            const bool on = prn[i] > 0;
-            const bool restart = (flags[i] & GAL_CH_RESTART) != 0;
-            const bool reset = on && (restart || e == 0);
-            const double start = restart ? p0[i] : state_in[s].carr_phase;
-            const double d = galnco::eff_step(dstep[i]);
-            double adv = on ? (double)N * d : 0.0;  // idle epochs leave the phase alone
-            adv = adv - std::trunc(adv);
-            const double mine = reset ? start : guess_reduce(run, d);
-            run = reset ? start + adv : run + adv;
-            run = run - std::trunc(run);  // (only the fraction matters; keeps the sums small)
-            if (on) {
-                const bool use_root = reset || kind != 1;  // (a chain without a root is rejected by gal_synth_plan)
-                pguess[i] = mine;
-                gss_w[i] = use_root ? (long long)e * N : ev_w;
-                gss_r[i] = use_root ? mine : ev_r;
-            }
-            // the last event up to the END of this epoch: a wrap inside it, else its root, else what came before
-            if (!on) {
-                kind = 2;
-            } else {
-                int om;
-                double rr;
-                if (galnco::ideal_last_wrap(mine, d, N, &om, &rr)) {
-                    kind = 1;
-                    ev_w = (long long)e * N + om;
-                    ev_r = rr;
-                } else if (reset) {
-                    kind = 1;
-                    ev_w = (long long)e * N;
-                    ev_r = mine;
-                }
-            }
+// One slot's chain of guesses, stepped epoch by epoch inside gal_synth_plan's single pass over the records (round 6; round 5: a
+// function of its own over the staged arrays, slot by slot -- a strided second pass, 0.35 of a 1199-epoch plan's 0.9 ms).
+struct GuessChain {
+    double run = 0.0;  // unreduced phase (fraction) after the epoch before, counted from the last restart
+    int kind = 0;      // last event before this epoch: 0 nothing yet, 1 defined (a wrap or a root), 2 chain broken (idle epoch)
+    long long ev_w = 0;
+    double ev_r = 0.0;
+    // epoch e of the slot: on = the record is active, restart = GAL_CH_RESTART, p0 its start phase (canonical), dstep = fl(f_carr delt),
+    // start_in = the carried phase of state_in; writes the record's three guesses
+    void step(const int e, const int N, const bool on, const bool restart, const double p0, const double dstep, const double start_in,
+              double *pguess, long long *gss_w, double *gss_r)
+    {
+        if (!on) {  // idle epochs leave the phase alone and break the chain of events (never read; the staging buffer is not cleared)
+            kind = 2;
+            *pguess = 0.0;
+            *gss_w = 0;
+            *gss_r = 0.0;
+            return;
+        }
+        const bool reset = restart || e == 0;
+        const double start = restart ? p0 : start_in;
+        const double d = galnco::eff_step(dstep);
+        double adv = (double)N * d;
+        adv = adv - std::trunc(adv);
+        const double mine = reset ? start : guess_reduce(run, d);
+        run = reset ? start + adv : run + adv;
+        run = run - std::trunc(run);  // (only the fraction matters; keeps the sums small)
+        const bool use_root = reset || kind != 1;  // (a chain without a root is rejected by gal_synth_plan)
+        *pguess = mine;
+        *gss_w = use_root ? (long long)e * N : ev_w;
+        *gss_r = use_root ? mine : ev_r;
+        // the last event up to the END of this epoch: a wrap inside it, else its root, else what came before
+        int om;
+        double rr;
+        if (galnco::ideal_last_wrap(mine, d, N, &om, &rr)) {
+            kind = 1;
+            ev_w = (long long)e * N + om;
+            ev_r = rr;
+        } else if (reset) {
+            kind = 1;
+            ev_w = (long long)e * N;
+            ev_r = mine;
         }
     }
-}
+};
 
 struct gal_synth {
     gal_synth_cfg_t cfg{};
@@ -225,6 +225,7 @@ struct gal_synth {
     hipEvent_t ev_verc = nullptr; // k_verify_code done (k_synth_g batches; second walker stream)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
+    hipEvent_t ev_upd = nullptr;  // the plan's upload and memsets are complete (what the walkers of its first execute wait for)
 
     // tables in HBM
     int *d_lut = nullptr;
@@ -270,6 +271,17 @@ struct gal_synth {
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
     // their smallest distance (rw_threshold_gap) -- reused only for the identical step
     std::vector<double> rw_s0, rw_g0, rw_e0;
+    // ... and, since round 6, for every step within rw_rad of it: the thresholds T_u = 1 - frac(u s) move by u |ds| <= 15 |ds| and no
+    // u s crosses an integer while 15 |ds| stays below the distance of every T_u to 0 and 1 (rw_e0), so inside
+    // |ds| < min((e0 - min) / 15, (g0 - min) / 14) both gates keep their verdict.  A Doppler moves the step of the reference geometry by
+    // 2e-6 of itself, the radius is 6e-4: one evaluation per slot instead of one per record (14 388 x 0.3 us of a 1199-epoch plan)
+    std::vector<double> rw_rad;
+    bool host_only = false;       // GAL_TEST_HOOKS, gal_hooks_plan_host_ms: gal_synth_plan's host work without a device (timing on CPU)
+    hipEvent_t ev_up0 = nullptr, ev_up1 = nullptr;  // around the upload of the last plan (timed: stats.ms_h2d)
+    bool upload_pending = false;  // gal_synth_plan_async: the upload is enqueued, nobody has waited for it yet
+    bool upload_timed = false;
+    bool upload_unordered = false;  // ... and no execute has put its walkers behind it yet
+    float ms_plan = 0.0f;         // host time of the last gal_synth_plan (validation, lists, staging; without the wait for the upload)
     double prev_wait_us = 0.0;  // how long the last gal_synth_finish waited for its batch (paces the next one's naps)
     int g_holdoff = 0;  // batches for which k_synth_g is not used although it could be: its last batch listed too many groups
 };
@@ -321,6 +333,17 @@ static void create_stage(const char *what)
     static thread_local auto tl = std::chrono::steady_clock::now();
     const auto t = std::chrono::steady_clock::now();
     fprintf(stderr, "[create] %-34s +%7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tl).count());
+    tl = t;
+}
+
+// GAL_PLAN_TIMING=1: where gal_synth_plan spends its host time (stderr)
+static void plan_stage(const char *what)
+{
+    static const bool on = getenv("GAL_PLAN_TIMING") != nullptr;
+    if (!on) return;
+    static thread_local auto tl = std::chrono::steady_clock::now();
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[plan] %-34s +%8.1f us\n", what, std::chrono::duration<double, std::micro>(t - tl).count());
     tl = t;
 }
 
@@ -388,7 +411,9 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
     create_stage("streams");
     for (auto &e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
-    if (hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreate(&h->ev_up0) != hipSuccess || hipEventCreate(&h->ev_up1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ver, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_verc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
@@ -492,6 +517,9 @@ int gal_synth_destroy(gal_synth_t *h)
     for (auto &e : h->ev)
         if (e) hipEventDestroy(e);
     if (h->ev_prep) hipEventDestroy(h->ev_prep);
+    if (h->ev_upd) hipEventDestroy(h->ev_upd);
+    if (h->ev_up0) hipEventDestroy(h->ev_up0);
+    if (h->ev_up1) hipEventDestroy(h->ev_up1);
     if (h->ev_aux) hipEventDestroy(h->ev_aux);
     if (h->ev_walk) hipEventDestroy(h->ev_walk);
     if (h->ev_ver) hipEventDestroy(h->ev_ver);
@@ -518,18 +546,76 @@ size_t gal_synth_output_bytes(const gal_synth_t *h)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
-                   const gal_chan_state_t *state_in)
+// wait: return when the batch is resident in HBM (gal_synth_plan); else as soon as its upload is enqueued (gal_synth_plan_async)
+static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs, const gal_chan_state_t *state_in, const bool wait)
 {
     if (h && h->in_flight)
         return fail(GAL_E_STATE, "gal_synth_plan while a batch is in flight: call gal_synth_finish first");
     if (!h || !params || n_epochs < 1) return fail(GAL_E_INVAL, "gal_synth_plan: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    const auto t_plan0 = std::chrono::steady_clock::now();
+    plan_stage("enter");
+    if (!h->host_only) HIP_TRY(hipSetDevice(h->device));
     const int E = n_epochs, S = h->cfg.n_slots, N = h->cfg.samples_per_epoch;
     h->planned = false;
     h->executed = false;
 
-    // ---- validate the batch and build the active-channel lists (host, O(E*S))
+    // ---- the upload region's fixed part (sizes that depend on E and S only), so that ONE pass over the caller's records can validate
+    // them, list the active ones and write the SoA copies, the NCO steps and the carrier guesses (round 5: three passes and a copy of
+    // the records); the variable part -- page_init table, active lists -- is laid out behind it once the pass knows their sizes
+    const size_t ES = (size_t)E * S;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    const size_t o_plan = take(sizeof(DevPlan));
+    const size_t o_state_in = take(sizeof(gal_chan_state_t) * S);
+    // SoA copies of the records and the NCO steps (no kernel in front of the walker chain)
+    const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
+    const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
+    const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4);
+    // first guesses of the speculative carrier walk (GuessChain: host, O(E * S); rounds 1-4: a kernel in front of the chain)
+    const size_t o_pguess = take(ES * 8), o_gssw = take(ES * 8), o_gssr = take(ES * 8);
+    // (the 176-byte records themselves stay on the host: beside the SoA copies the device only ever read page_init of the records
+    // that (re)allocate a channel -- a compact table and an index row; rounds 1-5 uploaded all of them, 3.4 of 6.2 MB)
+    const size_t o_initix = take(ES * 4);
+    const size_t o_pinit = off;  // [restart records][16]; then the active lists
+    {
+        const size_t max_groups = 3 * (size_t)((S + kKernelMaxChan - 1) / kKernelMaxChan) + 2;
+        const size_t need = o_pinit + align_up(ES * GAL_PAGE_WORDS * 4, 256) + max_groups * (align_up((size_t)E * kActRow, 256) + align_up((size_t)E * 4, 256)) + 4096;
+        // (the staging buffer is free again once the upload of the plan before has been read out of it)
+        if (h->upload_pending) {
+            HIP_TRY(hipEventSynchronize(h->ev_up1));
+            h->upload_pending = false;
+        }
+        if (need > h->h_up_bytes) {
+            if (h->host_only) free(h->h_up);
+            else if (h->h_up) hipHostFree(h->h_up);
+            h->h_up = nullptr;
+            h->h_up_bytes = 0;
+            const size_t cap = need + need / 4;
+            if (h->host_only) h->h_up = (char *)malloc(cap);
+            else if (hipHostMalloc((void **)&h->h_up, cap, hipHostMallocDefault) != hipSuccess) h->h_up = nullptr;
+            if (!h->h_up) return fail(GAL_E_NOMEM, "pinned staging allocation of %zu bytes failed", cap);
+            h->h_up_bytes = cap;
+        }
+    }
+    char *const up = h->h_up;
+    int *const u_prn = (int *)(up + o_prn), *const u_ib0 = (int *)(up + o_ib0), *const u_initix = (int *)(up + o_initix);
+    uint32_t *const u_flags = (uint32_t *)(up + o_flags), *const u_pnext = (uint32_t *)(up + o_pnext), *const u_pinit = (uint32_t *)(up + o_pinit);
+    double *const u_x0 = (double *)(up + o_x0), *const u_p0 = (double *)(up + o_p0);
+    double *const u_cstep = (double *)(up + o_cstep), *const u_dstep = (double *)(up + o_dstep);
+    double *const u_pguess = (double *)(up + o_pguess), *const u_gssr = (double *)(up + o_gssr);
+    long long *const u_gssw = (long long *)(up + o_gssw);
+    gal_chan_state_t *const u_state = (gal_chan_state_t *)(up + o_state_in);
+    if (state_in) memcpy(u_state, state_in, sizeof(gal_chan_state_t) * S);
+    else memset(u_state, 0, sizeof(gal_chan_state_t) * S);
+    for (int i = 0; i < S; ++i)
+        if (u_state[i].carr_phase == 0.0) u_state[i].carr_phase = 0.0;  // -0.0 canonicalised to +0.0 (see carr_step in nco_walk.h)
+    std::vector<GuessChain> guess(S);
+
+    // ---- validate the batch, build the active-channel lists, split the records (host, O(E*S), one pass)
     std::vector<uint8_t> act_all((size_t)E * S, 0);
     std::vector<int> nact_all(E, 0);
     int nact_max = 0;
@@ -546,14 +632,33 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     //             index boundary would have thousands of groups in a row listed for the exact replay
     std::vector<uint8_t> rec_mode((size_t)E * S, 0), rec_g((size_t)E * S, 0);
     double cs2_max = 0.0;  // largest code step of the batch, half chips per sample
-    if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); h->rw_e0.assign(S, 0.0); }
+    if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); h->rw_e0.assign(S, 0.0); h->rw_rad.assign(S, 0.0); }
+    int n_restart = 0;  // records with GAL_CH_RESTART: their page_init goes up in a compact table
     const double delt = 1.0 / h->cfg.sample_rate;
     const bool cboc = (h->cfg.flags & GAL_CFG_CBOC) != 0;
     const double min_gap = cboc ? kRwMinGapCboc : kRwMinGap;
     for (int e = 0; e < E; ++e) {
         int n = 0;
         for (int s = 0; s < S; ++s) {
-            const gal_chan_epoch_t &r = params[(size_t)e * S + s];
+            const size_t i = (size_t)e * S + s;
+            const gal_chan_epoch_t &r = params[i];
+            {
+                // the SoA copies (every record, idle ones too: the device reads prn of all).  src/galileo-sdr.cpp:528,531: the product
+                // is rounded to double before it is added -- one IEEE multiplication, the same bits on the host as in the reference's loop
+                const bool on = r.prn > 0, restart = on && (r.flags & GAL_CH_RESTART);
+                u_prn[i] = r.prn;
+                u_flags[i] = r.flags;
+                u_ib0[i] = r.ibit0;
+                u_x0[i] = r.code_phase0;
+                u_p0[i] = r.carr_phase0 == 0.0 ? 0.0 : r.carr_phase0;
+                u_cstep[i] = r.f_code * delt;
+                u_dstep[i] = r.f_carr * delt;
+                memcpy(u_pnext + i * GAL_PAGE_WORDS, r.page_next, sizeof(r.page_next));
+                u_initix[i] = restart ? n_restart : 0;
+                if (restart) memcpy(u_pinit + (size_t)n_restart * GAL_PAGE_WORDS, r.page_init, sizeof(r.page_init));
+                guess[s].step(e, N, on, (r.flags & GAL_CH_RESTART) != 0, u_p0[i], u_dstep[i], u_state[s].carr_phase, u_pguess + i, u_gssw + i,
+                              u_gssr + i);
+            }
             if (r.prn <= 0) {
                 cur_prn[s] = 0;
                 continue;
@@ -580,6 +685,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
                             s, r.prn, cur_prn[s]);
             }
             cur_prn[s] = r.prn;
+            n_restart += (r.flags & GAL_CH_RESTART) ? 1 : 0;
             const double ad = std::fabs(r.f_carr * delt);
             // (a step of exactly zero is fine: the phase of the whole epoch is the checkpoint's, k_synth_g's loader lanes know its
             // index exactly; a step below 2^-40 that is not zero creeps over index boundaries for thousands of groups on end)
@@ -588,16 +694,21 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
             cs2_max = std::max(cs2_max, cs2);
             const int mode = rw_mode_of(cs2);
             if (mode != 0) {
-                // (evaluated for every new step: the distance is not a continuous function of the step -- when some u s
-                // crosses an integer its threshold jumps from 0 to 1 -- so a cached value cannot be extrapolated)
-                if (cs2 != h->rw_s0[s]) {
+                // (the distance is not a continuous function of the step -- when some u s crosses an integer its threshold jumps from
+                // 0 to 1 -- so a cached value is extrapolated only inside the radius in which nothing can cross: see rw_rad)
+                if (!(std::fabs(cs2 - h->rw_s0[s]) <= h->rw_rad[s])) {
                     h->rw_s0[s] = cs2;
                     h->rw_g0[s] = rw_threshold_gap(cs2);
                     h->rw_e0[s] = rw_threshold_edge(cs2);
+                    double rad = std::min((h->rw_e0[s] - min_gap) / 15.0, (h->rw_g0[s] - min_gap) / 14.0);
                     if (cboc) {  // ... and the pattern of the BOC(6,1) half periods: 6 s per sample
-                        h->rw_e0[s] = std::min(h->rw_e0[s], rw_threshold_edge(6.0 * cs2));
-                        h->rw_g0[s] = std::min(h->rw_g0[s], rw_threshold_gap(6.0 * cs2));
+                        const double e6 = rw_threshold_edge(6.0 * cs2), g6 = rw_threshold_gap(6.0 * cs2);
+                        h->rw_e0[s] = std::min(h->rw_e0[s], e6);
+                        h->rw_g0[s] = std::min(h->rw_g0[s], g6);
+                        rad = std::min(rad, std::min((e6 - min_gap) / 90.0, (g6 - min_gap) / 84.0));
                     }
+                    // (both gates pass with room: the verdict holds for every step this close; else only for this very step)
+                    h->rw_rad[s] = rad > 0.0 ? 0.98 * rad : 0.0;
                 }
                 if (h->rw_g0[s] > min_gap) {
                     rec_mode[(size_t)e * S + s] = (uint8_t)mode;
@@ -610,6 +721,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         nact_all[e] = n;
         if (n > nact_max) nact_max = n;
     }
+    plan_stage("validation + lists + SoA + guesses");
     // the batch: k_synth's fast body needs ONE window form on every record (P.rw); k_synth_g takes the records that are fit for it
     // in the form most of them have, the others go to an accumulating exact-replay launch behind it (classic windows)
     int rw_mode = 0;
@@ -783,28 +895,13 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     h->n_exact_records = n_exact_records;
     const int n_groups = (int)grp_nch.size();  // (rows in the upload, not launches per execute)
 
-    // ---- arena layout
-    const size_t ES = (size_t)E * S;
+    plan_stage("gate, chunking, groups");
+    // ---- arena layout: the variable part of the upload region, then the device-only arrays
+    (void)take((size_t)std::max(n_restart, 1) * GAL_PAGE_WORDS * 4);  // o_pinit
     const size_t CP1 = (size_t)nchunks + 1;
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        size_t o = off;
-        off = align_up(off + bytes, 256);
-        return o;
-    };
-    // upload region (ONE host->device copy from the handle's pinned staging buffer): the device copy of the plan,
-    // the epoch records, the start state, the active lists
-    const size_t o_plan = take(sizeof(DevPlan));
-    const size_t o_params = take(ES * sizeof(gal_chan_epoch_t));
-    const size_t o_state_in = take(sizeof(gal_chan_state_t) * S);
     const size_t o_act = take((size_t)n_groups * E * kActRow), o_nact = take((size_t)n_groups * E * 4);
-    // SoA copies of the records and the NCO steps (written below, on the host: no kernel in front of the walker chain)
-    const size_t o_prn = take(ES * 4), o_flags = take(ES * 4), o_ib0 = take(ES * 4);
-    const size_t o_x0 = take(ES * 8), o_p0 = take(ES * 8), o_cstep = take(ES * 8), o_dstep = take(ES * 8);
-    const size_t o_pnext = take(ES * GAL_PAGE_WORDS * 4);
-    // first guesses of the speculative carrier walk (carrier_guesses below: host, O(E * S); rounds 1-4: a kernel in front of the chain)
-    const size_t o_pguess = take(ES * 8), o_gssw = take(ES * 8), o_gssr = take(ES * 8);
     const size_t up_bytes = off;
+    if (up_bytes > h->h_up_bytes) return fail(GAL_E_STATE, "gal_synth_plan: staging buffer bound exceeded (%zu > %zu)", up_bytes, h->h_up_bytes);
     // zeroed region (ONE memset): checkpoints, first guesses, leg records that are read before they are written
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmr = take(LEGS * S * 8);
@@ -823,7 +920,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     const size_t o_scanm = take(galk_scanm_bytes(S, (int)LEGS));  // the stitch's look-back records (synth_kernels.hip: ScanM)
 
     const size_t total = off;
-    if (total > h->arena_bytes) {
+    if (!h->host_only && total > h->arena_bytes) {
         if (h->arena) hipFree(h->arena);
         h->arena = nullptr;
         h->arena_bytes = 0;
@@ -832,14 +929,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
         h->arena_bytes = total;
         h->scanm_off = ~(size_t)0;  // (new memory: the stitch's records have to be cleared)
     }
-    if (up_bytes > h->h_up_bytes) {
-        if (h->h_up) hipHostFree(h->h_up);
-        h->h_up = nullptr;
-        h->h_up_bytes = 0;
-        if (hipHostMalloc((void **)&h->h_up, up_bytes + up_bytes / 2, hipHostMallocDefault) != hipSuccess)
-            return fail(GAL_E_NOMEM, "pinned staging allocation of %zu bytes failed", up_bytes);
-        h->h_up_bytes = up_bytes + up_bytes / 2;
-    }
+    plan_stage("layout + buffers");
     char *base = (char *)h->arena;
     h->d_plan = (DevPlan *)(base + o_plan);
     DevPlan &P = h->P;
@@ -867,7 +957,7 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     }
     P.delt = 1.0 / h->cfg.sample_rate;
     P.cs25 = kCS25;
-    P.params = (const gal_chan_epoch_t *)(base + o_params);
+    P.page_init = (const uint32_t *)(base + o_pinit); P.init_ix = (const int *)(base + o_initix);
     P.state_in = (const gal_chan_state_t *)(base + o_state_in);
     P.state_out = (gal_chan_state_t *)(base + o_state_out);
     P.prn = (int *)(base + o_prn); P.flags = (uint32_t *)(base + o_flags); P.ib0 = (int *)(base + o_ib0);
@@ -931,58 +1021,45 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
 #endif
 
     // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
-    // goes over in one copy; one memset clears what must start at zero; one sync at the end: after plan() the batch
-    // is resident in HBM.  (Round 1 issued 4 pageable copies and 11 memsets one by one: 0.2 ms per plan, a quarter of
-    // a per-epoch call.)  A start phase of -0.0 is canonicalised to +0.0 (see carr_step in nco_walk.h).
+    // goes over in one copy; one memset clears what must start at zero.  (Round 1 issued 4 pageable copies and 11 memsets one by
+    // one: 0.2 ms per plan, a quarter of a per-epoch call.)  Round 6 (the engine on FRESH parameters): ONE pass
+    // over the caller's records writes every array of the region -- no memset of the staging buffer, no copy of the 176-byte records
+    // (rounds 1-5: both, then a second pass for the SoA split) --, and the upload is not waited for unless the caller asked
+    // (gal_synth_plan: resident on return; gal_synth_plan_async: the walkers of the next execute wait for it on the device).
     {
-        char *up = h->h_up;
-        memset(up, 0, up_bytes);
+        if (n_restart == 0) memset(u_pinit, 0, GAL_PAGE_WORDS * 4);
         memcpy(up + o_plan, &P, sizeof(DevPlan));
-        gal_chan_epoch_t *rows = (gal_chan_epoch_t *)(up + o_params);
-        memcpy(rows, params, ES * sizeof(gal_chan_epoch_t));
-        for (size_t i = 0; i < ES; ++i)
-            if (rows[i].carr_phase0 == 0.0) rows[i].carr_phase0 = 0.0;
-        {
-            // src/galileo-sdr.cpp:528,531: the product is rounded to double before it is added -- one IEEE multiplication,
-            // the same bits on the host as in the reference's loop
-            int *u_prn = (int *)(up + o_prn), *u_ib0 = (int *)(up + o_ib0);
-            uint32_t *u_flags = (uint32_t *)(up + o_flags), *u_pnext = (uint32_t *)(up + o_pnext);
-            double *u_x0 = (double *)(up + o_x0), *u_p0 = (double *)(up + o_p0);
-            double *u_cstep = (double *)(up + o_cstep), *u_dstep = (double *)(up + o_dstep);
-            for (size_t i = 0; i < ES; ++i) {
-                const gal_chan_epoch_t &r = rows[i];
-                u_prn[i] = r.prn;
-                u_flags[i] = r.flags;
-                u_ib0[i] = r.ibit0;
-                u_x0[i] = r.code_phase0;
-                u_p0[i] = r.carr_phase0;
-                u_cstep[i] = r.f_code * P.delt;
-                u_dstep[i] = r.f_carr * P.delt;
-                memcpy(u_pnext + i * GAL_PAGE_WORDS, r.page_next, sizeof(r.page_next));
-            }
-        }
-        gal_chan_state_t *st = (gal_chan_state_t *)(up + o_state_in);
-        if (state_in) memcpy(st, state_in, sizeof(gal_chan_state_t) * S);
-        for (int i = 0; i < S; ++i)
-            if (st[i].carr_phase == 0.0) st[i].carr_phase = 0.0;
-        carrier_guesses(E, S, N, (const int *)(up + o_prn), (const uint32_t *)(up + o_flags), (const double *)(up + o_p0),
-                        (const double *)(up + o_dstep), st, (double *)(up + o_pguess), (long long *)(up + o_gssw), (double *)(up + o_gssr));
         memcpy(up + o_act, act_g.data(), act_g.size());
         memcpy(up + o_nact, nact_g.data(), nact_g.size() * sizeof(int));
-        hipStream_t st_up = handle_stream(h);
-        if (!st_up) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
-        HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
-        HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
-        HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
-        // (the stitch's tickets and look-back records: no word there may look like a tag this handle is still going to hand out.
-        // Its own records never do -- tags only grow -- so this is for a region that held something else: a new layout)
-        const size_t scanm_clear = galk_scanm_status_bytes(S, (int)LEGS);
-        if (h->scanm_off != o_scanm || h->scanm_clear != scanm_clear) {
-            HIP_TRY(hipMemsetAsync(base + o_scanm, 0, scanm_clear, st_up));
-            h->scanm_off = o_scanm;
-            h->scanm_clear = scanm_clear;
+        plan_stage("lists copied");
+        h->ms_plan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+        if (!h->host_only) {
+            hipStream_t st_up = handle_stream(h);
+            if (!st_up) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
+            HIP_TRY(hipEventRecord(h->ev_up0, st_up));
+            HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
+            HIP_TRY(hipEventRecord(h->ev_up1, st_up));  // (the staging buffer is free from here on; the copy is what ms_h2d times)
+            h->upload_timed = true;
+            HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
+            HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
+            // (the stitch's tickets and look-back records: no word there may look like a tag this handle is still going to hand out.
+            // Its own records never do -- tags only grow -- so this is for a region that held something else: a new layout)
+            const size_t scanm_clear = galk_scanm_status_bytes(S, (int)LEGS);
+            if (h->scanm_off != o_scanm || h->scanm_clear != scanm_clear) {
+                HIP_TRY(hipMemsetAsync(base + o_scanm, 0, scanm_clear, st_up));
+                h->scanm_off = o_scanm;
+                h->scanm_clear = scanm_clear;
+            }
+            // what the walker streams of the next execute wait for (they do not wait for the caller's stream otherwise)
+            HIP_TRY(hipEventRecord(h->ev_upd, st_up));
+            h->upload_pending = true;
+            h->upload_unordered = true;
+            if (wait) {
+                HIP_TRY(hipStreamSynchronize(st_up));
+                h->upload_pending = false;
+                h->upload_unordered = false;
+            }
         }
-        HIP_TRY(hipStreamSynchronize(st_up));
     }
     h->nact_max = nact_max;
     h->act_prefix.assign((size_t)E + 1, 0);
@@ -995,6 +1072,61 @@ int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epo
     h->planned = true;
     return GAL_OK;
 }
+
+int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs, const gal_chan_state_t *state_in)
+{
+    return plan_impl(h, params, n_epochs, state_in, true);
+}
+
+int gal_synth_plan_async(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs, const gal_chan_state_t *state_in)
+{
+    return plan_impl(h, params, n_epochs, state_in, false);
+}
+
+#ifdef GAL_TEST_HOOKS
+// The HOST side of gal_synth_plan on its own -- validation, lists, staging; no device, no upload -- `reps` times over the same
+// records: milliseconds per plan (tests/test_plan_host.py: the staged arrays against numpy; tools: what a fresh plan costs the host).
+static gal_synth *g_host_plan = nullptr;
+double gal_hooks_plan_host_ms(const gal_synth_cfg_t *cfg, const gal_chan_epoch_t *params, int32_t n_epochs, const gal_chan_state_t *state_in,
+                              int32_t reps)
+{
+    gal_synth *&g = g_host_plan;
+    if (g) {
+        free(g->h_up);
+        delete g;
+        g = nullptr;
+    }
+    if (!cfg || !params) return -1.0;
+    g = new gal_synth();
+    g->cfg = *cfg;
+    g->host_only = true;
+    init_tables();
+    double best = 1e30;
+    for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (plan_impl(g, params, n_epochs, state_in, false) != GAL_OK) return -1.0;
+        best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best;
+}
+// ... and where an array of that plan lies in its staging buffer (host_only: the arena's base is 0, the plan's device pointers are
+// offsets into the upload region); "family": (const void *)(1 + P.fam), "groups": 1 + the launches per execute
+const void *gal_hooks_plan_host_array(const char *name)
+{
+    const gal_synth *g = g_host_plan;
+    if (!g || !g->planned || !name) return nullptr;
+    const DevPlan &P = g->P;
+    const struct { const char *n; const void *p; } tab[] = {
+        {"prn", P.prn}, {"flags", P.flags}, {"ib0", P.ib0}, {"x0", P.x0}, {"p0", P.p0}, {"cstep", P.cstep}, {"dstep", P.dstep},
+        {"page_next", P.page_next}, {"pguess", P.pguess}, {"gss_w", P.gss_w}, {"gss_r", P.gss_r}, {"init_ix", P.init_ix},
+        {"page_init", P.page_init}, {"state_in", P.state_in}, {"act", g->d_act}, {"nact", g->d_nact}};
+    for (const auto &t : tab)
+        if (!strcmp(t.n, name)) return g->h_up + (size_t)(uintptr_t)t.p;
+    if (!strcmp(name, "family")) return (const void *)(uintptr_t)(1 + P.fam);
+    if (!strcmp(name, "groups")) return (const void *)(uintptr_t)(1 + g->n_groups);
+    return nullptr;
+}
+#endif
 
 // verify_here: k_synth_g does not verify the carrier checkpoints itself (k_synth's exact replay does, on its way); k_verify_carr
 // does, in front of it on the same stream (repair paths, handles without a walker stream) -- the first launch of a batch runs it
@@ -1090,6 +1222,10 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     // write is scratch of this handle, whose last reader (k_synth of the previous batch) has completed because
     // gal_synth_finish has been called (in_flight above).  k_synth itself stays in order on the caller's stream.
     hipStream_t ws = h->walk_stream ? h->walk_stream : st;
+    if (h->upload_unordered) {  // gal_synth_plan_async: the walkers read what the upload brings
+        if (ws != st) HIP_TRY(hipStreamWaitEvent(ws, h->ev_upd, 0));
+        h->upload_unordered = false;
+    }
     HIP_TRY(hipEventRecord(h->ev[0], ws));
     HIP_TRY(hipEventRecord(h->ev_prep, ws));
     // Speculative carrier walk, the chain k_synth waits for: first guesses (which also reset the batch's counters), then
@@ -1356,6 +1492,12 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
     h->stats.ms_synth = ms_synth;
     h->stats.ms_repair = h->stats.synth_runs == 1 ? ms_repair : 0.0f;
     h->stats.window_mode = h->P.rw;
+    h->stats.ms_plan = h->ms_plan;
+    if (h->upload_timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev_up0, h->ev_up1) == hipSuccess) h->stats.ms_h2d = ms;
+        else (void)hipGetLastError();
+    }
     h->legs_walked = h->first_pass_legs + ctr_end[CTR_WALKS];  // (a first pass walks every active leg: counted here, not on the device)
     h->legs_translated = ctr_end[CTR_SHIFTS];
     copy_stats(h, stats, stats_bytes);

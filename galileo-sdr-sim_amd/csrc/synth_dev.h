@@ -35,7 +35,9 @@ struct DevPlan {
     double delt;  // 1.0 / sample_rate, src/galileo-sdr.cpp:162
     uint32_t cs25;
 
-    const gal_chan_epoch_t *params;  // [E][S] as uploaded
+    const uint32_t *page_init;  // [restart records][16]: the page in force at a (re)allocation (gal_chan_epoch_t::page_init), compact --
+    const int *init_ix;         // [E][S] row of page_init for a record with GAL_CH_RESTART (round 6: the 176-byte records themselves are no
+                                // longer uploaded, this was all the device read from them beside the SoA copies: half of a plan's upload)
     const gal_chan_state_t *state_in;  // [S]
     gal_chan_state_t *state_out;       // [S]
 

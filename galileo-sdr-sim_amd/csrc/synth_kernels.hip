@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(GUESS_THREADS) void k_pages(DevPlan P)
         const int mine = restart ? 2 * e + 1 : before;
         if (in && prn > 0) {
             const uint32_t *src = mine < 0 ? P.state_in[s].page
-                                  : (mine & 1) ? P.params[(size_t)(mine >> 1) * P.S + s].page_init
+                                  : (mine & 1) ? P.page_init + (size_t)P.init_ix[(size_t)(mine >> 1) * P.S + s] * GAL_PAGE_WORDS
                                                : P.page_next + ((size_t)(mine >> 1) * P.S + s) * GAL_PAGE_WORDS;
             uint32_t *dst = P.page_cur + (size_t)idx * GAL_PAGE_WORDS;
             uint32_t w[GAL_PAGE_WORDS];
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(GUESS_THREADS) void k_pages(DevPlan P)
     // end-of-batch state for the next call
     if (t < GAL_PAGE_WORDS) {
         const uint32_t *src = carry < 0 ? P.state_in[s].page
-                              : (carry & 1) ? P.params[(size_t)(carry >> 1) * P.S + s].page_init
+                              : (carry & 1) ? P.page_init + (size_t)P.init_ix[(size_t)(carry >> 1) * P.S + s] * GAL_PAGE_WORDS
                                             : P.page_next + ((size_t)(carry >> 1) * P.S + s) * GAL_PAGE_WORDS;
         P.state_out[s].page[t] = src[t];
     }

@@ -78,6 +78,8 @@ class _Stats(ctypes.Structure):
         ("repaired_groups", ctypes.c_int32),
         ("ms_repair", ctypes.c_float),
         ("exact_records", ctypes.c_int32),
+        ("ms_plan", ctypes.c_float),
+        ("ms_h2d", ctypes.c_float),
     ]
 
 
@@ -96,6 +98,7 @@ EXPORTED_SYMBOLS = (
     "gal_synth_destroy",
     "gal_synth_set_stream",
     "gal_synth_plan",
+    "gal_synth_plan_async",
     "gal_synth_output_bytes",
     "gal_synth_walk_counts",
     "gal_synth_execute",
@@ -139,6 +142,7 @@ def load_library(hooks=False):
     lib.gal_synth_destroy.argtypes = [vp]
     lib.gal_synth_set_stream.argtypes = [vp, vp]
     lib.gal_synth_plan.argtypes = [vp, vp, i32, vp]
+    lib.gal_synth_plan_async.argtypes = [vp, vp, i32, vp]
     lib.gal_synth_walk_counts.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                           ctypes.POINTER(ctypes.c_int64)]
     lib.gal_synth_walk_counts.restype = ctypes.c_int
@@ -251,12 +255,12 @@ class SynthEngine:
         """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None."""
         self._check(self._lib.gal_synth_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
 
-    def plan(self, params, state_in=None):
+    def plan(self, params, state_in=None, wait=True):
+        """wait=False: gal_synth_plan_async -- returns once the upload is enqueued; the next execute's walkers wait for it."""
         p = self._params(params)
         s = self._state(state_in)
-        self._check(
-            self._lib.gal_synth_plan(self._h, p.ctypes.data, p.shape[0], s.ctypes.data if s is not None else None)
-        )
+        fn = self._lib.gal_synth_plan if wait else self._lib.gal_synth_plan_async
+        self._check(fn(self._h, p.ctypes.data, p.shape[0], s.ctypes.data if s is not None else None))
         self.n_epochs = p.shape[0]
 
     def output_bytes(self):

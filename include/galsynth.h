@@ -146,8 +146,10 @@ typedef struct gal_synth_stats {
                                    that stands still or is faster than 120 table entries per 16 samples, pattern thresholds that
                                    crowd, another window form than the batch's -- and took an accumulating exact-replay launch
                                    behind it (0 in every scenario of the reference's geometry seen so far)                      */
+    float   ms_plan;            /* 0.4: host time of the gal_synth_plan[_async] call behind this batch (validation, lists, staging)    */
+    float   ms_h2d;             /* 0.4: device time of its host->device copy (one copy of the SoA records out of pinned memory)        */
 } gal_synth_stats_t;
-/* The struct only ever GROWS AT ITS END (0.2: 40 bytes, walk_passes .. synth_runs; 0.3 / 0.4: 56).  gal_synth_finish and
+/* The struct only ever GROWS AT ITS END (0.2: 40 bytes, walk_passes .. synth_runs; 0.3: 56; 0.4: 64).  gal_synth_finish and
  * gal_synth_run_host are function-like macros over the _n entry points below, which copy min(the caller's sizeof, the library's)
  * bytes: a caller compiled against an older header never gets more than its own struct holds.  The plain SYMBOLS of those two
  * names stay exported for binaries built against 0.2 and fill exactly those 40 bytes.  Caveat of the macros: the two names cannot
@@ -177,6 +179,16 @@ int gal_synth_set_stream(gal_synth_t *h, void *hip_stream);
  */
 int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                    const gal_chan_state_t *state_in);
+
+/*
+ * The same, but returns as soon as the batch's upload is ENQUEUED on the handle's stream (its host work -- validation, lists, the
+ * SoA split into pinned memory -- is done; `params` and `state_in` may be reused).  The walkers of the next gal_synth_execute[_range]
+ * wait for the upload on the device.  This is how a caller with fresh parameters for every batch -- the reference computes them
+ * between epochs, src/galileo-sdr.cpp:450-479 -- keeps two handles busy: plan(k+1) on the idle handle while batch k runs on the
+ * other (bench.py: configs.fresh_plan).  Errors of the upload itself surface in gal_synth_execute / gal_synth_finish.
+ */
+int gal_synth_plan_async(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
+                         const gal_chan_state_t *state_in);
 
 /* Bytes of IQ the planned batch produces: n_epochs * samples_per_epoch * 4. */
 size_t gal_synth_output_bytes(const gal_synth_t *h);

@@ -37,6 +37,11 @@ def test_bench_json_line():
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert d["value"] > 1000.0  # far above the 260 Msamples/s target even on a 24-epoch batch
+    # the same step on fresh parameters: a new scenario planned every step, the last two outputs equal to the oracle's
+    fp = d["configs"]["fresh_plan"]
+    assert fp["output_equals_oracle"] is True and len(fp["oracle_checks"]) == 2 and fp["distinct_parameter_sets"] >= 3
+    assert fp["oracle_checks"][0]["seed"] != fp["oracle_checks"][1]["seed"]
+    assert fp["plan_ms"] > 0 and fp["h2d_ms"] > 0 and fp["ms_per_step"] > 0 and d["config"]["plan_ms"] == fp["plan_ms"]
 
 
 def test_report_exchange_falls_back_to_the_control_group():
