@@ -256,13 +256,17 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0
             "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3), "window_mode": stats[-1].get("window_mode")}
 
 
-def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms):
+def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms, local_rank):
     """the engine on FRESH parameters.  The headline re-executes one resident plan; no caller runs the same 120 s
     twice -- the reference computes its parameters between epochs (src/galileo-sdr.cpp:450-479).  Here every step gets a scenario of
-    its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish: gal_synth_plan_async on the handle that
-    has just been finished -- validation, lists, the SoA split into pinned memory, the upload enqueued -- while the other handle's
-    batch runs on the device.  The parameter sets are made before the timed region (producing them is the front-end's job, f1).
-    The outputs of the last two steps -- two different seeds -- are then compared with the oracle, every int16 of every epoch."""
+    its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish.  As in the headline TWO batches are in
+    flight on the device; a THIRD handle is the one being planned (gal_synth_plan_async: validation, lists, the SoA split into pinned
+    memory, the upload enqueued): the host finishes the oldest batch, executes the handle it planned a step ago, then plans the
+    handle it has just finished with the next scenario -- plan(k+1) runs under execute(k).  (`two_handles`: the same with the plan
+    between a handle's finish and its own next execute -- the walkers then start half a millisecond later, at the END of the other
+    batch's synthesis instead of at its start.)  The parameter sets are made before the timed region (producing them is the
+    front-end's job, row f1).  The outputs of the last two steps -- two different seeds -- are then compared with the oracle, every
+    int16 of every epoch."""
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
 
@@ -270,58 +274,137 @@ def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epo
     from oracle_binding import oracle_run
 
     depth = len(engines)
-    warm = 2 * depth
-    n_sets = min(steps + warm, 64)  # (beyond 64 steps the seeds repeat, 64 steps apart: 3.4 MB of records each)
+    warm = 2 * (depth + 1)
+    n_sets = min(steps + warm + 1, 64)  # (beyond 64 steps the seeds repeat, 64 steps apart: 3.4 MB of records each)
     sets = [pkg.shard.rank_workload(1000 + k, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate)
             for k in range(n_sets)]
-    which = [None] * depth
+    # the spare handle: same configuration, its own stream and output
+    spare = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank, test_hooks=HOOKS_BUILD)
+    spare_stream = torch.cuda.Stream()
+    spare.set_stream(spare_stream.cuda_stream)
+    eng3 = list(engines) + [spare]
+    out3 = list(outs) + [torch.empty_like(outs[0])]
+    which = [None] * len(eng3)
+    host = {"finish": 0.0, "plan": 0.0, "execute": 0.0}
 
-    def run(first, n):
+    def run_two(first, n):  # plan between a handle's finish and its own next execute
         stats = []
         inflight = [False] * depth
         for k in range(n):
             j = k % depth
             if inflight[j]:
-                stats.append(engines[j].finish()[1])
-            engines[j].plan(sets[(first + k) % n_sets], wait=False)
-            engines[j].execute(outs[j].data_ptr())
+                stats.append(eng3[j].finish()[1])
+            eng3[j].plan(sets[(first + k) % n_sets], wait=False)
+            eng3[j].execute(out3[j].data_ptr())
             which[j] = (first + k) % n_sets
             inflight[j] = True
         for k in range(n, n + depth):
             j = k % depth
             if inflight[j]:
-                stats.append(engines[j].finish()[1])
+                stats.append(eng3[j].finish()[1])
                 inflight[j] = False
         return stats
 
-    run(0, warm)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stats = run(warm, steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert all(x["chain_mismatch"] == 0 for x in stats)
+    state = {"next": 0}
+    stamps = []  # host time at which each step's finish returned
+
+    def run_three(n):
+        """n steps; on entry nothing is in flight."""
+        stats, fly = [], []
+        ready = None
+        idle = list(range(len(eng3)))
+
+        def plan(j):
+            k = state["next"] % n_sets
+            state["next"] += 1
+            eng3[j].plan(sets[k], wait=False)
+            which[j] = k
+
+        done = 0
+        started = 0
+        while done < n:
+            ta = time.perf_counter()
+            if len(fly) == depth or started == n:
+                j = fly.pop(0)
+                stats.append(eng3[j].finish()[1])
+                stamps.append(time.perf_counter())
+                idle.append(j)
+                done += 1
+            tb = time.perf_counter()
+            if started < n:
+                if ready is None:  # (pipeline fill: nothing was planned ahead)
+                    ready = idle.pop(0)
+                    plan(ready)
+                eng3[ready].execute(out3[ready].data_ptr())
+                fly.append(ready)
+                started += 1
+                ready = None
+            tc = time.perf_counter()
+            if started < n and idle:
+                ready = idle.pop(0)
+                plan(ready)  # under the two batches in flight
+            td = time.perf_counter()
+            host["finish"] += tb - ta
+            host["execute"] += tc - tb
+            host["plan"] += td - tc
+        return stats
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        host.update(finish=0.0, plan=0.0, execute=0.0)
+        t0 = time.perf_counter()
+        stats = fn()
+        torch.cuda.synchronize()
+        return stats, time.perf_counter() - t0, dict(host)
+
+    run_two(0, warm)
+    stats2, dt2, host2 = timed(lambda: run_two(warm, steps))
+    run_three(warm)
+    del stamps[:]
+    stats, dt, host3 = timed(lambda: run_three(steps))
+    # finish-to-finish intervals by the carrier passes the step needed: a scenario in which a channel's Doppler passes through zero has
+    # carrier cycles of millions of samples, the ideal-arithmetic guess of such a wrap's sample index can be off by one, and every leg
+    # anchored at it is walked again in a second (third) pass -- a longer walker chain than the other batch's synthesis hides
+    by_passes = {}
+    for k in range(1, len(stats)):
+        by_passes.setdefault(int(stats[k]["walk_passes"]), []).append((stamps[k] - stamps[k - 1]) * 1e3)
+    assert len(stats) == steps and all(x["chain_mismatch"] == 0 for x in stats + stats2)
     ms = dt / steps * 1e3
     value = epochs * n_samp * steps / dt / 1e6
+    last = sorted(range(len(eng3)), key=lambda j: which[j])[-2:]  # the two handles that ran the last two scenarios
 
     def check(j):
         ref_iq, _ = oracle_run(sets[which[j]], n_samp, rate)
         bad, piece = 0, 64 * n_samp * 2
         for a in range(0, ref_iq.size, piece):
-            bad += int(np.count_nonzero(outs[j][a:a + piece].cpu().numpy() != ref_iq[a:a + piece]))
+            bad += int(np.count_nonzero(out3[j][a:a + piece].cpu().numpy() != ref_iq[a:a + piece]))
         return {"seed": 1000 + which[j], "epochs_compared": epochs, "int16_different": bad,
                 "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}
 
-    with ThreadPoolExecutor(depth) as ex:  # ctypes releases the GIL inside the oracle
-        checks = list(ex.map(check, range(depth)))
+    with ThreadPoolExecutor(2) as ex:  # ctypes releases the GIL inside the oracle
+        checks = list(ex.map(check, last))
+    spare.close()
+    del out3[-1]
+
+    def summary(st, d, h):
+        return {"ms_per_step": round(d / steps * 1e3, 4), "value": round(epochs * n_samp * steps / d / 1e6, 1),
+                "plan_ms": round(sum(x["ms_plan"] for x in st) / len(st), 4), "h2d_ms": round(sum(x["ms_h2d"] for x in st) / len(st), 4),
+                "steps_with_a_repeated_synthesis": sum(x.get("synth_runs", 1) > 1 for x in st), "walk_passes_max": max(x["walk_passes"] for x in st),
+                "avg_kernel_ms": round(sum(x["ms_synth"] for x in st) / len(st), 4), "avg_walk_ms": round(sum(x["ms_walk"] for x in st) / len(st), 4),
+                "host_ms_per_step": {k: round(v / steps * 1e3, 4) for k, v in h.items()}}
+
+    s3 = summary(stats, dt, host3)
     return {"value": round(value, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "steps": steps, "distinct_parameter_sets": n_sets,
-            "plan_ms": round(sum(x["ms_plan"] for x in stats) / len(stats), 4),
-            "h2d_ms": round(sum(x["ms_h2d"] for x in stats) / len(stats), 4),
+            "handles": len(eng3), "in_flight": depth,
+            "plan_ms": s3["plan_ms"], "h2d_ms": s3["h2d_ms"],
             "ratio_to_resident_plan_step": round(ms / resident_ms, 4) if resident_ms else None,
-            "synth_runs_max": max(x.get("synth_runs", 1) for x in stats),
+            **{k: s3[k] for k in ("steps_with_a_repeated_synthesis", "walk_passes_max", "avg_kernel_ms", "avg_walk_ms", "host_ms_per_step")},
+            "ms_per_step_by_walk_passes": {str(k): {"steps": len(v), "ms": round(sum(v) / len(v), 4)} for k, v in sorted(by_passes.items())},
+            "two_handles": {**summary(stats2, dt2, host2), "ratio_to_resident_plan_step": round(dt2 / steps * 1e3 / resident_ms, 4) if resident_ms else None},
             "output_equals_oracle": all(c["int16_different"] == 0 for c in checks), "oracle_checks": checks,
-            "what": "step = gal_synth_plan_async (new scenario: host validation + SoA split + upload enqueued) + execute + finish, %d handles; "
-                    "plan_ms = host time of the plan call, h2d_ms = device time of its upload, both per step" % depth}
+            "what": "step = gal_synth_plan_async (a new scenario: host validation + SoA split + upload enqueued) + execute + finish; %d batches in "
+                    "flight, a third handle being planned meanwhile; plan_ms = host time of the plan call, h2d_ms = device time of its upload, "
+                    "both per step" % depth}
 
 
 def profiled_kernel_ms(kind="bench"):
@@ -793,8 +876,8 @@ def main():
                                      % (v["int16_different"], v["epochs_compared"]))
         if world == 1 and args.workload in ("syn12", "dyn") and not strong and args.signal == "boc11" and not args.no_fresh_plan:
             # the same step on FRESH parameters (plan + execute + finish, another scenario every step), on the headline's handles
-            line["configs"] = {"fresh_plan": leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, args.channels, args.epochs,
-                                                            args.steps, elapsed / args.steps * 1e3)}
+            line["configs"] = {"fresh_plan": leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, args.channels, args.epochs,
+                                                            args.steps, elapsed / args.steps * 1e3, local_rank)}
             line["config"]["plan_ms"] = line["configs"]["fresh_plan"]["plan_ms"]  # host time of one gal_synth_plan of this workload
             if not line["configs"]["fresh_plan"]["output_equals_oracle"]:
                 print(json.dumps(line))

@@ -142,11 +142,13 @@ constexpr int kVerifyRotation = 8;  // GAL_CFG_VERIFY_SAMPLED: k_verify_carr / k
                                     // all of them).  Same box, M-SYN12, pipelined step / one handle / k_synth_g beside it, carrier legs only
                                     // (profiles/r05f_verify_ab.log): none 0.974 / 1.230 / 0.842 ms; every leg 1.010 / 1.297 / 0.890; every 4th
                                     // 0.985 / 1.258 / 0.865; 8th 0.979 / 1.238 / 0.846; 16th 0.976 / 1.234 / 0.845
-constexpr int kDefaultPasses = 2;   // carrier passes enqueued up front: walk + stitch (which translates on the spot), one spare --
-                                    // no-op launches in front of k_synth when the chain is complete after one, as it normally
-                                    // is; a handle whose last batch got by with one enqueues one (gal_synth_finish iterates and
-                                    // repeats the synthesis if that turns out to be one too few, and the handle goes back to two)
-
+constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front for a NEW plan: walk + stitch (which translates on the spot), two spare --
+                                    // no-op launches in front of k_synth when the chain is complete after one, as it is for four fresh
+                                    // scenarios in five (tools/fresh_plan_probe.py, 32 seeds of M-SYN12: 26 x 1 pass, 4 x 2, 2 x 3; a batch that
+                                    // needs more than were enqueued pays gal_synth_finish's iteration and a SECOND synthesis, 3.4 ms
+                                    // instead of 1.9).  A plan that is executed again enqueues what its last execute needed (the chain
+                                    // is deterministic); rounds 3-5 kept that count per HANDLE, right for a bench that re-executes one
+                                    // resident plan and wrong for a caller with new parameters every batch
 }  // namespace
 
 // First guesses of the speculative carrier walk (synth_kernels.hip: k_walk_carr, first pass): per slot and epoch the IDEAL-arithmetic
@@ -1069,6 +1071,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     h->stats.n_active_max = nact_max;
     h->stats.chunk_samples = R;
     h->stats.chunks_per_epoch = nchunks;
+    h->enq_passes = kDefaultPasses;
     h->planned = true;
     return GAL_OK;
 }
@@ -1189,6 +1192,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     if (((uintptr_t)iq_dev) & 15) return fail(GAL_E_INVAL, "iq_dev must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
     // (the range is recorded only once every check has passed: finish()'s repair paths re-synthesise it)
+    if (h->executed && (first_epoch != h->range_e0 || n_epochs != h->range_ne)) h->enq_passes = std::max(h->enq_passes, kDefaultPasses);  // another range of the plan: its own pass count
     h->range_e0 = first_epoch;
     h->range_ne = n_epochs;
     // TRANSLATED carrier legs are covered by k_synth's replay check, which works by induction from the chain root
@@ -1485,7 +1489,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
     if (h->P.fam == 1 && (double)ctr_end[CTR_GFLAGS] > 0.004 * (double)h->range_ne * (double)((h->P.N + 15) / 16) + 4096.0)
         h->g_holdoff = 9;  // (this batch is exact like any other; the handle's next 8 go to the exact-replay kernel)
     h->stats.walk_passes = ctr_end[CTR_PASSES];
-    h->enq_passes = ctr_end[CTR_PASSES] > 1 ? kDefaultPasses : 1;
+    h->enq_passes = std::max(1, std::min(ctr_end[CTR_PASSES], 8));  // (of THIS plan, executed again; a new plan starts from kDefaultPasses)
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;

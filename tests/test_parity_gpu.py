@@ -405,8 +405,9 @@ def _dev_equal(a, b, piece=1 << 30):
 
 def test_m_syn24_full_size_properties(pkg):
     """BASELINE config 4 at FULL size (M-SYN24: 5999 epochs x 2 500 000 samples x 24 SVs @25 MS/s = 15.0 G samples,
-    60 GB of IQ per run, sample indices beyond 2^32 bytes and 2^32 int16 elements), where the oracle would need an hour:
-      * the first 2 and the LAST 2 epochs equal the oracle (the latter restarted on the carried state of a split run);
+    60 GB of IQ per run, sample indices beyond 2^32 bytes and 2^32 int16 elements):
+      * EVERY epoch equals the oracle (round 6: 64 slices on the host's cores, states chained by induction -- see
+        _every_epoch_against_the_oracle_in_slices); the first 2 and the LAST 2 epochs once more on their own;
       * chunk 0 (default) and 2048 give the same 60 GB;
       * a run split 3000 + 2999 with the carried state equals the single run, end state included;
       * the chain self-check is clean, the all-walked fallback is never needed, the synthesis ran once per batch."""
@@ -465,6 +466,59 @@ def test_m_syn24_full_size_properties(pkg):
     ref_tail, ref_st = oracle_run(tail, n, rate, st_c)
     assert np.array_equal(full[5997 * n * 2:].cpu().numpy(), ref_tail)
     assert np.array_equal(ref_st["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+    del a
+    torch.cuda.empty_cache()
+    _every_epoch_against_the_oracle_in_slices(pkg, p, full, n, rate, S, state_full)
+
+
+def _every_epoch_against_the_oracle_in_slices(pkg, p, full, n, rate, S, state_full, n_slices=64):
+    """EVERY epoch of config 4 (15 G samples x 24 channels, ~11 CPU-minutes of the oracle) against the oracle, on the
+    host's cores: the 5999 epochs are cut into 64 slices; slice k's start state is the END state gal_synth_execute_range returns for
+    slice k - 1 (the engine walks the prefix silently); every slice runs through oracle_run on its own thread (ctypes releases the
+    GIL), in pieces of 4 epochs with the oracle's own state carried, and must give (a) the samples of the single 60 GB run, int16 by
+    int16, and (b) an end state BITWISE equal to the start state the next slice was given.  (b) closes the induction: slice 0 starts
+    from the records' own restart, so every state the slices start from is the oracle's own -- the 64 threads together ARE the
+    sequential oracle run over all 5999 epochs (src/galileo-sdr.cpp:481-539)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    E = p.shape[0]
+    per = n * 2
+    bounds = [round(k * E / n_slices) for k in range(n_slices + 1)]
+    starts = [None]  # start state of every slice, from the engine
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n, n_slots=S, device=0) as eng:
+        eng.plan(p)
+        scratch = torch.empty(max(b - a for a, b in zip(bounds[:-1], bounds[1:])) * per, dtype=torch.int16, device="cuda")
+        for k in range(n_slices):
+            a, b = bounds[k], bounds[k + 1]
+            eng.execute(scratch.data_ptr(), a, b - a)
+            st, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0 and eng.walk_counts()[2] == 0
+            assert _dev_equal(full[a * per:b * per], scratch[: (b - a) * per]), k  # the range alone = its part of the single run
+            starts.append(st)
+        del scratch
+    act = state_full["prn"] > 0
+    assert np.array_equal(starts[-1]["carr_phase"][act].view(np.uint64), state_full["carr_phase"][act].view(np.uint64))
+
+    def run_slice(k):
+        a, b = bounds[k], bounds[k + 1]
+        st, bad = starts[k], 0
+        for c in range(a, b, 4):
+            d = min(c + 4, b)
+            ref, st = oracle_run(p[c:d], n, rate, state_in=st)
+            bad += int(np.count_nonzero(full[c * per:d * per].cpu().numpy() != ref))
+        nxt = starts[k + 1]
+        on = nxt["prn"] > 0
+        state_ok = (np.array_equal(st["carr_phase"][on].view(np.uint64), nxt["carr_phase"][on].view(np.uint64))
+                    and np.array_equal(st["page"][on], nxt["page"][on]) and np.array_equal(st["prn"], nxt["prn"]))
+        return bad, state_ok
+
+    with ThreadPoolExecutor(min(os.cpu_count() or 1, n_slices)) as ex:
+        res = list(ex.map(run_slice, range(n_slices)))
+    assert sum(r[0] for r in res) == 0, [k for k, r in enumerate(res) if r[0]]
+    assert all(r[1] for r in res), [k for k, r in enumerate(res) if not r[1]]
 
 
 def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
@@ -512,6 +566,63 @@ def test_replay_check_catches_a_wrong_translation(pkg, monkeypatch):
             iq2, _, _ = eng.run_host(p)
             assert eng.walk_counts()[2] == 0
         assert np.array_equal(iq2, ref_iq)
+
+
+def test_plan_async_with_fresh_parameters_every_batch(pkg):
+    """gal_synth_plan_async (round 6): the plan returns with its upload enqueued, the next execute's walkers wait for it on the device.
+    Two handles, a NEW scenario for every batch (other seed, other channel count, a state carried into some), planned on the handle
+    that has just been finished while the other one's batch runs: every batch bit-exact, end states included; the staging buffer is
+    reused only after its upload has left it (plans back to back on one handle)."""
+    import torch
+
+    n = 52000
+    sets = [pkg.workloads.make_synthetic(n_epochs=6 + (k % 5) * 7, n_chan=3 + (k * 5) % 12, n_slots=16, samples_per_epoch=n, seed=900 + k)
+            for k in range(9)]
+    refs = [oracle_run(q, n, 2.6e6) for q in sets]
+    engines = [pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.empty(max(q.shape[0] for q in sets) * n * 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+    for e, st in zip(engines, streams):
+        e.set_stream(st.cuda_stream)
+    pending = [None, None]
+
+    def reap(j):
+        k = pending[j]
+        st, stats = engines[j].finish()
+        ref_iq, ref_st = refs[k]
+        assert stats["chain_mismatch"] == 0 and stats["ms_plan"] > 0 and stats["ms_h2d"] > 0
+        assert np.array_equal(outs[j][: ref_iq.size].cpu().numpy(), ref_iq), k
+        act = ref_st["prn"] > 0
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+        pending[j] = None
+
+    for rep in range(3):
+        for k in range(len(sets)):
+            j = k % 2
+            if pending[j] is not None:
+                reap(j)
+            if k == 4:  # two plans back to back on one handle: the second must wait for the first upload to leave the staging buffer
+                engines[j].plan(sets[0], wait=False)
+            engines[j].plan(sets[k], wait=False)
+            engines[j].execute(outs[j].data_ptr())
+            pending[j] = k
+    for j in range(2):
+        if pending[j] is not None:
+            reap(j)
+    # a carried state through the asynchronous plan: a scenario split in two, the second half planned without waiting
+    q = sets[4]
+    half = q.shape[0] // 2
+    engines[0].plan(q[:half], wait=False)
+    engines[0].execute(outs[0].data_ptr())
+    st_a, _ = engines[0].finish()
+    a = outs[0][: half * n * 2].cpu().numpy()
+    engines[0].plan(q[half:], st_a, wait=False)
+    engines[0].execute(outs[0].data_ptr())
+    st_b, _ = engines[0].finish()
+    b = outs[0][: (q.shape[0] - half) * n * 2].cpu().numpy()
+    assert np.array_equal(np.concatenate([a, b]), refs[4][0])
+    for e in engines:
+        e.close()
 
 
 def test_ranges_of_one_plan_keep_the_stitch_records_apart(pkg, monkeypatch):
