@@ -30,15 +30,32 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 METRIC = "IQ Msamples/s (×real-time @2.6MS/s), 12-SV static E1B/C, 1/2/4/8 GPU"
 
 
-def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0, gpu_out=None):
+def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0, gpu_out=None, extra_checks=()):
     """Time the CPU restatement of the reference loop (oracle/galsyn_oracle.c, 1 thread, -O2
     -ffp-contract=off) on a bounded prefix of the same workload.  Checker code used ONLY as the
-    reported baseline, never in the product path.
+    reported baseline, never in the product path.  (The ONLY function of this file that touches anything under oracle/:
+    tests/test_abi.py::test_product_never_touches_the_oracle checks that.)
+    extra_checks: (label, params, device tensor) of other legs' outputs -- configs.fresh_plan's last two scenarios -- compared with the
+    oracle here, every int16 of every epoch, on threads of their own; the verdicts come back under "extra_checks".
     gpu_out: the int16 output of the timed steps (device tensor): the oracle's samples over the epochs it ran -- all of them
     on the GPU box's host -- are compared with it int16 by int16; the verdict goes into the line."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import oracle_run
 
+    extra_verdicts = []
+    if extra_checks:
+        from concurrent.futures import ThreadPoolExecutor as _Pool
+
+        def _check(item):
+            label, q, dev = item
+            ref, _ = oracle_run(q, n_samp, rate)
+            bad_, piece_ = 0, 64 * n_samp * 2
+            for a_ in range(0, ref.size, piece_):
+                bad_ += int(np.count_nonzero(dev[a_:a_ + piece_].cpu().numpy() != ref[a_:a_ + piece_]))
+            return {**label, "epochs_compared": int(q.shape[0]), "int16_different": bad_}
+
+        with _Pool(len(extra_checks)) as ex_:  # ctypes releases the GIL inside the oracle
+            extra_verdicts = list(ex_.map(_check, extra_checks))
     probe = 4
     t0 = time.perf_counter()
     oracle_run(params[:probe], n_samp, rate)
@@ -100,6 +117,7 @@ def cpu_baseline(pkg, params, n_samp, rate, target_seconds=12.0, gpu_out=None):
     except Exception as e:  # a baseline, not the product: report and go on
         ref_own = {"error": str(e)[:200]}
     return {
+        **({"extra_checks": extra_verdicts} if extra_verdicts else {}),
         **({"reference_loop": ref_own} if ref_own else {}),
         **({"output_vs_oracle": verdict} if verdict else {}),
         "value": round(plain, 3),
@@ -266,12 +284,8 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
     between a handle's finish and its own next execute -- the walkers then start half a millisecond later, at the END of the other
     batch's synthesis instead of at its start.)  The parameter sets are made before the timed region (producing them is the
     front-end's job, row f1).  The outputs of the last two steps -- two different seeds -- are then compared with the oracle, every
-    int16 of every epoch."""
+    int16 of every epoch (by cpu_baseline, which gets them as `pending`)."""
     import hashlib
-    from concurrent.futures import ThreadPoolExecutor
-
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_binding import oracle_run
 
     depth = len(engines)
     warm = 2 * (depth + 1)
@@ -283,7 +297,7 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
     spare_stream = torch.cuda.Stream()
     spare.set_stream(spare_stream.cuda_stream)
     eng3 = list(engines) + [spare]
-    out3 = list(outs) + [torch.empty_like(outs[0])]
+    out3 = [torch.empty_like(outs[0]) for _ in eng3]  # (its own outputs: the headline's stay as they are for the oracle's verdict on them)
     which = [None] * len(eng3)
     host = {"finish": 0.0, "plan": 0.0, "execute": 0.0}
 
@@ -373,18 +387,9 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
     value = epochs * n_samp * steps / dt / 1e6
     last = sorted(range(len(eng3)), key=lambda j: which[j])[-2:]  # the two handles that ran the last two scenarios
 
-    def check(j):
-        ref_iq, _ = oracle_run(sets[which[j]], n_samp, rate)
-        bad, piece = 0, 64 * n_samp * 2
-        for a in range(0, ref_iq.size, piece):
-            bad += int(np.count_nonzero(out3[j][a:a + piece].cpu().numpy() != ref_iq[a:a + piece]))
-        return {"seed": 1000 + which[j], "epochs_compared": epochs, "int16_different": bad,
-                "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}
-
-    with ThreadPoolExecutor(2) as ex:  # ctypes releases the GIL inside the oracle
-        checks = list(ex.map(check, last))
+    # what the oracle is to look at (cpu_baseline does, the only place of this file that touches the checker)
+    pending = [({"seed": 1000 + which[j], "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}, sets[which[j]], out3[j]) for j in last]
     spare.close()
-    del out3[-1]
 
     def summary(st, d, h):
         return {"ms_per_step": round(d / steps * 1e3, 4), "value": round(epochs * n_samp * steps / d / 1e6, 1),
@@ -401,10 +406,9 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
             **{k: s3[k] for k in ("steps_with_a_repeated_synthesis", "walk_passes_max", "avg_kernel_ms", "avg_walk_ms", "host_ms_per_step")},
             "ms_per_step_by_walk_passes": {str(k): {"steps": len(v), "ms": round(sum(v) / len(v), 4)} for k, v in sorted(by_passes.items())},
             "two_handles": {**summary(stats2, dt2, host2), "ratio_to_resident_plan_step": round(dt2 / steps * 1e3 / resident_ms, 4) if resident_ms else None},
-            "output_equals_oracle": all(c["int16_different"] == 0 for c in checks), "oracle_checks": checks,
             "what": "step = gal_synth_plan_async (a new scenario: host validation + SoA split + upload enqueued) + execute + finish; %d batches in "
                     "flight, a third handle being planned meanwhile; plan_ms = host time of the plan call, h2d_ms = device time of its upload, "
-                    "both per step" % depth}
+                    "both per step" % depth}, pending
 
 
 def profiled_kernel_ms(kind="bench"):
@@ -863,25 +867,29 @@ def main():
         if args.signal == "cboc":
             line["config"]["signal"] = "CBOC(6,1,1/11), opt-in mode (not the reference's signal, not the headline)"
             args.no_cpu_baseline = True
+        pending = []
+        if world == 1 and args.workload in ("syn12", "dyn") and not strong and args.signal == "boc11" and not args.no_fresh_plan:
+            # the same step on FRESH parameters (plan + execute + finish, another scenario every step), on the headline's handles
+            fp, pending = leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, args.channels, args.epochs,
+                                         args.steps, elapsed / args.steps * 1e3, local_rank)
+            line["configs"] = {"fresh_plan": fp}
+            line["config"]["plan_ms"] = fp["plan_ms"]  # host time of one gal_synth_plan of this workload
         if world == 1 and not args.no_cpu_baseline:
             # (in front of the extras, which free the timed outputs: the checker's samples are compared with them)
-            line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate, gpu_out=out)  # (world 1: the whole scenario)
+            line["cpu_baseline"] = cpu_baseline(pkg, params, n_samp, rate, gpu_out=out, extra_checks=pending)  # (world 1: the whole scenario)
             v = line["cpu_baseline"].pop("output_vs_oracle", None)
+            xc = line["cpu_baseline"].pop("extra_checks", None)
+            if xc is not None:
+                line["configs"]["fresh_plan"]["oracle_checks"] = xc
+                line["configs"]["fresh_plan"]["output_equals_oracle"] = all(c["int16_different"] == 0 for c in xc)
             if v is not None:
                 line["config"]["output_equals_oracle"] = v["equal"]
                 line["config"]["output_vs_oracle"] = v
-                if not v["equal"]:
-                    print(json.dumps(line))
-                    raise SystemExit("bench: the timed output differs from the oracle in %d int16 values of the first %d epochs"
-                                     % (v["int16_different"], v["epochs_compared"]))
-        if world == 1 and args.workload in ("syn12", "dyn") and not strong and args.signal == "boc11" and not args.no_fresh_plan:
-            # the same step on FRESH parameters (plan + execute + finish, another scenario every step), on the headline's handles
-            line["configs"] = {"fresh_plan": leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, args.channels, args.epochs,
-                                                            args.steps, elapsed / args.steps * 1e3, local_rank)}
-            line["config"]["plan_ms"] = line["configs"]["fresh_plan"]["plan_ms"]  # host time of one gal_synth_plan of this workload
-            if not line["configs"]["fresh_plan"]["output_equals_oracle"]:
+            if (v is not None and not v["equal"]) or (xc is not None and not line["configs"]["fresh_plan"]["output_equals_oracle"]):
                 print(json.dumps(line))
-                raise SystemExit("bench: a fresh-plan step's output differs from the oracle")
+                raise SystemExit("bench: an output differs from the oracle (headline: %s; fresh-plan scenarios: %s)" % (
+                    v and v["int16_different"], xc and [c["int16_different"] for c in xc]))
+        del pending
         if default_run and not args.no_extras:
             # untimed-for-headline legs (kernel-only above, kernel + D2H and the file sink here; configs 3/4)
             line["e2e"] = {"kernel_plus_d2h": leg_kernel_plus_d2h(torch, engines, outs, streams, e_first, e_count, n_samp)}

@@ -133,7 +133,8 @@ void init_tables()
 
 constexpr int kKernelMaxChan = 12;  // channels one k_synth launch replays per lane
 constexpr size_t kRunHostStagedBytes = 32u << 20;  // gal_synth_run_host: batches up to here land in pinned memory of the handle
-constexpr int kActRow = 16;         // bytes per epoch in a channel group's active-position list (synth_kernels.hip: GAL_ACT_ROW)
+constexpr int kActRow = 32;         // bytes per epoch in a channel group's active-position list (synth_common.h: GAL_ACT_ROW)
+constexpr int kGroupMaxChan = 24;   // channels one k_synth_g launch takes (BOC(1,1); its wide instances: synth_group.hip)
 constexpr int kGroupChunk = 1024;   // k_synth_g: samples per wave iteration = chunk length of its batches (synth_group.hip: SG_CHUNK)
 constexpr int kGroupSyms = 64;      // ... symbol masks per channel and epoch (SG_SYMS)
 constexpr int kGroupListMin = 1 << 16;  // ... least capacity of the undecided-group list (a 120 s batch lists ~2000 of 19.5 M groups);
@@ -840,11 +841,22 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     const int W = (nchunks + Lc - 1) / Lc;
     const size_t LEGS = (size_t)E * W;
 
-    // ---- channel groups (one synth launch each; later groups accumulate onto the first).  Per group: one 16-byte row per epoch
-    // (<= kKernelMaxChan positions, zero-padded; the kernels read it as one word quad).  k_synth_g batches: first the groups of the
+    // ---- channel groups (one synth launch each; later groups accumulate onto the first).  Per group: one 32-byte row per epoch
+    // (<= kKernelMaxChan positions for k_synth, which reads one word quad; <= kGroupMaxChan for k_synth_g's wide instances; zero-padded).  k_synth_g batches: first the groups of the
     // records that are fit for it (kind 1), then -- if the batch has any -- the groups of the others (kind 0: k_synth on classic
     // windows, accumulating), then ONCE MORE all records in groups of kind 0: what gal_synth_finish's list-overflow path launches.
     std::vector<int> grp_nch, grp_kind;
+    // k_synth_g launches of <= 12 channels, later ones accumulating (rounds 3-5), or its WIDE instances, up to 24 channels in one launch
+    // (round 6).  Measured, config 4's geometry, 24 SVs at 25 MS/s, kernel alone / pipelined step
+    // (tools/wide_ab2.sh, profiles/r06_wide_ab.log): 5999 epochs 82.6 / 99.0 ms wide against 84.2 / 100.5 narrow (+1.9 % / +1.5 %: what the
+    // read-modify-write of the second launch costs an issue-bound kernel); 600 epochs 10.1-10.3 / 10.5-10.7 ms wide against 9.14 / 10.3
+    // narrow -- one block of 16 waves per CU has nobody to hide its table build and its tail behind (two narrow launches overlap each
+    // other's).  So: wide where a block is a whole long epoch and the launch has many rounds of them, narrow otherwise.
+    bool narrow_g = !(E >= 2048 && (N + kGroupChunk - 1) / kGroupChunk >= 1024);
+#ifdef GAL_TEST_HOOKS
+    if (getenv("GAL_G_NARROW")) narrow_g = true;
+    if (getenv("GAL_G_WIDE")) narrow_g = false;
+#endif
     std::vector<uint8_t> act_g;
     std::vector<int> nact_g;
     auto add_groups = [&](const int kind, auto &&take_record) {
@@ -859,7 +871,8 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
             }
             most = std::max(most, cnt[e]);
         }
-        const int ng = most == 0 ? (kind == 1 || grp_nch.empty() ? 1 : 0) : (most + kKernelMaxChan - 1) / kKernelMaxChan;
+        const int max_ch = (kind == 1 && !cboc && !narrow_g) ? kGroupMaxChan : kKernelMaxChan;
+        const int ng = most == 0 ? (kind == 1 || grp_nch.empty() ? 1 : 0) : (most + max_ch - 1) / max_ch;
         const size_t g0 = grp_nch.size();
         grp_nch.resize(g0 + ng, 0);
         grp_kind.resize(g0 + ng, kind);

@@ -10,7 +10,7 @@
 
 #define SYN_BLOCK 256
 #define SYN_GROUP 16
-#define GAL_ACT_ROW 16  // bytes per epoch in the active-position lists (<= 12 entries used, zero-padded)
+#define GAL_ACT_ROW 32  // bytes per epoch in the active-position lists (<= 24 entries used, zero-padded; k_synth reads the first 16)
 #define STR_WORDS 512
 #define STR_PITCH 513  // LDS words per channel: one pad word (= word 0) so that "the next word" never wraps
 #define RW_BINS 128        // bins of the group-start fraction (k_synth<.., RW = 1>)

@@ -55,7 +55,10 @@ using namespace galdev;
 #define SG_LUT_N 1152   // entries per carrier table: 512 (mirrored phase still negative) + 511 + 129 (behind a wrap inside a group)
 #define SG_AMB 128u
 #define SG_BIAS (1049088.0 + 1.4901161193847656250e-08)  // 2^20 + 512 + 2^-26
-#define SG_MAXCH 12
+#define SG_MAXCH 12     // channel positions of the instances for up to 12 channels (two blocks of 512 threads per CU) ...
+#define SG_MAXCH_WIDE 24  // ... and of the wide instances, 13 .. 24 positions in ONE launch (round 6: 24 stream rows = 56 KB of 133 KB
+                          // of LDS, one block of 1024 threads per CU -- the same four waves per SIMD; rounds 3-5 ran such a batch as two
+                          // launches of <= 12, the second one adding onto the first's samples: a read-modify-write of the whole output)
 
 // What a group start needs of its channel and chunk, wave-uniform: written once per wave iteration by a LOADER lane (lane j < NCH
 // fetches channel j's checkpoint of the NEXT chunk while the wave works on the current one) into the wave's own LDS slots, read
@@ -296,7 +299,9 @@ __global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(SG_W
 void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restrict__ act_all, const int *__restrict__ nact_all,
                uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
 {
-    static_assert(NCH >= 1 && NCH <= SG_MAXCH, "1..12 channel positions per launch");
+    static_assert(NCH >= 1 && NCH <= SG_MAXCH_WIDE, "1..24 channel positions per launch");
+    static_assert(SIG == 0 || NCH <= SG_MAXCH, "the CBOC mode is built for up to 12 positions per launch");
+    constexpr int MC = NCH <= SG_MAXCH ? SG_MAXCH : SG_MAXCH_WIDE;  // positions the per-wave records are laid out for
     // CBOC keeps two bin tables per channel (chip holds, half-period parity) of 64 bins each, as in k_synth
     constexpr int BINS = SIG ? CB_BINS : RW_BINS, BPITCH = SIG ? CB_BIN_PITCH : RW_BIN_PITCH;
     __shared__ uint32_t s_str[NCH * SG_STR_PITCH];
@@ -309,10 +314,10 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     __shared__ uint32_t s_pat6[SIG ? NCH * 16 : 1];
     __shared__ float s_thr6[SIG ? NCH * 16 : 1];
     __shared__ uint32_t s_sym[NCH * SG_SYMS];
-    __shared__ __attribute__((aligned(16))) SgRec s_rec[(SG_THREADS / 64) * 2 * SG_MAXCH];  // [wave][buffer][position]
-    __shared__ double s_c511[SG_MAXCH];
-    __shared__ uint32_t s_lutd[SG_MAXCH];
-    __shared__ uint32_t s_sya[(SG_THREADS / 64) * 2 * SG_MAXCH];  // ... LDS byte address of the sign mask of the chunk's first symbol
+    __shared__ __attribute__((aligned(16))) SgRec s_rec[(SG_THREADS / 64) * 2 * MC];  // [wave][buffer][position]
+    __shared__ double s_c511[MC];
+    __shared__ uint32_t s_lutd[MC];
+    __shared__ uint32_t s_sya[(SG_THREADS / 64) * 2 * MC];  // ... LDS byte address of the sign mask of the chunk's first symbol
     __shared__ int s_rwbad;
 
     // (s_setprio 1 / 2 here, to keep the verification kernel that runs beside this one out of its issue slots: the kernel ALONE gets
@@ -392,10 +397,11 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     // ---- phase 0 (scalar): the epoch's active list, slot indices
     const int nact = __builtin_amdgcn_readfirstlane(nact_all[e]);
     const uint4 aw = *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW);
-    const uint32_t awv[4] = {aw.x, aw.y, aw.z, aw.w};
-    int ixs[SG_MAXCH];
+    const uint4 aw2 = MC > 16 ? *reinterpret_cast<const uint4 *>(act_all + (size_t)e * GAL_ACT_ROW + 16) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t awv[8] = {aw.x, aw.y, aw.z, aw.w, aw2.x, aw2.y, aw2.z, aw2.w};
+    int ixs[MC];
 #pragma unroll
-    for (int j = 0; j < SG_MAXCH; ++j) {
+    for (int j = 0; j < MC; ++j) {
         // slot index e * S + act[j] of position j (idle positions alias slot act[0]: loads stay in bounds, results unused)
         ixs[j] = __builtin_amdgcn_readfirstlane(e * G.S + (int)((awv[j >> 2] >> (8 * (j & 3))) & 0xffu));
     }
@@ -450,7 +456,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     };
     // the DDA's step 511 |d| and the table base (plain / conjugate table minus the exponent field of [2^20, 2^21) << 2, so that
     // the address is ONE shift-add of t's high word) of every position
-    if (tid < SG_MAXCH) {
+    if (tid < MC) {
         int ix = 0;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) ix = tid == q ? ixs[q] : ix;
@@ -606,8 +612,8 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     // epoch start (idle: an all-zero row)
     const uint32_t *const syml = s_sym + jl * SG_SYMS - (onl ? p_ib0[ixl] : 0);
     const uint32_t mtab0 = (uint32_t)(uintptr_t)(sg_lds_u32)s_mtab;
-    SgRec *const recw = s_rec + wv * 2 * SG_MAXCH;
-    uint32_t *const syaw = s_sya + wv * 2 * SG_MAXCH;
+    SgRec *const recw = s_rec + wv * 2 * MC;
+    uint32_t *const syaw = s_sya + wv * 2 * MC;
     const int cstep_w = nw;
     int c = __builtin_amdgcn_readfirstlane(c_begin + wv);
     // checkpoint of chunk cc: x (pre-check code phase, chips), p (carrier phase), ibit | flipped << 16
@@ -646,11 +652,11 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         r.s = sl;
         r.dabs = dabsl;
         if (lane < NCH) {
-            recw[buf * SG_MAXCH + lane] = r;
+            recw[buf * MC + lane] = r;
             // (idle positions: steps zero, stream row zero, sign pairs zero -- no contribution)
             const uint32_t ks = onl ? (lib & 0xffffu) + 500u * (lib >> 16) + (pend ? 1u : 0u) : 0u;
             const uint32_t pair = syml[ks] * 4u + syml[ks + 1];
-            syaw[buf * SG_MAXCH + lane] = mtab0 + pair * (SG_MPOS * 4u);
+            syaw[buf * MC + lane] = mtab0 + pair * (SG_MPOS * 4u);
         }
     };
     if (c < c_end) fetch(c);
@@ -681,8 +687,8 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         }
         uint32_t amb = ~0u;
         uint64_t undec = rw_off ? ~0ull : 0ull;
-        const SgRec *rec = recw + buf * SG_MAXCH;
-        const uint32_t *sya = syaw + buf * SG_MAXCH;
+        const SgRec *rec = recw + buf * MC;
+        const uint32_t *sya = syaw + buf * MC;
         // balanced parts: 5, 6, 7, 9, 10, 11 positions are cut 3+2, 3+3, 4+3, 3+3+3, 4+3+3, 4+4+3
 #define SG_PART(J0, CNT) sg_part<J0, CNT, MODE, SIG, BINS, BPITCH>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat, s_bin6, s_pat6, nact); \
                          __builtin_amdgcn_sched_barrier(0);
@@ -705,7 +711,32 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         else if constexpr (NCH == 9) { SG_PART(0, 3) SG_PART(3, 3) SG_PART(6, 3) }
         else if constexpr (NCH == 10) { SG_PART(0, 4) SG_PART(4, 3) SG_PART(7, 3) }
         else if constexpr (NCH == 11) { SG_PART(0, 4) SG_PART(4, 4) SG_PART(8, 3) }
-        else { SG_PART(0, 4) SG_PART(4, 4) SG_PART(8, 4) }
+        else if constexpr (NCH == 12) { SG_PART(0, 4) SG_PART(4, 4) SG_PART(8, 4) }
+        else {
+            // the wide instances: parts of four, the last 5 / 6 / 7 positions cut 3+2 / 3+3 / 4+3 as above
+            SG_PART(0, 4) SG_PART(4, 4)
+            constexpr int R8 = NCH - 8;  // 5 .. 16 positions left
+            if constexpr (R8 == 5) { SG_PART(8, 3) SG_PART(11, 2) }
+            else if constexpr (R8 == 6) { SG_PART(8, 3) SG_PART(11, 3) }
+            else if constexpr (R8 == 7) { SG_PART(8, 4) SG_PART(12, 3) }
+            else {
+                SG_PART(8, 4)
+                constexpr int R12 = NCH - 12;  // 4 .. 12
+                if constexpr (R12 <= 4) { SG_PART(12, R12) }
+                else if constexpr (R12 == 5) { SG_PART(12, 3) SG_PART(15, 2) }
+                else if constexpr (R12 == 6) { SG_PART(12, 3) SG_PART(15, 3) }
+                else if constexpr (R12 == 7) { SG_PART(12, 4) SG_PART(16, 3) }
+                else {
+                    SG_PART(12, 4)
+                    constexpr int R16 = NCH - 16;  // 4 .. 8
+                    if constexpr (R16 <= 4) { SG_PART(16, R16) }
+                    else if constexpr (R16 == 5) { SG_PART(16, 3) SG_PART(19, 2) }
+                    else if constexpr (R16 == 6) { SG_PART(16, 3) SG_PART(19, 3) }
+                    else if constexpr (R16 == 7) { SG_PART(16, 4) SG_PART(20, 3) }
+                    else { SG_PART(16, 4) SG_PART(20, 4) }
+                }
+            }
+        }
 #undef SG_PART
         if (vec_ok) {
 #pragma unroll
@@ -872,10 +903,11 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
 // the partly empty third round costs less than it looks (the blocks left run on emptier SIMDs, faster), a block that crosses an
 // epoch boundary pays a barrier and a second set of tables, and 512 blocks that live as long as the launch leave the next batch's
 // walker kernels no SIMD to start on.  (GAL_TEST_HOOKS: GAL_G_ROUNDS / GAL_G_BPE select those layouts.)
-static int sg_grid(const DevPlan *P, int ne)
+static int sg_grid(const DevPlan *P, int ne, int nch = 0)
 {
     const long long U = (long long)ne * P->nchunks;
-    const int slots = P->gslots > 0 ? P->gslots : 512;
+    const bool wide = nch > SG_MAXCH;  // one block of 16 waves per CU instead of two of 8
+    const int slots = (P->gslots > 0 ? P->gslots : 512) / (wide ? 2 : 1);
 #ifdef SG_BALANCED_RANGES
     if (P->grounds > 0 && U >= (long long)slots * P->grounds * 32) return slots * P->grounds;  // balanced persistent ranges
 #else
@@ -883,7 +915,7 @@ static int sg_grid(const DevPlan *P, int ne)
 #endif
     int bpe = P->gbpe > 0 ? P->gbpe : 1;                                                        // (hooks: fixed blocks per epoch)
     if (P->gbpe <= 0) {
-        const int nw = 8;  // waves per block
+        const int nw = wide ? 16 : 8;  // waves per block
         bpe = (slots + ne - 1) / ne;
         const int most = P->nchunks / (2 * nw) > 1 ? P->nchunks / (2 * nw) : 1;
         bpe = bpe > most ? most : bpe;
@@ -892,9 +924,9 @@ static int sg_grid(const DevPlan *P, int ne)
     return ne * bpe;
 }
 // ... and the blocks per epoch of that grid (0: a hooks layout that ignores the epoch boundaries)
-static int sg_bpe(const DevPlan *P, int ne)
+static int sg_bpe(const DevPlan *P, int ne, int nch = 0)
 {
-    return sg_grid(P, ne) / ne;
+    return sg_grid(P, ne, nch) / ne;
 }
 
 template <bool ACC, int MODE, int SIG>
@@ -904,27 +936,39 @@ static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const 
 #ifdef SG_FORCE_THREADS  // A/B builds (tools/build_variant_g.sh)
     const dim3 grid(sg_grid(P, ne)), block(SG_FORCE_THREADS);
 #else
-    const dim3 grid(sg_grid(P, ne)), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
+    const dim3 grid(sg_grid(P, ne, nch)), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
 #endif
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
     {  // one instance per channel count, in the CBOC mode too (round 4: 4 / 8 / 12 positions, a 9-SV batch paid for 12)
         switch (nch) {
             GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
             GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
-        default: return -1;
+        default:
+            if constexpr (SIG == 0) {  // the wide instances (BOC(1,1) only): 13 .. 24 positions, blocks of 1024 threads, one per CU
+                const dim3 wblock(SG_THREADS);
+#define GAL_WCASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, wblock, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
+                switch (nch) {
+                    GAL_WCASE(13) GAL_WCASE(14) GAL_WCASE(15) GAL_WCASE(16) GAL_WCASE(17) GAL_WCASE(18)
+                    GAL_WCASE(19) GAL_WCASE(20) GAL_WCASE(21) GAL_WCASE(22) GAL_WCASE(23) GAL_WCASE(24)
+                default: return -1;
+                }
+#undef GAL_WCASE
+                break;
+            }
+            return -1;
         }
     }
 #undef GAL_CASE
     return 0;
 }
 
-static SynGeom sg_geom(const DevPlan *P, int e0, int ne)
+static SynGeom sg_geom(const DevPlan *P, int e0, int ne, int nch = 0)
 {
     SynGeom G;
     G.e0 = e0;
     G.ne = ne;
     G.S = P->S; G.N = P->N; G.R = P->R; G.nchunks = P->nchunks; G.CP1 = P->CP1;
-    G.blocks_per_epoch = ne > 0 ? sg_bpe(P, ne) : 1;
+    G.blocks_per_epoch = ne > 0 ? sg_bpe(P, ne, nch) : 1;
     G.cls = 1;
     G.per = P->nchunks;
     return G;
@@ -937,7 +981,7 @@ extern "C" int galk_launch_synth_g(const DevPlan *P, const DevPlan *Pd, int nch,
                                    uint32_t *iq, int e0, int ne, hipStream_t st)
 {
     if (P->R != SG_CHUNK) return -2;
-    const SynGeom G = sg_geom(P, e0, ne);
+    const SynGeom G = sg_geom(P, e0, ne, nch);
     if (P->signal == 1) {
 #define SG_MODE_CASE(m) case m: return accumulate ? launch_synth_g_t<true, m, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G) \
                                                   : launch_synth_g_t<false, m, 1>(P, Pd, nch, act, nact, iq, e0, ne, st, G);

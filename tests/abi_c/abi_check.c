@@ -15,7 +15,9 @@ _Static_assert(offsetof(gal_chan_epoch_t, page_init) == 112, "page_init");
 _Static_assert(offsetof(gal_chan_state_t, page) == 8, "state.page");
 _Static_assert(offsetof(gal_synth_cfg_t, flags) == 28, "cfg.flags");
 _Static_assert(sizeof(gal_synth_cfg_t) == 40, "gal_synth_cfg_t");
-_Static_assert(sizeof(gal_synth_stats_t) == 56, "gal_synth_stats_t");
+_Static_assert(sizeof(gal_synth_stats_t) == 64, "gal_synth_stats_t");
+_Static_assert(offsetof(gal_synth_stats_t, ms_plan) == 56, "stats.ms_plan");
+_Static_assert(offsetof(gal_synth_stats_t, ms_h2d) == 60, "stats.ms_h2d");
 _Static_assert(offsetof(gal_synth_stats_t, ms_walk) == 24, "stats.ms_walk");
 _Static_assert(offsetof(gal_synth_stats_t, window_mode) == 32, "stats.window_mode");
 _Static_assert(offsetof(gal_synth_stats_t, synth_runs) == 36, "stats.synth_runs");

@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -284,6 +285,52 @@ def test_cli_config5_all_eight_sites(pkg, tmp_path):
         (md5, n), n_sv = want[k]
         assert n == 2999 * 260000 * 4 and got[k] == (md5, n), (k, sites[k], n_sv)
         assert (rec["sites"][k]["md5"], rec["sites"][k]["bytes"]) == got[k], (k, sites[k], "reference program")
+
+
+@pytest.mark.gpu
+def test_cli_config3_300s_motion_file(pkg, tmp_path):
+    """BASELINE config 3 LITERALLY: a 300 s, 10 Hz circular user-motion file through the command line --
+    `-u tests/golden/circle_track_300s.csv -t 2022/02/20,12:00:00 -d 300`, the reference's hook for it: src/galileo-sdr.cpp:443-448 --
+    2999 epochs, 3 118 960 000 bytes.  The file's md5 must be the md5 of the oracle's stream on the front-end's rows, every byte.
+    THE REFERENCE HAS NO -u (getopt accepts it, no case handles it: src/main.cpp:216; galileo_task always runs its static mode,
+    src/galileo-sdr.cpp:221-222): tests/golden/ref_task_config3.json (tools/ref_task_config3.py, made where the reference can be built)
+    records as a CHECKED fact that the reference program's file for this very command line is the static default-site scenario, byte
+    for byte -- so there are no reference bytes for a moving receiver; what the reference does have, the per-epoch position hook
+    (xyz[iumd], :443-448) fed over UDP, is what test_live_position.py and test_cli_udp_position_updates pin."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rec = json.load(open(os.path.join(g, "ref_task_config3.json")))
+    track = os.path.join(g, "circle_track_300s.csv")
+    assert hashlib.md5(open(track, "rb").read()).hexdigest() == rec["track_md5"]
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    out = os.path.join(shm, "galtest_%d_config3.ishort" % os.getpid())
+
+    def front_end_oracle():
+        rows = pkg.Scenario(NAV, start=rec["start"], duration_s=rec["duration_s"], iono_enable=True, motion_file=track).all()
+        static = pkg.Scenario(NAV, llh=(-6, 51, 100), start=rec["start"], duration_s=rec["duration_s"], iono_enable=True).all()
+        return _oracle_md5(pkg, rows), rows, static
+
+    with ThreadPoolExecutor(1) as ex:  # (the oracle's 20 s of CPU beside the CLI run)
+        want = ex.submit(front_end_oracle)
+        try:
+            r = subprocess.run([CLI, "-e", NAV, "-u", track, "-t", rec["start"], "-d", str(rec["duration_s"]), "-P", "0", "-o", out],
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr
+            h, n = hashlib.md5(), 0
+            with open(out, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(blk)
+                    n += len(blk)
+        finally:
+            if os.path.exists(out):
+                os.remove(out)
+        (md5, m), rows, static = want.result()
+    assert rows.shape == (2999, 16) and n == m == 2999 * 260000 * 4
+    act = rows["prn"][0] > 0
+    assert np.abs((rows["f_carr"] - static["f_carr"])[:, act]).max() > 10.0  # the receiver does move
+    assert h.hexdigest() == md5 == rec["front_end_oracle_md5"], "CLI file vs front-end -> oracle (here, and where the fixture was made)"
+    assert rec["reference_ignores_u"] is True and rec["reference_md5_with_u"] == rec["static_default_site_md5"] != md5
 
 
 @pytest.mark.gpu

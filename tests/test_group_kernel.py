@@ -187,6 +187,50 @@ def test_group_kernel_ragged_sizes_and_more_channels_than_one_launch(pkg):
         assert stats["kernel_family"] == 1 and stats["repaired_groups"] >= 1
 
 
+@pytest.mark.parametrize("n_chan", [13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
+def test_group_kernel_wide_instances_every_channel_count(pkg, n_chan, monkeypatch):
+    """Round 6: 13 .. 24 channels in ONE launch of k_synth_g (its wide instances: 24 stream rows in LDS, blocks of 1024 threads, one per
+    CU; rounds 3-5: two launches of <= 12, the second adding onto the first's samples).  Every channel count, with page flips, pending
+    wraps, a channel that stands still and listed groups; the same bits as the oracle and as the narrow launches (hooks: GAL_G_NARROW)."""
+    monkeypatch.setenv("GAL_G_WIDE", "1")  # (the plan takes them on its own for long high-rate batches only: 2048+ epochs of 1024+ chunks)
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=n_chan, n_slots=24, samples_per_epoch=52000, seed=600 + n_chan)
+    p["ibit0"][:, 0] = 498
+    p["code_phase0"][1, 1] = 4095.5  # a wrap pending at the first sample of an epoch
+    p["f_carr"][:, 2] = 0.0
+    p["carr_phase0"][0, 3:7] = 0.0   # listed groups for certain
+    iq, _, stats = _compare(pkg, p, 52000, test_hooks=True)
+    assert stats["kernel_family"] == 1 and stats["n_active_max"] == n_chan and stats["repaired_groups"] >= 1 and stats["exact_records"] == 0
+
+
+def test_group_kernel_wide_instances_other_rates_ranges_and_more_than_24(pkg, monkeypatch):
+    """The wide instances in every window form (25 MS/s: BASELINE config 4's; 8 and 4 MS/s), epochs of no whole chunk, ranges of one
+    plan, channels leaving mid-batch, and 25 .. 40 channels (a wide launch + an accumulating one); narrow launches give the same."""
+    import torch
+
+    for rate, n_samp, n_chan, n_slots, want in ((25e6, 100000, 24, 24, 2), (8e6, 60007, 19, 24, 3), (4e6, 40000, 16, 16, 4),
+                                                (2.6e6, 26001, 40, 40, 1), (2.6e6, 30000, 25, 32, 1)):
+        p = pkg.workloads.make_synthetic(n_epochs=5, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate, seed=int(rate / 1e5) + n_chan)
+        p[3:, 5] = np.zeros((), dtype=p.dtype)  # a channel that leaves
+        monkeypatch.setenv("GAL_G_WIDE", "1")
+        iq, _, stats = _compare(pkg, p, n_samp, rate=rate, test_hooks=True)
+        monkeypatch.delenv("GAL_G_WIDE")
+        assert stats["kernel_family"] == 1 and stats["window_mode"] == want, (rate, stats)
+        iq2, _, stats2 = _compare(pkg, p, n_samp, rate=rate)  # the product's choice for a batch this short: narrow launches
+        assert stats2["kernel_family"] == 1 and np.array_equal(iq, iq2)
+    n = 52000
+    p = pkg.workloads.make_synthetic(n_epochs=9, n_chan=21, n_slots=24, samples_per_epoch=n, seed=4242)
+    ref_iq, _ = oracle_run(p, n, 2.6e6)
+    monkeypatch.setenv("GAL_G_WIDE", "1")
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=24, device=0, test_hooks=True) as eng:
+        eng.plan(p)
+        for e0, ne in ((0, 9), (3, 4), (8, 1), (0, 2)):
+            out = torch.empty(ne * n * 2, dtype=torch.int16, device="cuda")
+            eng.execute(out.data_ptr(), e0, ne)
+            _, stats = eng.finish()
+            assert stats["chain_mismatch"] == 0
+            assert np.array_equal(out.cpu().numpy(), ref_iq[e0 * n * 2:(e0 + ne) * n * 2]), (e0, ne)
+
+
 def test_group_kernel_page_flip_code_wraps_and_state_carry(pkg):
     """Symbol counters at the page flip (:497-506), a code wrap pending at the first sample of an epoch (:491), windows across
     the wrap, and a run split in two calls with the state carried by the caller."""

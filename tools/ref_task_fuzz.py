@@ -16,6 +16,7 @@ starts at the edges of the file's span (profiles/archive/r04_ref_task_fuzz_odd.l
 runs in parallel); --replay F --cli: on the GPU box, take the reference's answers from F instead of running the reference there (it binds
 a fixed UDP port, so it runs one instance at a time without network namespaces): only the product runs (r04_ref_task_replay_cli.log).
 --toc: long cases (65-130 s) that run across a 10-minute mark of the records' TOC grid and several 30 s refreshes (r04_ref_task_fuzz_toc.log).
+--long300: 200-300 s cases, up to the reference's cap of 3000 epochs: ten re-allocations per run (tests/golden/ref_task_recorded_300s.json).
 
 A case our front-end REJECTS (start outside the file's span) is counted as skipped and what the reference did with it is printed (it
 exits with status 1 there too).  A case in which a satellite in view runs out of ephemeris is the reference's undefined behaviour
@@ -69,6 +70,10 @@ def make_case(rng, c, odd=False):
         k["start"] = "2022/02/20,%02d:%d9:%02d" % (hh, int(rng.integers(0, 6)), int(rng.integers(0, 50)))
         k["dur"] = float(rng.choice([65, 80, 100, 130]))
         k["tovr"] = False
+    if "--long300" in sys.argv[1:]:  # --long300 (round 6): 200-300 s, up to the reference's cap (USER_MOTION_SIZE 3000 epochs,
+        # include/constants.h:14): six to ten 30 s re-allocations and several TOC marks per run
+        k["dur"] = float(rng.choice([200, 240, 270, 300]))
+        k["tovr"] = bool(rng.random() < 0.1)
     return k
 
 
