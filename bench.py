@@ -432,6 +432,22 @@ def profiled_kernel_ms(kind="bench"):
     return None, None
 
 
+def kernel_source_sha256():
+    """Hash of the sources the profiled kernel is built from (tools/pmc_synth.sh writes the same into its summary)."""
+    import hashlib
+
+    src = os.path.join(ROOT, "galileo-sdr-sim_amd", "csrc")
+    return hashlib.sha256(b"".join(open(os.path.join(src, f), "rb").read() for f in ("synth_group.hip", "synth_common.h", "synth_dev.h"))).hexdigest()
+
+
+def profile_is_current(path):
+    """A committed profile summary belongs to THIS build of the kernel (a stale file would go unnoticed)."""
+    try:
+        return json.load(open(path)).get("kernel_source_sha256") == kernel_source_sha256()
+    except Exception:
+        return False
+
+
 def measured_traffic():
     """HBM bytes per k_synth launch from the newest committed PMC summary (rocprofv3 --pmc WRITE_SIZE /
     FETCH_SIZE passes, profiles/*_pmc_k_synth.json); None if there is none.  bench.py cannot run
@@ -443,6 +459,8 @@ def measured_traffic():
         return None, None
     try:
         d = json.load(open(files[-1]))
+        if not profile_is_current(files[-1]):  # measured on another build of the kernel: not this line's traffic
+            return None, os.path.basename(files[-1]) + " (STALE: the kernel's sources have changed since it was measured)"
         return int(d["hbm_bytes_per_launch"]), os.path.basename(files[-1])
     except Exception:
         return None, None
@@ -457,7 +475,7 @@ def measured_issue(kernel_ms, channel_samples):
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_k_synth_all.json")))
-    if not files or not kernel_ms:
+    if not files or not kernel_ms or not profile_is_current(files[-1]):
         return None
     try:
         d = json.load(open(files[-1]))
@@ -534,7 +552,7 @@ def main():
                     "of a world this way, one after the other, to read shard.epoch_range's balance off ONE GPU without the ranks "
                     "disturbing each other; says nothing about scaling")
     ap.add_argument("--site", type=int, default=None, help="--workload locations: the site (0..7 of shard.LOCATIONS) this process "
-                    "simulates instead of site `rank` -- the per-site 1-GPU baseline of config 5 (tools/config5_sites.sh)")
+                    "simulates instead of site `rank` -- the per-site 1-GPU baseline of config 5 (config5_sites.sh (a tool of rounds 3-5: git history))")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3, 4],
                     help="engine handles in flight: 2 = software pipeline, the NCO walk of step k+1 (latency "
                     "bound, on the handle's high-priority stream) runs beside the synthesis kernel of step k (issue "
@@ -577,7 +595,7 @@ def main():
     def init_process_group():
         # GAL_BENCH_FORCE_DIST=1: initialise the process group for world size 1 as well (launched by torch.distributed.run
         # --nproc-per-node 1): the RCCL calls of the N > 1 path -- init, barrier, the two all_reduce of the report,
-        # all_gather_object -- on a box with one GPU (tools/rccl_one_rank.sh)
+        # all_gather_object -- on a box with one GPU (rccl_one_rank.sh (a tool of rounds 3-5: git history))
         if not (world > 1 or os.environ.get("GAL_BENCH_FORCE_DIST")):
             return None
         import torch.distributed as dist_mod

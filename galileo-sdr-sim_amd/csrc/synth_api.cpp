@@ -744,7 +744,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     const long long n_grec = g_count[g_mode];
     // epochs in which some record is not fit for k_synth_g in that form: the accumulating exact-replay launch behind it costs about
     // what a whole k_synth_g launch costs PER EPOCH IT HAS WORK IN (its blocks run the slow body at this chunk length: measured 1.0 ms
-    // over 1199 epochs for one channel, tools/gated_cost.py), the other epochs' blocks leave at once
+    // over 1199 epochs for one channel, gated_cost.py (a tool of rounds 3-5: git history)), the other epochs' blocks leave at once
     int n_exact_epochs = 0;
     for (int e = 0; e < E; ++e) {
         bool any = false;
@@ -795,7 +795,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
             // (0.29 ms for a one-epoch call).  Shorter chunks spread the same samples over more lanes: aim at one block
             // per CU (65536 chunks in the batch), not below ~416 samples per chunk: every chunk is also a checkpoint the
             // walkers have to store, and for a one-epoch call 208-sample chunks lose more in the walker chain (0.33 ms)
-            // than they win in the kernel (0.08 ms) -- 416: 0.26 + 0.13 ms (tools/per_epoch_breakdown.py).
+            // than they win in the kernel (0.08 ms) -- 416: 0.26 + 0.13 ms (per_epoch_breakdown.py (a tool of rounds 3-5: git history)).
             double centre = 1024.0;
             int lo = 768, hi = 1536;
             const double want = (double)E * (double)N / 65536.0;

@@ -328,7 +328,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     // on epoch boundaries: a block's run lies inside ONE epoch -- one set of tables (sg_grid).  The balanced layouts that ignore the
     // epoch boundaries (a range that crosses one is worked off segment by segment, the block rebuilds its per-epoch tables in
     // between; consecutive ranges on the same XCD), measured slower, are in variant builds only: -DSG_BALANCED_RANGES,
-    // tools/build_variant_g.sh
+    // build_variant_g.sh (a tool of rounds 3-5: git history)
 #ifdef SG_BALANCED_RANGES
     const int nb = (int)gridDim.x;
     const int xb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -933,7 +933,7 @@ template <bool ACC, int MODE, int SIG>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
-#ifdef SG_FORCE_THREADS  // A/B builds (tools/build_variant_g.sh)
+#ifdef SG_FORCE_THREADS  // A/B builds (build_variant_g.sh (a tool of rounds 3-5: git history))
     const dim3 grid(sg_grid(P, ne)), block(SG_FORCE_THREADS);
 #else
     const dim3 grid(sg_grid(P, ne, nch)), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);

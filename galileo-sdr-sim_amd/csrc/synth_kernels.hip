@@ -40,7 +40,7 @@ using namespace galdev;
 // k_synth take minutes in one go: TU 0 holds the walker kernels and the launch dispatcher -- the only part the
 // GAL_TEST_HOOKS build changes --, TU 1..4 one family of k_synth each, (SIG, RW) = (0, 0), (0, 1), (0, 2), (1, 0), shared
 // by both libraries; TU 5 the family (0, 3), TU 6 (1, 1): CBOC on resampled windows.  Without GAL_TU everything lands in one
-// translation unit (tools/kasm.sh).  (The default kernel of the reference geometry, k_synth_g, is synth_group.hip.)
+// translation unit (kasm.sh (a tool of rounds 3-5: git history)).  (The default kernel of the reference geometry, k_synth_g, is synth_group.hip.)
 #if !defined(GAL_TU)
 #define GAL_TU_WALK 1
 #define GAL_TU_SYNTH 1
@@ -701,7 +701,7 @@ __device__ __forceinline__ void stitch_publish(const DevPlan &P, const int t, co
 
 // ---- The stitch, in 256-thread blocks, one leg per thread.  (Rounds 2-4 had a 1024-thread block per slot for batches up to 512
 // epochs, k_carr_scan: 16 waves and 72 KB of LDS on ONE CU -- beside a running synthesis kernel that means waiting for a CU to
-// drain completely -- with 10-step scans through LDS; tools/stitch_ab.sh, one handle: 0.189 -> 0.179 ms per step at 1 epoch,
+// drain completely -- with 10-step scans through LDS; stitch_ab.sh (a tool of rounds 3-5: git history), one handle: 0.189 -> 0.179 ms per step at 1 epoch,
 // 0.451 -> 0.419 at 128, 0.880 -> 0.731 at 512 with this kernel in its place.)  The legs of a slot are spread over B blocks (one
 // wave per SIMD: such a block starts as soon as ONE synthesis block retires); a batch of up to 32 epochs has B = 1 and none of what
 // follows.  What a single block would do with two block-wide scans is done with block-local scans plus a LOOK-BACK over the blocks
@@ -714,7 +714,7 @@ __device__ __forceinline__ void stitch_publish(const DevPlan &P, const int t, co
 // legs a block takes is decided by a TICKET it draws when it starts, not by blockIdx: a block only ever waits for blocks with a
 // lower ticket, and those are running or done -- no assumption about the order in which the hardware dispatches a grid over the
 // XCDs.  Records carry the launch's tag, so nothing has to be cleared between passes.
-//   What it costs (tools/scanm_stamps.py, 1199 epochs: 38 blocks per slot, 608 in all, 80 us alone on the device): the two
+//   What it costs (scanm_stamps.py (a tool of rounds 3-5: git history), 1199 epochs: 38 blocks per slot, 608 in all, 80 us alone on the device): the two
 // exchanges are 15-25 us each -- an agent-scope store and the loads that wait for it cross the fabric between the XCDs, 2-3 us
 // a trip and four trips per exchange -- which is what the two kernel boundaries cost before; the checkpoint shifts at the end
 // are 17 us (80 MB read + written); the scans themselves 1 + 4 us.
@@ -768,7 +768,7 @@ __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, _
 #define SCANM_ORDER() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 #ifdef GAL_TEST_HOOKS
-// where k_scanm's time goes (tools/scanm_stamps.py): the 100 MHz wall clock at nine points of every block
+// where k_scanm's time goes (scanm_stamps.py (a tool of rounds 3-5: git history)): the 100 MHz wall clock at nine points of every block
 #define SCANM_NSTAMP 9
 #define SCANM_STAMP_BLOCKS 4096
 __device__ unsigned long long g_scanm_stamp[SCANM_STAMP_BLOCKS * SCANM_NSTAMP];  // [block][stage]: plain stores, nothing shared
@@ -794,7 +794,7 @@ __device__ __forceinline__ void scanm_wait(const uint32_t *st, size_t o, uint32_
 
 // Wave-wide inclusive scans of the two chains by lane shuffles (six steps, no LDS round trips, no barriers), and the step across
 // a block's four waves: each wave's total through LDS, one barrier.  This kernel runs once per batch, every CU executes its code
-// cold, and tools/scanm_stamps.py shows the time going where code is executed for the FIRST time, whatever it does (a block
+// cold, and scanm_stamps.py (a tool of rounds 3-5: git history) shows the time going where code is executed for the FIRST time, whatever it does (a block
 // with nothing in front of it spends 11 us in a look-back of two barriers when the look-back's code is new, 1 us when the
 // block-local scan has already fetched it): what counts is the number of instruction-cache lines on the path.  So the scans
 // are real functions (__noinline__), called for the block's own legs and again for the aggregates of the blocks in front, and

@@ -125,7 +125,7 @@ def load_library(hooks=False):
         return _libs[hooks]
     path = HOOKS_LIB_PATH if hooks else LIB_PATH
     if not hooks and os.environ.get("GAL_SYNTH_LIB"):
-        # A/B experiments only (tools/build_variant.sh): another build of the same sources, e.g. other register targets;
+        # A/B experiments only (build_variant.sh (a tool of rounds 3-5: git history)): another build of the same sources, e.g. other register targets;
         # bench.py marks such a line "variant_lib" -- never a result
         path = os.path.abspath(os.environ["GAL_SYNTH_LIB"])
     if not os.path.exists(path):

@@ -87,3 +87,18 @@ def test_report_exchange_falls_back_to_the_control_group():
     assert out[4] == "gloo (RCCL failed: on another rank)" and calls[n:] == [(None, "cuda"), ("ctl", "cpu")]
     with pytest.raises(RuntimeError):  # no control group to fall back to: the error is the caller's
         bench.exchange_report(dist, "nccl", {"group": None}, report_rccl_down)
+
+
+def test_committed_pmc_summaries_belong_to_this_build_of_the_kernel():
+    """bench.py quotes HBM traffic and instruction counts of k_synth_g from the newest committed PMC summaries (it cannot run
+    rocprofv3 on itself): they must have been measured on the kernel sources in this tree (tools/pmc_synth.sh records their hash) --
+    VERDICT r5 item 8: a stale file would otherwise go unnoticed when the kernel changes."""
+    import glob
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for pat in ("*_pmc_k_synth.json", "*_pmc_k_synth_all.json"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        assert files, pat
+        assert bench.profile_is_current(files[-1]), "%s was measured on other kernel sources: run tools/profile_round.sh and commit its summaries" % os.path.basename(files[-1])

@@ -7,7 +7,7 @@ tag=${1:-rXX}
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1"
+cmd="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-fresh-plan --pipeline 1"
 i=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
             "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_LDS_IDX_ACTIVE" "WRITE_SIZE" "FETCH_SIZE"; do
@@ -36,6 +36,10 @@ if "WRITE_SIZE" in res and "FETCH_SIZE" in res:
     # 32-byte requests against a 64-byte unit there, i.e. the raw KiB figure is doubled (MI355X_MICROARCH guide,
     # HBM / rocprofv3 section) -- same correction as in profiles/archive/r01_pmc_write_fetch.md
     res["hbm_bytes_per_launch"] = int((res["WRITE_SIZE"] + 2.0 * res["FETCH_SIZE"]) * 1024)
+# which build of the kernel this was measured on: bench.py and tests/test_bench_contract.py compare it with the tree's
+import hashlib
+res["kernel_source_sha256"] = hashlib.sha256(b"".join(open("galileo-sdr-sim_amd/csrc/" + f, "rb").read() for f in (
+    "synth_group.hip", "synth_common.h", "synth_dev.h"))).hexdigest()
 json.dump(res, open("gpurun_out/%s_pmc_k_synth_all.json" % tag, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
 PY
