@@ -297,23 +297,31 @@ def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
     assert stats["walk_passes"] == 1 and stats["synth_runs"] == 1
 
 
-def test_enqueued_carrier_passes_adapt_to_the_previous_batch(pkg):
-    """A handle enqueues two carrier passes for its first batch and one after a batch that got by with one.  If a batch
-    then needs the second after all, gal_synth_finish() iterates and repeats the synthesis (synth_runs == 2), and the next
-    batch gets two again."""
+def test_enqueued_carrier_passes_belong_to_the_plan(pkg):
+    """A NEW plan gets three carrier passes enqueued up front (round 6: four fresh scenarios in five need one, the others two or three,
+    and a batch that needs more than were enqueued pays a second synthesis); a plan that is EXECUTED AGAIN enqueues what its last
+    execute needed.  Rounds 3-5 kept the count per handle ("one after a batch that got by with one"): right for a bench that
+    re-executes one resident plan, wrong for a caller with new parameters every batch -- the hard batch behind an easy one was
+    repaired by a second synthesis (synth_runs == 2).  Now it never is."""
+    import torch
+
     hard, n_samp, rate, chunk = _hard_batch(pkg)
     easy = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=8, samples_per_epoch=n_samp, seed=12)
     ref_hard, _ = oracle_run(hard, n_samp, rate)
     ref_easy, _ = oracle_run(easy, n_samp, rate)
     with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=8, device=0, chunk_samples=chunk) as eng:
-        iq, _, stats = eng.run_host(hard)  # first batch: two passes enqueued
-        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 2 and stats["synth_runs"] == 1
-        iq, _, stats = eng.run_host(easy)  # still two enqueued (the batch before needed them); needs one
-        assert np.array_equal(iq, ref_easy) and stats["walk_passes"] == 1 and stats["synth_runs"] == 1
-        iq, _, stats = eng.run_host(hard)  # one enqueued, two needed: repaired
-        assert np.array_equal(iq, ref_hard) and stats["walk_passes"] >= 2 and stats["synth_runs"] == 2
-        iq, _, stats = eng.run_host(hard)  # two enqueued again
-        assert np.array_equal(iq, ref_hard) and stats["synth_runs"] == 1
+        for params, ref, need_two in ((hard, ref_hard, True), (easy, ref_easy, False), (hard, ref_hard, True), (hard, ref_hard, True)):
+            iq, _, stats = eng.run_host(params)
+            assert np.array_equal(iq, ref) and stats["synth_runs"] == 1
+            assert (stats["walk_passes"] >= 2) if need_two else (stats["walk_passes"] == 1)
+        # the same plan executed again and again: same passes, one synthesis each
+        eng.plan(hard)
+        out = torch.empty(ref_hard.size, dtype=torch.int16, device="cuda")
+        for _ in range(3):
+            eng.execute(out.data_ptr())
+            _, stats = eng.finish()
+            assert stats["walk_passes"] >= 2 and stats["synth_runs"] == 1
+            assert np.array_equal(out.cpu().numpy(), ref_hard)
 
 
 def test_translated_legs_on_moving_receiver(pkg):
