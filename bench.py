@@ -279,8 +279,9 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
     twice -- the reference computes its parameters between epochs (src/galileo-sdr.cpp:450-479).  Here every step gets a scenario of
     its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish.  As in the headline TWO batches are in
     flight on the device; a THIRD handle is the one being planned (gal_synth_plan_async: validation, lists, the SoA split into pinned
-    memory, the upload enqueued): the host finishes the oldest batch, executes the handle it planned a step ago, then plans the
-    handle it has just finished with the next scenario -- plan(k+1) runs under execute(k).  (`two_handles`: the same with the plan
+    memory, the upload enqueued) ON A SECOND HOST THREAD: the main thread finishes the oldest batch, executes the handle that was
+    planned a step ago, and hands the handle it has just finished to the planner with the next scenario -- plan(k+1) runs under
+    execute(k), on the host as on the device.  (`two_handles`: the same with the plan
     between a handle's finish and its own next execute -- the walkers then start half a millisecond later, at the END of the other
     batch's synthesis instead of at its start.)  The parameter sets are made before the timed region (producing them is the
     front-end's job, row f1).  The outputs of the last two steps -- two different seeds -- are then compared with the oracle, every
@@ -322,6 +323,12 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
     state = {"next": 0}
     stamps = []  # host time at which each step's finish returned
 
+    from concurrent.futures import ThreadPoolExecutor
+
+    planner = ThreadPoolExecutor(1)  # the caller's planning thread (the reference's parameter producers run between its epochs; a caller
+                                     # of this engine runs them -- and the plan call -- beside the batches in flight; ctypes releases the GIL)
+    planned = {}
+
     def run_three(n):
         """n steps; on entry nothing is in flight."""
         stats, fly = [], []
@@ -331,8 +338,8 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
         def plan(j):
             k = state["next"] % n_sets
             state["next"] += 1
-            eng3[j].plan(sets[k], wait=False)
             which[j] = k
+            planned[j] = planner.submit(eng3[j].plan, sets[k], None, False)
 
         done = 0
         started = 0
@@ -349,6 +356,7 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
                 if ready is None:  # (pipeline fill: nothing was planned ahead)
                     ready = idle.pop(0)
                     plan(ready)
+                planned.pop(ready).result()  # (planned a step ago, beside the batches in flight: done long since)
                 eng3[ready].execute(out3[ready].data_ptr())
                 fly.append(ready)
                 started += 1
@@ -389,6 +397,7 @@ def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_
 
     # what the oracle is to look at (cpu_baseline does, the only place of this file that touches the checker)
     pending = [({"seed": 1000 + which[j], "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}, sets[which[j]], out3[j]) for j in last]
+    planner.shutdown()
     spare.close()
 
     def summary(st, d, h):

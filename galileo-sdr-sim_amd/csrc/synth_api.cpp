@@ -158,18 +158,11 @@ constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front for a NE
 // only through bitwise equality with the verified chain; the guesses decide how many legs can be accepted by translation.  Epoch-major
 // [E][S] (a prefix computation: a range execute's cut plan sees the same values).  Rounds 1-4 ran this as a kernel (k_carr_guess, a
 // block scan per slot: 22 us at the head of the chain every batch waits for); on the host it is ~100 flops per record at plan time.
-static double guess_reduce(double x, double d)
-{
-    // the reference keeps the phase in (-1, 1) with the sign of the step it was last wrapped with (src/galileo-sdr.cpp:531-532)
-    x = x - std::trunc(x);
-    if (x != 0.0 && d != 0.0 && ((x < 0.0) != (d < 0.0))) x += d < 0.0 ? -1.0 : 1.0;
-    return x;
-}
-
 // One slot's chain of guesses, stepped epoch by epoch inside gal_synth_plan's single pass over the records (round 6; round 5: a
 // function of its own over the staged arrays, slot by slot -- a strided second pass, 0.35 of a 1199-epoch plan's 0.9 ms).
 struct GuessChain {
-    double run = 0.0;  // unreduced phase (fraction) after the epoch before, counted from the last restart
+    double ph = 0.0;   // guessed phase after the epoch before, in the REFERENCE'S representation: in (-1, 1), keeping its sign until it
+                       // crosses zero; a wrap keeps the sign (`p += d; p -= (long)p`, src/galileo-sdr.cpp:531-532)
     int kind = 0;      // last event before this epoch: 0 nothing yet, 1 defined (a wrap or a root), 2 chain broken (idle epoch)
     long long ev_w = 0;
     double ev_r = 0.0;
@@ -186,18 +179,30 @@ struct GuessChain {
             return;
         }
         const bool reset = restart || e == 0;
-        const double start = restart ? p0 : start_in;
         const double d = galnco::eff_step(dstep);
-        double adv = (double)N * d;
-        adv = adv - std::trunc(adv);
-        const double mine = reset ? start : guess_reduce(run, d);
-        run = reset ? start + adv : run + adv;
-        run = run - std::trunc(run);  // (only the fraction matters; keeps the sums small)
+        const double mine = reset ? (restart ? p0 : start_in) : ph;
+        // The phase at the END of the epoch.  A phase and a step of different signs (the epochs behind a Doppler sign change: a
+        // satellite at culmination) run towards zero, and crossing zero is NOT a wrap -- trunc() of a phase in (-1, 1) is 0 -- so
+        // the phase takes the step's sign only once it has crossed; wraps keep it.  (Rounds 1-5 gave the carried phase the sign of
+        // the NEXT epoch's step: 0.3 in front of a negative step became -0.7, the device predicted a wrap 0.3 / |d| samples on that
+        // never happens, and every leg anchored at it went into a second and third pass: tools/fresh_plan_probe.py, the four seeds of
+        // 32 whose Doppler crosses zero.)
+        const double full = (double)N * d;
+        double y = mine + (full - std::trunc(full));  // (only the fraction matters; keeps the sum small)
+        y = y - std::trunc(y);
+        const bool mixed = mine != 0.0 && d != 0.0 && ((mine < 0.0) != (d < 0.0));
+        const bool crossed = !mixed || std::fabs(full) > std::fabs(mine);
+        if (y != 0.0 && d != 0.0) {
+            const bool neg = crossed ? d < 0.0 : mine < 0.0;
+            if ((y < 0.0) != neg) y += neg ? -1.0 : 1.0;
+        }
+        ph = y;
         const bool use_root = reset || kind != 1;  // (a chain without a root is rejected by gal_synth_plan)
         *pguess = mine;
         *gss_w = use_root ? (long long)e * N : ev_w;
         *gss_r = use_root ? mine : ev_r;
-        // the last event up to the END of this epoch: a wrap inside it, else its root, else what came before
+        // the last event up to the END of this epoch: a wrap inside it (ideal_last_wrap counts the integers the unreduced phase
+        // passes in the step's direction -- zero is none), else its root, else what came before
         int om;
         double rr;
         if (galnco::ideal_last_wrap(mine, d, N, &om, &rr)) {
@@ -917,7 +922,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     const size_t o_act = take((size_t)n_groups * E * kActRow), o_nact = take((size_t)n_groups * E * 4);
     const size_t up_bytes = off;
     if (up_bytes > h->h_up_bytes) return fail(GAL_E_STATE, "gal_synth_plan: staging buffer bound exceeded (%zu > %zu)", up_bytes, h->h_up_bytes);
-    // zeroed region (ONE memset): checkpoints, first guesses, leg records that are read before they are written
+    // checkpoints (not cleared), then the zeroed region (ONE memset): leg records that are read before they are written
     const size_t o_cpx = take(ES * CP1 * 8), o_cpp = take(ES * CP1 * 8), o_cpi = take(ES * CP1 * 4);
     const size_t o_ancw = take(LEGS * S * 8), o_ancr = take(LEGS * S * 8), o_clmr = take(LEGS * S * 8);
     const size_t o_pend = take(LEGS * S * 8), o_ver = take(LEGS * S), o_dirty = take(LEGS * S), o_risk = take(LEGS * S);
@@ -992,6 +997,13 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     P.tdir = (int8_t *)(base + o_tdir);
     P.scanm = (void *)(base + o_scanm);
     P.translate = 1;
+    P.hook_spoil = 0;
+#ifdef GAL_TEST_HOOKS
+    // one first-pass anchor that is WRONG by a sample (slot 0, leg GAL_HOOK_BAD_LEG): the stitch re-anchors the leg at another event, a
+    // second pass walks it again -- the batch that needs more than one carrier pass, which the tests of the repair paths want (since
+    // round 6's guesses no random small batch does: tools/find_multi_pass_batch.py)
+    if (getenv("GAL_GUESS_SPOIL")) P.hook_spoil = 1;
+#endif
     P.tr_e0 = 0;
     P.tr_e1 = E;
     P.cp_e0 = 0;
@@ -1055,7 +1067,16 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
             HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
             HIP_TRY(hipEventRecord(h->ev_up1, st_up));  // (the staging buffer is free from here on; the copy is what ms_h2d times)
             h->upload_timed = true;
-            HIP_TRY(hipMemsetAsync(base + o_cpx, 0, zero_end - o_cpx, st_up));
+            // what must start at zero: the leg records that a stitch may read before a walk has written them.  The checkpoint arrays
+            // (98 MB of a 1199-epoch plan, 7 GB of config 4's) need no clearing: every entry a kernel USES -- those of active records
+            // of the executed epochs -- is written by the walkers of the same execute first; idle positions alias a slot whose values
+            // are read and dropped.  (Rounds 1-5 cleared them with every plan: ~0.05 ms of fill kernels per fresh M-SYN12 plan beside
+            // the other handle's synthesis.  Checked by running the GPU suite on a build that fills them with NaN bit patterns
+            // instead: GAL_TEST_HOOKS, GAL_ARENA_POISON=1.)
+#ifdef GAL_TEST_HOOKS
+            if (getenv("GAL_ARENA_POISON")) HIP_TRY(hipMemsetAsync(base + o_cpx, 0xff, o_ancw - o_cpx, st_up));
+#endif
+            HIP_TRY(hipMemsetAsync(base + o_ancw, 0, zero_end - o_ancw, st_up));
             HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
             // (the stitch's tickets and look-back records: no word there may look like a tag this handle is still going to hand out.
             // Its own records never do -- tags only grow -- so this is for a region that held something else: a new layout)

@@ -74,6 +74,7 @@ struct DevPlan {
     void *scanm;         // scratch of the stitch: tickets and look-back records (synth_kernels.hip: ScanM)
     int translate;       // 1 normal; 0: always re-walk (the all-walked fallback); 2: GAL_TEST_HOOKS builds only
     int tr_e0, tr_e1;    // legs of epochs outside [tr_e0, tr_e1) are never translated (gal_synth_execute_range)
+    int hook_spoil;      // GAL_TEST_HOOKS builds only (GAL_GUESS_SPOIL): the first pass anchors leg GAL_HOOK_BAD_LEG of slot 0 one sample late
     int cp_e0;           // the walkers emit chunk checkpoints from this epoch on only (gal_synth_execute_range: epochs in
                          // front of the range are walked silently -- their states are needed, their checkpoints are not)
 

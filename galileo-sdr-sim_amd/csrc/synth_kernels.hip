@@ -303,6 +303,9 @@ __global__ void k_walk_carr(DevPlan P, int first)
             cur = P.gss_w[idx];
             p = P.gss_r[idx];
         }
+#ifdef GAL_TEST_HOOKS
+        if (P.hook_spoil && li == GAL_HOOK_BAD_LEG) cur += 1;  // a guessed wrap event that is off by one sample: walked again in pass two
+#endif
         P.anc_w[li] = cur;
         P.anc_r[li] = p;
         P.verified[li] = 0;

@@ -148,7 +148,9 @@ def test_cli_sigint_finishes_the_current_epoch(tmp_path):
     out = tmp_path / "int.ishort"
     p = subprocess.Popen([CLI, "-e", NAV, "-l", "-6,51,100", "-t", "2022/02/20,12:00:00", "-d", "8", "-r", "-P", "0", "-o",
                           str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    time.sleep(2.0)
+    t0 = time.time()  # (how long HIP takes to start varies with the box: wait for five paced epochs in the file, not for a fixed time)
+    while time.time() - t0 < 20.0 and not (os.path.exists(str(out)) and os.path.getsize(str(out)) >= 5 * 260000 * 4):
+        time.sleep(0.05)
     p.send_signal(signal.SIGINT)
     p.wait(timeout=30)
     assert p.returncode == 0, p.stderr.read()

@@ -109,3 +109,46 @@ def test_host_plan_time_is_reported(pkg, capsys):
     with capsys.disabled():
         print("\n[host plan, 1199 x 16 records: %.3f ms]" % ms)
     assert ms < 20.0
+
+
+def test_carrier_guesses_through_a_doppler_zero_crossing(pkg):
+    """The first guesses of the speculative carrier walk (gal_synth_plan, GuessChain) against the exact chain, epoch by epoch, for
+    carriers whose Doppler passes through zero (a satellite at culmination) and for one that flips its sign at 3 kHz: the guessed
+    phase at every epoch start is the exact one to 1e-9 cycles IN THE REFERENCE'S REPRESENTATION -- the phase keeps its sign until it
+    crosses zero, and crossing zero is not a wrap (src/galileo-sdr.cpp:531-532) -- and the guessed last wrap event in front of an
+    epoch is the true one.  (Rounds 1-5 gave the carried phase the sign of the NEXT step: a phantom wrap behind every sign change, a
+    second and a third walker pass for the batch: tools/fresh_plan_probe.py.)"""
+    from test_walker_cpu import LIBW
+
+    lib = _hooks(pkg)
+    w = ctypes.CDLL(LIBW)
+    w.galwalk_carr.restype = ctypes.c_double
+    w.galwalk_carr.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    E, S, N, rate = 300, 8, 26000, 2.6e6
+    p = pkg.workloads.make_synthetic(n_epochs=E, n_chan=4, n_slots=S, samples_per_epoch=N, sample_rate=rate, seed=9)
+    e = np.arange(E)
+    p["f_carr"][:, 0] = 30.0 - 0.2 * e          # crosses zero at epoch 150, slowly
+    p["f_carr"][:, 1] = -3.0 + 0.02 * e         # ... from below, more slowly still
+    p["f_carr"][:, 2] = np.where(e % 50 < 25, 3000.0, -3000.0)  # flips its sign at full speed
+    p["f_carr"][:, 3] = -1234.5                 # an ordinary negative Doppler
+    p["f_code"][:, :4] = 1.023e6 + p["f_carr"][:, :4] * 0.0006493506493506494
+    _plan(pkg, lib, p, n_samp=N, rate=rate)
+    n = E * S
+    pg = _arr(lib, "pguess", np.float64, n).reshape(E, S)
+    gw = _arr(lib, "gss_w", np.int64, n).reshape(E, S)
+    gr = _arr(lib, "gss_r", np.float64, n).reshape(E, S)
+    dstep = _arr(lib, "dstep", np.float64, n).reshape(E, S)
+    for s in range(4):
+        ph = float(p["carr_phase0"][0, s])
+        last_w, last_r = 0, ph
+        cp = np.zeros(N + 1)
+        for ep in range(E):
+            assert abs(pg[ep, s] - ph) < 1e-9, (s, ep, pg[ep, s], ph)            # same representation, not just the same phase mod 1
+            assert gw[ep, s] == last_w and abs(gr[ep, s] - last_r) < 1e-9, (s, ep, gw[ep, s], last_w)
+            d = float(dstep[ep, s])
+            end = w.galwalk_carr(ph, d, N, 1, cp.ctypes.data, None)           # the exact phase before every sample of the epoch
+            cp[N] = end
+            wraps = np.flatnonzero(np.abs(cp[:N] + d) >= 1.0)                   # samples whose step wrapped: `p -= (long)p` took something
+            if wraps.size:
+                last_w, last_r = ep * N + int(wraps[-1]) + 1, float(cp[wraps[-1] + 1])
+            ph = end
