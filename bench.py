@@ -274,150 +274,93 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0
             "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3), "window_mode": stats[-1].get("window_mode")}
 
 
-def leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms, local_rank):
+def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms):
     """the engine on FRESH parameters.  The headline re-executes one resident plan; no caller runs the same 120 s
     twice -- the reference computes its parameters between epochs (src/galileo-sdr.cpp:450-479).  Here every step gets a scenario of
-    its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish.  As in the headline TWO batches are in
-    flight on the device; a THIRD handle is the one being planned (gal_synth_plan_async: validation, lists, the SoA split into pinned
-    memory, the upload enqueued) ON A SECOND HOST THREAD: the main thread finishes the oldest batch, executes the handle that was
-    planned a step ago, and hands the handle it has just finished to the planner with the next scenario -- plan(k+1) runs under
-    execute(k), on the host as on the device.  (`two_handles`: the same with the plan
-    between a handle's finish and its own next execute -- the walkers then start half a millisecond later, at the END of the other
-    batch's synthesis instead of at its start.)  The parameter sets are made before the timed region (producing them is the
-    front-end's job, row f1).  The outputs of the last two steps -- two different seeds -- are then compared with the oracle, every
-    int16 of every epoch (by cpu_baseline, which gets them as `pending`)."""
+    its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish, on the headline's two handles and one
+    host thread:  finish(j);  execute(j) -- which makes the plan that was STAGED while j's batch before was in flight the handle's,
+    enqueues its upload and the walkers behind it --;  gal_synth_plan_async(j, the scenario after next) with the batch just executed
+    in flight: validation, lists and the SoA split into pinned memory run under the two batches on the device -- plan(k+1) under
+    execute(k).  The parameter sets are made before the timed region (producing them is the front-end's job, row f1).  The outputs
+    of the last two steps -- two different seeds -- are then compared with the oracle, every int16 of every epoch (by cpu_baseline,
+    which gets them as `pending`)."""
     import hashlib
 
     depth = len(engines)
-    warm = 2 * (depth + 1)
-    n_sets = min(steps + warm + 1, 64)  # (beyond 64 steps the seeds repeat, 64 steps apart: 3.4 MB of records each)
+    warm = 2 * depth
+    n_sets = min(steps + warm, 64)  # (beyond 64 steps the seeds repeat, 64 steps apart: 3.4 MB of records each)
     sets = [pkg.shard.rank_workload(1000 + k, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate)
             for k in range(n_sets)]
-    # the spare handle: same configuration, its own stream and output
-    spare = pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=n_slots, device=local_rank, test_hooks=HOOKS_BUILD)
-    spare_stream = torch.cuda.Stream()
-    spare.set_stream(spare_stream.cuda_stream)
-    eng3 = list(engines) + [spare]
-    out3 = [torch.empty_like(outs[0]) for _ in eng3]  # (its own outputs: the headline's stay as they are for the oracle's verdict on them)
-    which = [None] * len(eng3)
+    out2 = [torch.empty_like(outs[0]) for _ in engines]  # (its own outputs: the headline's stay as they are for the oracle's verdict on them)
+    which = [None] * depth
     host = {"finish": 0.0, "plan": 0.0, "execute": 0.0}
+    stamps = []  # host time at which each step's finish returned
 
-    def run_two(first, n):  # plan between a handle's finish and its own next execute
+    staged = [None] * depth
+
+    def run(first, n):
+        """n steps, each with ONE plan call: the handles come in with the first `depth` scenarios staged (as a caller in steady state
+        always has the next batch planned) and leave with the scenarios of the steps behind the last one staged."""
         stats = []
         inflight = [False] * depth
         for k in range(n):
             j = k % depth
+            ta = time.perf_counter()
             if inflight[j]:
-                stats.append(eng3[j].finish()[1])
-            eng3[j].plan(sets[(first + k) % n_sets], wait=False)
-            eng3[j].execute(out3[j].data_ptr())
-            which[j] = (first + k) % n_sets
+                stats.append(engines[j].finish()[1])
+                stamps.append(time.perf_counter())
+            tb = time.perf_counter()
+            if staged[j] is None:  # (pipeline fill: nothing was planned ahead for this handle)
+                staged[j] = (first + k) % n_sets
+                engines[j].plan(sets[staged[j]], wait=False)
+            tc = time.perf_counter()
+            engines[j].execute(out2[j].data_ptr())
+            which[j], staged[j] = staged[j], None
             inflight[j] = True
+            td = time.perf_counter()
+            staged[j] = (first + k + depth) % n_sets  # the scenario this handle runs next, planned while its batch is in flight
+            engines[j].plan(sets[staged[j]], wait=False)
+            te = time.perf_counter()
+            host["finish"] += tb - ta
+            host["execute"] += td - tc
+            host["plan"] += (tc - tb) + (te - td)
         for k in range(n, n + depth):
             j = k % depth
             if inflight[j]:
-                stats.append(eng3[j].finish()[1])
+                stats.append(engines[j].finish()[1])
+                stamps.append(time.perf_counter())
                 inflight[j] = False
         return stats
 
-    state = {"next": 0}
-    stamps = []  # host time at which each step's finish returned
-
-    from concurrent.futures import ThreadPoolExecutor
-
-    planner = ThreadPoolExecutor(1)  # the caller's planning thread (the reference's parameter producers run between its epochs; a caller
-                                     # of this engine runs them -- and the plan call -- beside the batches in flight; ctypes releases the GIL)
-    planned = {}
-
-    def run_three(n):
-        """n steps; on entry nothing is in flight."""
-        stats, fly = [], []
-        ready = None
-        idle = list(range(len(eng3)))
-
-        def plan(j):
-            k = state["next"] % n_sets
-            state["next"] += 1
-            which[j] = k
-            planned[j] = planner.submit(eng3[j].plan, sets[k], None, False)
-
-        done = 0
-        started = 0
-        while done < n:
-            ta = time.perf_counter()
-            if len(fly) == depth or started == n:
-                j = fly.pop(0)
-                stats.append(eng3[j].finish()[1])
-                stamps.append(time.perf_counter())
-                idle.append(j)
-                done += 1
-            tb = time.perf_counter()
-            if started < n:
-                if ready is None:  # (pipeline fill: nothing was planned ahead)
-                    ready = idle.pop(0)
-                    plan(ready)
-                planned.pop(ready).result()  # (planned a step ago, beside the batches in flight: done long since)
-                eng3[ready].execute(out3[ready].data_ptr())
-                fly.append(ready)
-                started += 1
-                ready = None
-            tc = time.perf_counter()
-            if started < n and idle:
-                ready = idle.pop(0)
-                plan(ready)  # under the two batches in flight
-            td = time.perf_counter()
-            host["finish"] += tb - ta
-            host["execute"] += tc - tb
-            host["plan"] += td - tc
-        return stats
-
-    def timed(fn):
-        torch.cuda.synchronize()
-        host.update(finish=0.0, plan=0.0, execute=0.0)
-        t0 = time.perf_counter()
-        stats = fn()
-        torch.cuda.synchronize()
-        return stats, time.perf_counter() - t0, dict(host)
-
-    run_two(0, warm)
-    stats2, dt2, host2 = timed(lambda: run_two(warm, steps))
-    run_three(warm)
+    run(0, warm)
+    torch.cuda.synchronize()
+    host.update(finish=0.0, plan=0.0, execute=0.0)
     del stamps[:]
-    stats, dt, host3 = timed(lambda: run_three(steps))
-    # finish-to-finish intervals by the carrier passes the step needed: a scenario in which a channel's Doppler passes through zero has
-    # carrier cycles of millions of samples, the ideal-arithmetic guess of such a wrap's sample index can be off by one, and every leg
-    # anchored at it is walked again in a second (third) pass -- a longer walker chain than the other batch's synthesis hides
+    t0 = time.perf_counter()
+    stats = run(warm, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(stats) == steps and all(x["chain_mismatch"] == 0 for x in stats)
+    ms = dt / steps * 1e3
+    # finish-to-finish intervals by the carrier passes the step needed (a scenario in which a channel's Doppler passes through zero
+    # has carrier cycles of millions of samples; some of its legs are walked again in a second pass)
     by_passes = {}
     for k in range(1, len(stats)):
         by_passes.setdefault(int(stats[k]["walk_passes"]), []).append((stamps[k] - stamps[k - 1]) * 1e3)
-    assert len(stats) == steps and all(x["chain_mismatch"] == 0 for x in stats + stats2)
-    ms = dt / steps * 1e3
-    value = epochs * n_samp * steps / dt / 1e6
-    last = sorted(range(len(eng3)), key=lambda j: which[j])[-2:]  # the two handles that ran the last two scenarios
-
     # what the oracle is to look at (cpu_baseline does, the only place of this file that touches the checker)
-    pending = [({"seed": 1000 + which[j], "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}, sets[which[j]], out3[j]) for j in last]
-    planner.shutdown()
-    spare.close()
-
-    def summary(st, d, h):
-        return {"ms_per_step": round(d / steps * 1e3, 4), "value": round(epochs * n_samp * steps / d / 1e6, 1),
-                "plan_ms": round(sum(x["ms_plan"] for x in st) / len(st), 4), "h2d_ms": round(sum(x["ms_h2d"] for x in st) / len(st), 4),
-                "steps_with_a_repeated_synthesis": sum(x.get("synth_runs", 1) > 1 for x in st), "walk_passes_max": max(x["walk_passes"] for x in st),
-                "avg_kernel_ms": round(sum(x["ms_synth"] for x in st) / len(st), 4), "avg_walk_ms": round(sum(x["ms_walk"] for x in st) / len(st), 4),
-                "host_ms_per_step": {k: round(v / steps * 1e3, 4) for k, v in h.items()}}
-
-    s3 = summary(stats, dt, host3)
-    return {"value": round(value, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "steps": steps, "distinct_parameter_sets": n_sets,
-            "handles": len(eng3), "in_flight": depth,
-            "plan_ms": s3["plan_ms"], "h2d_ms": s3["h2d_ms"],
+    pending = [({"seed": 1000 + which[j], "params_md5": hashlib.md5(sets[which[j]].tobytes()).hexdigest()[:12]}, sets[which[j]], out2[j])
+               for j in range(depth)]
+    return {"value": round(epochs * n_samp * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(ms, 4), "steps": steps,
+            "distinct_parameter_sets": n_sets, "handles": depth,
+            "plan_ms": round(sum(x["ms_plan"] for x in stats) / len(stats), 4), "h2d_ms": round(sum(x["ms_h2d"] for x in stats) / len(stats), 4),
             "ratio_to_resident_plan_step": round(ms / resident_ms, 4) if resident_ms else None,
-            **{k: s3[k] for k in ("steps_with_a_repeated_synthesis", "walk_passes_max", "avg_kernel_ms", "avg_walk_ms", "host_ms_per_step")},
+            "steps_with_a_repeated_synthesis": sum(x.get("synth_runs", 1) > 1 for x in stats), "walk_passes_max": max(x["walk_passes"] for x in stats),
+            "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 4), "avg_walk_ms": round(sum(x["ms_walk"] for x in stats) / len(stats), 4),
+            "host_ms_per_step": {k: round(v / steps * 1e3, 4) for k, v in host.items()},
             "ms_per_step_by_walk_passes": {str(k): {"steps": len(v), "ms": round(sum(v) / len(v), 4)} for k, v in sorted(by_passes.items())},
-            "two_handles": {**summary(stats2, dt2, host2), "ratio_to_resident_plan_step": round(dt2 / steps * 1e3 / resident_ms, 4) if resident_ms else None},
-            "what": "step = gal_synth_plan_async (a new scenario: host validation + SoA split + upload enqueued) + execute + finish; %d batches in "
-                    "flight, a third handle being planned meanwhile; plan_ms = host time of the plan call, h2d_ms = device time of its upload, "
-                    "both per step" % depth}, pending
+            "what": "step = gal_synth_plan_async (a new scenario: host validation + SoA split into pinned memory, staged while the handle's "
+                    "batch before is in flight) + execute (commits the staged plan: upload enqueued, walkers behind it) + finish; %d handles, "
+                    "one host thread; plan_ms = host time of the plan call, h2d_ms = device time of its upload, both per step" % depth}, pending
 
 
 def profiled_kernel_ms(kind="bench"):
@@ -897,8 +840,8 @@ def main():
         pending = []
         if world == 1 and args.workload in ("syn12", "dyn") and not strong and args.signal == "boc11" and not args.no_fresh_plan:
             # the same step on FRESH parameters (plan + execute + finish, another scenario every step), on the headline's handles
-            fp, pending = leg_fresh_plan(torch, pkg, engines, outs, streams, n_samp, rate, n_slots, args.channels, args.epochs,
-                                         args.steps, elapsed / args.steps * 1e3, local_rank)
+            fp, pending = leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, args.channels, args.epochs,
+                                         args.steps, elapsed / args.steps * 1e3)
             line["configs"] = {"fresh_plan": fp}
             line["config"]["plan_ms"] = fp["plan_ms"]  # host time of one gal_synth_plan of this workload
         if world == 1 and not args.no_cpu_baseline:

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -217,7 +218,24 @@ struct GuessChain {
     }
 };
 
+// What a plan produces on the host.  gal_synth_plan[_async] fills one of these (and the pinned staging buffer) WITHOUT touching what
+// the batch in flight still needs; commit_staged() makes it the handle's plan and enqueues its upload -- at once if nothing is in
+// flight, else at the next gal_synth_execute (behind the gal_synth_finish of the batch in flight): plan(k+1) under execute(k) on ONE
+// handle (round 6).  Until the commit the device pointers of P are OFFSETS into the arena.
+struct StagedPlan {
+    DevPlan P{};
+    int n_groups = 0, all_first = 0, all_count = 0, n_exact_records = 0, nact_max = 0;
+    std::vector<int> group_nch, group_kind;
+    std::vector<int64_t> act_prefix;
+    size_t o_plan = 0, o_act = 0, o_nact = 0, up_bytes = 0, total = 0;
+    size_t o_cpx = 0, o_ancw = 0, zero_end = 0, o_clmw = 0, clmw_bytes = 0, o_scanm = 0, scanm_clear = 0;
+    int R = 0, nchunks = 0;
+    float ms_plan = 0.0f;
+};
+
 struct gal_synth {
+    StagedPlan staged;            // the plan made while a batch was in flight (or being committed)
+    bool staged_pending = false;  // ... waits for its commit
     gal_synth_cfg_t cfg{};
     int device = 0;
     int n_cu = 256;  // compute units of the device (MI355X: 256)
@@ -548,24 +566,113 @@ int gal_synth_set_stream(gal_synth_t *h, void *hip_stream)
 
 size_t gal_synth_output_bytes(const gal_synth_t *h)
 {
-    if (!h || !h->planned) return 0;
+    if (!h) return 0;
+    if (h->staged_pending) return (size_t)h->staged.P.E * (size_t)h->staged.P.N * 4u;  // (the plan the next execute runs)
+    if (!h->planned) return 0;
     return (size_t)h->P.E * (size_t)h->P.N * 4u;
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The staged plan becomes the handle's: arena (grown if need be), device pointers, the ONE host->device copy out of the pinned
+// staging buffer, the memsets of what must start clean.  Everything the device needs is laid out in the staging buffer exactly as
+// in the arena.  (Round 1 issued 4 pageable copies and 11 memsets one by one: 0.2 ms per plan.  Round 6: one pass over the caller's
+// records fills the buffer -- no memset of it, no copy of the 176-byte records --, and the upload is not waited for unless the
+// caller asked: gal_synth_plan is resident on return, gal_synth_plan_async's upload is waited for by the walkers on the device.)
+static int commit_staged(gal_synth *h, const bool wait)
+{
+    StagedPlan &sp = h->staged;
+    if (!h->host_only && sp.total > h->arena_bytes) {
+        if (h->arena) hipFree(h->arena);
+        h->arena = nullptr;
+        h->arena_bytes = 0;
+        if (hipMalloc(&h->arena, sp.total) != hipSuccess) return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", sp.total);
+        h->arena_bytes = sp.total;
+        h->scanm_off = ~(size_t)0;  // (new memory: the stitch's records have to be cleared)
+    }
+    char *const base = (char *)h->arena;
+    DevPlan &P = sp.P;
+    {
+        // offsets -> addresses (every pointer of the plan into the arena; lut and str are the handle's tables, absolute already)
+        auto rb = [&](auto *&ptr) { ptr = (std::remove_reference_t<decltype(ptr)>)(base + (size_t)(uintptr_t)ptr); };
+        rb(P.page_init); rb(P.init_ix); rb(P.state_in); rb(P.state_out); rb(P.prn); rb(P.flags); rb(P.ib0); rb(P.x0); rb(P.p0);
+        rb(P.cstep); rb(P.dstep); rb(P.page_next); rb(P.page_cur); rb(P.flip_in); rb(P.pguess); rb(P.gss_w); rb(P.gss_r);
+        rb(P.anc_w); rb(P.anc_r); rb(P.clm_w); rb(P.clm_r); rb(P.pend); rb(P.verified); rb(P.dirty); rb(P.risk); rb(P.marg);
+        rb(P.shift); rb(P.tpos); rb(P.tdir); rb(P.scanm); rb(P.cp_x); rb(P.cp_p); rb(P.cp_ib); rb(P.ctr); rb(P.gflist);
+    }
+    h->P = P;
+    h->d_plan = (DevPlan *)(base + sp.o_plan);
+    h->d_act = (uint8_t *)(base + sp.o_act);
+    h->d_nact = (int *)(base + sp.o_nact);
+    h->n_groups = sp.n_groups; h->all_first = sp.all_first; h->all_count = sp.all_count; h->n_exact_records = sp.n_exact_records;
+    h->group_nch = std::move(sp.group_nch);
+    h->group_kind = std::move(sp.group_kind);
+    h->act_prefix = std::move(sp.act_prefix);
+    h->nact_max = sp.nact_max;
+    h->ms_plan = sp.ms_plan;
+    h->staged_pending = false;
+    h->planned = false;
+    h->executed = false;
+    char *const up = h->h_up;
+    memcpy(up + sp.o_plan, &h->P, sizeof(DevPlan));
+    if (!h->host_only) {
+        hipStream_t st_up = handle_stream(h);
+        if (!st_up) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
+        HIP_TRY(hipEventRecord(h->ev_up0, st_up));
+        HIP_TRY(hipMemcpyAsync(base, up, sp.up_bytes, hipMemcpyHostToDevice, st_up));
+        HIP_TRY(hipEventRecord(h->ev_up1, st_up));  // (the staging buffer is free from here on; the copy is what ms_h2d times)
+        h->upload_timed = true;
+        // what must start at zero: the leg records that a stitch may read before a walk has written them.  The checkpoint arrays
+        // (98 MB of a 1199-epoch plan, 7 GB of config 4's) need no clearing: every entry a kernel USES -- those of active records
+        // of the executed epochs -- is written by the walkers of the same execute first; idle positions alias a slot whose values
+        // are read and dropped.  (Rounds 1-5 cleared them with every plan: ~0.05 ms of fill kernels per fresh M-SYN12 plan beside
+        // the other handle's synthesis.  Checked by running the GPU suite on a build that fills them with NaN bit patterns
+        // instead: GAL_TEST_HOOKS, GAL_ARENA_POISON=1.)
+#ifdef GAL_TEST_HOOKS
+        if (getenv("GAL_ARENA_POISON")) HIP_TRY(hipMemsetAsync(base + sp.o_cpx, 0xff, sp.o_ancw - sp.o_cpx, st_up));
+#endif
+        HIP_TRY(hipMemsetAsync(base + sp.o_ancw, 0, sp.zero_end - sp.o_ancw, st_up));
+        HIP_TRY(hipMemsetAsync(base + sp.o_clmw, 0xff, sp.clmw_bytes, st_up));
+        // (the stitch's tickets and look-back records: no word there may look like a tag this handle is still going to hand out.
+        // Its own records never do -- tags only grow -- so this is for a region that held something else: a new layout)
+        if (h->scanm_off != sp.o_scanm || h->scanm_clear != sp.scanm_clear) {
+            HIP_TRY(hipMemsetAsync(base + sp.o_scanm, 0, sp.scanm_clear, st_up));
+            h->scanm_off = sp.o_scanm;
+            h->scanm_clear = sp.scanm_clear;
+        }
+        // what the walker streams of the next execute wait for (they do not wait for the caller's stream otherwise)
+        HIP_TRY(hipEventRecord(h->ev_upd, st_up));
+        h->upload_pending = true;
+        h->upload_unordered = true;
+        if (wait) {
+            HIP_TRY(hipStreamSynchronize(st_up));
+            h->upload_pending = false;
+            h->upload_unordered = false;
+        }
+    }
+    memset(&h->stats, 0, sizeof(h->stats));
+    h->stats.n_epochs = h->P.E;
+    h->stats.n_active_max = h->nact_max;
+    h->stats.chunk_samples = sp.R;
+    h->stats.chunks_per_epoch = sp.nchunks;
+    h->enq_passes = kDefaultPasses;
+    h->planned = true;
+    return GAL_OK;
+}
+
 // wait: return when the batch is resident in HBM (gal_synth_plan); else as soon as its upload is enqueued (gal_synth_plan_async)
 static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs, const gal_chan_state_t *state_in, const bool wait)
 {
-    if (h && h->in_flight)
-        return fail(GAL_E_STATE, "gal_synth_plan while a batch is in flight: call gal_synth_finish first");
+    if (h && h->in_flight && wait)
+        return fail(GAL_E_STATE, "gal_synth_plan while a batch is in flight: call gal_synth_finish first (gal_synth_plan_async may be "
+                                 "called with a batch in flight: its upload then waits for the next gal_synth_execute)");
     if (!h || !params || n_epochs < 1) return fail(GAL_E_INVAL, "gal_synth_plan: bad argument");
     const auto t_plan0 = std::chrono::steady_clock::now();
     plan_stage("enter");
     if (!h->host_only) HIP_TRY(hipSetDevice(h->device));
     const int E = n_epochs, S = h->cfg.n_slots, N = h->cfg.samples_per_epoch;
-    h->planned = false;
-    h->executed = false;
+    h->staged_pending = false;  // (a staged plan that was never executed is replaced)
+    StagedPlan sp;
 
     // ---- the upload region's fixed part (sizes that depend on E and S only), so that ONE pass over the caller's records can validate
     // them, list the active ones and write the SoA copies, the NCO steps and the carrier guesses (round 5: three passes and a copy of
@@ -900,19 +1007,19 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     };
     int n_exact_records = 0;
     if (fam_g) {
-        h->n_groups = add_groups(1, [&](size_t i) { return rec_g[i] && rec_mode[i] == g_mode; });
-        h->n_groups += add_groups(0, [&](size_t i) { return !(rec_g[i] && rec_mode[i] == g_mode); });
+        sp.n_groups = add_groups(1, [&](size_t i) { return rec_g[i] && rec_mode[i] == g_mode; });
+        sp.n_groups += add_groups(0, [&](size_t i) { return !(rec_g[i] && rec_mode[i] == g_mode); });
         n_exact_records = (int)(n_records - n_grec);
-        h->all_first = h->n_groups;
-        h->all_count = n_exact_records ? add_groups(0, [](size_t) { return true; }) : 0;  // (no exact records: the kind-1 groups ARE all)
+        sp.all_first = sp.n_groups;
+        sp.all_count = n_exact_records ? add_groups(0, [](size_t) { return true; }) : 0;  // (no exact records: the kind-1 groups ARE all)
     } else {
-        h->n_groups = add_groups(0, [](size_t) { return true; });
-        h->all_first = 0;
-        h->all_count = 0;
+        sp.n_groups = add_groups(0, [](size_t) { return true; });
+        sp.all_first = 0;
+        sp.all_count = 0;
     }
-    h->group_nch = grp_nch;
-    h->group_kind = grp_kind;
-    h->n_exact_records = n_exact_records;
+    sp.group_nch = grp_nch;
+    sp.group_kind = grp_kind;
+    sp.n_exact_records = n_exact_records;
     const int n_groups = (int)grp_nch.size();  // (rows in the upload, not launches per execute)
 
     plan_stage("gate, chunking, groups");
@@ -940,19 +1047,9 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     const size_t o_scanm = take(galk_scanm_bytes(S, (int)LEGS));  // the stitch's look-back records (synth_kernels.hip: ScanM)
 
     const size_t total = off;
-    if (!h->host_only && total > h->arena_bytes) {
-        if (h->arena) hipFree(h->arena);
-        h->arena = nullptr;
-        h->arena_bytes = 0;
-        if (hipMalloc(&h->arena, total) != hipSuccess)
-            return fail(GAL_E_NOMEM, "hipMalloc of %zu bytes failed", total);
-        h->arena_bytes = total;
-        h->scanm_off = ~(size_t)0;  // (new memory: the stitch's records have to be cleared)
-    }
     plan_stage("layout + buffers");
-    char *base = (char *)h->arena;
-    h->d_plan = (DevPlan *)(base + o_plan);
-    DevPlan &P = h->P;
+    char *const base = nullptr;  // (offsets: commit_staged adds the arena's address)
+    DevPlan &P = sp.P;
     P.E = E; P.S = S; P.N = N; P.R = R; P.nchunks = nchunks; P.CP1 = (int)CP1;
     P.blocks_per_epoch = (tiles + 3) / 4;
     {
@@ -985,7 +1082,6 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     P.cstep = (double *)(base + o_cstep); P.dstep = (double *)(base + o_dstep);
     P.page_next = (uint32_t *)(base + o_pnext); P.page_cur = (uint32_t *)(base + o_pcur);
     P.flip_in = (uint8_t *)(base + o_flip);
-    h->d_act = (uint8_t *)(base + o_act); h->d_nact = (int *)(base + o_nact);
     P.pguess = (double *)(base + o_pguess);
     P.gss_w = (long long *)(base + o_gssw); P.gss_r = (double *)(base + o_gssr);
     P.anc_w = (long long *)(base + o_ancw); P.anc_r = (double *)(base + o_ancr);
@@ -1047,67 +1143,24 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     }
 #endif
 
-    // ---- upload: everything the device needs is laid out in the pinned staging buffer exactly as in the arena and
-    // goes over in one copy; one memset clears what must start at zero.  (Round 1 issued 4 pageable copies and 11 memsets one by
-    // one: 0.2 ms per plan, a quarter of a per-epoch call.)  Round 6 (the engine on FRESH parameters): ONE pass
-    // over the caller's records writes every array of the region -- no memset of the staging buffer, no copy of the 176-byte records
-    // (rounds 1-5: both, then a second pass for the SoA split) --, and the upload is not waited for unless the caller asked
-    // (gal_synth_plan: resident on return; gal_synth_plan_async: the walkers of the next execute wait for it on the device).
-    {
-        if (n_restart == 0) memset(u_pinit, 0, GAL_PAGE_WORDS * 4);
-        memcpy(up + o_plan, &P, sizeof(DevPlan));
-        memcpy(up + o_act, act_g.data(), act_g.size());
-        memcpy(up + o_nact, nact_g.data(), nact_g.size() * sizeof(int));
-        plan_stage("lists copied");
-        h->ms_plan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
-        if (!h->host_only) {
-            hipStream_t st_up = handle_stream(h);
-            if (!st_up) return fail(GAL_E_DEVICE, "hipStreamCreate failed");
-            HIP_TRY(hipEventRecord(h->ev_up0, st_up));
-            HIP_TRY(hipMemcpyAsync(base, up, up_bytes, hipMemcpyHostToDevice, st_up));
-            HIP_TRY(hipEventRecord(h->ev_up1, st_up));  // (the staging buffer is free from here on; the copy is what ms_h2d times)
-            h->upload_timed = true;
-            // what must start at zero: the leg records that a stitch may read before a walk has written them.  The checkpoint arrays
-            // (98 MB of a 1199-epoch plan, 7 GB of config 4's) need no clearing: every entry a kernel USES -- those of active records
-            // of the executed epochs -- is written by the walkers of the same execute first; idle positions alias a slot whose values
-            // are read and dropped.  (Rounds 1-5 cleared them with every plan: ~0.05 ms of fill kernels per fresh M-SYN12 plan beside
-            // the other handle's synthesis.  Checked by running the GPU suite on a build that fills them with NaN bit patterns
-            // instead: GAL_TEST_HOOKS, GAL_ARENA_POISON=1.)
-#ifdef GAL_TEST_HOOKS
-            if (getenv("GAL_ARENA_POISON")) HIP_TRY(hipMemsetAsync(base + o_cpx, 0xff, o_ancw - o_cpx, st_up));
-#endif
-            HIP_TRY(hipMemsetAsync(base + o_ancw, 0, zero_end - o_ancw, st_up));
-            HIP_TRY(hipMemsetAsync(base + o_clmw, 0xff, LEGS * S * 8, st_up));
-            // (the stitch's tickets and look-back records: no word there may look like a tag this handle is still going to hand out.
-            // Its own records never do -- tags only grow -- so this is for a region that held something else: a new layout)
-            const size_t scanm_clear = galk_scanm_status_bytes(S, (int)LEGS);
-            if (h->scanm_off != o_scanm || h->scanm_clear != scanm_clear) {
-                HIP_TRY(hipMemsetAsync(base + o_scanm, 0, scanm_clear, st_up));
-                h->scanm_off = o_scanm;
-                h->scanm_clear = scanm_clear;
-            }
-            // what the walker streams of the next execute wait for (they do not wait for the caller's stream otherwise)
-            HIP_TRY(hipEventRecord(h->ev_upd, st_up));
-            h->upload_pending = true;
-            h->upload_unordered = true;
-            if (wait) {
-                HIP_TRY(hipStreamSynchronize(st_up));
-                h->upload_pending = false;
-                h->upload_unordered = false;
-            }
-        }
-    }
-    h->nact_max = nact_max;
-    h->act_prefix.assign((size_t)E + 1, 0);
-    for (int e = 0; e < E; ++e) h->act_prefix[e + 1] = h->act_prefix[e] + nact_all[e];
-    memset(&h->stats, 0, sizeof(h->stats));
-    h->stats.n_epochs = E;
-    h->stats.n_active_max = nact_max;
-    h->stats.chunk_samples = R;
-    h->stats.chunks_per_epoch = nchunks;
-    h->enq_passes = kDefaultPasses;
-    h->planned = true;
-    return GAL_OK;
+    // ---- the staging buffer is complete but for the device copy of the plan (its pointers are final at the commit)
+    if (n_restart == 0) memset(u_pinit, 0, GAL_PAGE_WORDS * 4);
+    memcpy(up + o_act, act_g.data(), act_g.size());
+    memcpy(up + o_nact, nact_g.data(), nact_g.size() * sizeof(int));
+    plan_stage("lists copied");
+    sp.nact_max = nact_max;
+    sp.act_prefix.assign((size_t)E + 1, 0);
+    for (int e = 0; e < E; ++e) sp.act_prefix[e + 1] = sp.act_prefix[e] + nact_all[e];
+    sp.o_plan = o_plan; sp.o_act = o_act; sp.o_nact = o_nact; sp.up_bytes = up_bytes; sp.total = total;
+    sp.o_cpx = o_cpx; sp.o_ancw = o_ancw; sp.zero_end = zero_end; sp.o_clmw = o_clmw; sp.clmw_bytes = LEGS * S * 8;
+    sp.o_scanm = o_scanm; sp.scanm_clear = galk_scanm_status_bytes(S, (int)LEGS);
+    sp.R = R; sp.nchunks = nchunks;
+    sp.ms_plan = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+    h->staged = std::move(sp);
+    h->staged_pending = true;
+    // nothing in flight: the plan is the handle's at once, its upload enqueued (and waited for by gal_synth_plan).  A batch in flight
+    // (gal_synth_plan_async only): the arena still belongs to it -- the commit happens in the next gal_synth_execute
+    return h->in_flight ? GAL_OK : commit_staged(h, wait);
 }
 
 int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs, const gal_chan_state_t *state_in)
@@ -1207,9 +1260,19 @@ static int enqueue_synth(gal_synth *h, uint32_t *iq, bool verify_here)
     return GAL_OK;
 }
 
+// a plan made while the batch before was in flight becomes the handle's now (that batch must have been finished)
+static int ensure_committed(gal_synth *h)
+{
+    if (!h->staged_pending) return GAL_OK;
+    if (h->in_flight) return fail(GAL_E_STATE, "gal_synth_execute while a batch is in flight: call gal_synth_finish first");
+    HIP_TRY(hipSetDevice(h->device));
+    return commit_staged(h, false);
+}
+
 int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
 {
     if (!h) return fail(GAL_E_INVAL, "gal_synth_execute: null argument");
+    if (const int rc = ensure_committed(h)) return rc;
     if (!h->planned) return fail(GAL_E_STATE, "gal_synth_execute before gal_synth_plan");
     return gal_synth_execute_range(h, iq_dev, 0, h->P.E);
 }
@@ -1217,6 +1280,7 @@ int gal_synth_execute(gal_synth_t *h, int16_t *iq_dev)
 int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch, int32_t n_epochs)
 {
     if (!h || !iq_dev) return fail(GAL_E_INVAL, "gal_synth_execute: null argument");
+    if (const int rc = ensure_committed(h)) return rc;
     if (!h->planned) return fail(GAL_E_STATE, "gal_synth_execute before gal_synth_plan");
     if (first_epoch < 0 || n_epochs < 1 || first_epoch + n_epochs > h->P.E)
         return fail(GAL_E_INVAL, "gal_synth_execute_range: epochs [%d, %d) outside the planned batch of %d", first_epoch,

@@ -53,6 +53,22 @@ long galwalk_carr_iters(double p, double d, int N)
     return it;
 }
 
+// ONE carrier cycle from the wrap residual r (the phase right after a wrap, or any start phase): samples to the next wrap, the
+// residual there, the walk's binade margin (every start within +-margin of r takes the same itinerary: same sample count, residual
+// shifted by the same amount) and the closed-form iterations it cost.  For tools/carrier_table_prototype.py (DESIGN.md section 9:
+// the wrap-residual -> next-residual map as a piecewise translation).  Returns 0 if no wrap happens within n_max samples.
+int galwalk_cycle(double r, double d, int n_max, int *n_out, double *r_out, double *margin_out, long *iters_out)
+{
+    const WalkOut o = carr_walk_track(r, d, 1.0 / __builtin_fabs(d), n_max, n_max + 1, n_max + 1, [](int, double) {});
+    if (o.last_w < 0) return 0;
+    // (n_max is chosen by the caller so that exactly one wrap lies inside: last_w is the first)
+    if (n_out) *n_out = o.last_w;
+    if (r_out) *r_out = o.last_r;
+    if (margin_out) *margin_out = o.margin;
+    if (iters_out) *iters_out = galwalk_carr_iters(r, d, o.last_w);
+    return 1;
+}
+
 void galwalk_code(double x, int ibit, double c, int N, int R, double *cpx, uint32_t *cpi, double *xend,
                   int *ibend, int *flipped)
 {

@@ -175,17 +175,24 @@ int gal_synth_set_stream(gal_synth_t *h, void *hip_stream);
  * Upload the per-epoch parameters of a batch: params[e * n_slots + s], e < n_epochs (host memory).
  * state_in (host, n_slots entries, may be NULL for a fresh run) gives carr_phase/page for channels
  * that continue from a previous batch (records without GAL_CH_RESTART in their first active epoch).
- * After this call the batch is resident in HBM.
+ * After this call the batch is resident in HBM.  GAL_E_STATE while a batch is in flight (gal_synth_plan_async may be called then).
  */
 int gal_synth_plan(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                    const gal_chan_state_t *state_in);
 
 /*
- * The same, but returns as soon as the batch's upload is ENQUEUED on the handle's stream (its host work -- validation, lists, the
- * SoA split into pinned memory -- is done; `params` and `state_in` may be reused).  The walkers of the next gal_synth_execute[_range]
- * wait for the upload on the device.  This is how a caller with fresh parameters for every batch -- the reference computes them
- * between epochs, src/galileo-sdr.cpp:450-479 -- keeps two handles busy: plan(k+1) on the idle handle while batch k runs on the
- * other (bench.py: configs.fresh_plan).  Errors of the upload itself surface in gal_synth_execute / gal_synth_finish.
+ * The same without waiting: the host work of the plan -- validation, lists, the SoA split into the handle's pinned staging buffer --
+ * is done when it returns (`params` and `state_in` may be reused).
+ *   - Nothing in flight on the handle: the upload is ENQUEUED on the handle's stream; the walkers of the next
+ *     gal_synth_execute[_range] wait for it on the device.
+ *   - A batch IN FLIGHT (gal_synth_execute called, gal_synth_finish not yet): allowed -- this is plan(k+1) under execute(k).  The
+ *     plan is staged on the host only (the arena still belongs to the batch in flight); the next gal_synth_execute[_range], which
+ *     must come behind the gal_synth_finish of that batch, makes it the handle's plan, enqueues the upload and goes on.  Until then
+ *     gal_synth_finish / gal_synth_walk_counts speak of the batch in flight; gal_synth_output_bytes of the staged plan.
+ * This is how a caller with fresh parameters for every batch -- the reference computes them between epochs,
+ * src/galileo-sdr.cpp:450-479 -- keeps two handles busy: finish(A); execute(A); plan_async(A, the scenario after next), the same
+ * for B (bench.py: configs.fresh_plan).  One thread at a time per handle.  Errors of the upload itself surface in
+ * gal_synth_execute / gal_synth_finish.
  */
 int gal_synth_plan_async(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_epochs,
                          const gal_chan_state_t *state_in);

@@ -651,6 +651,79 @@ def test_plan_async_with_fresh_parameters_every_batch(pkg):
         e.close()
 
 
+def test_plan_async_while_the_batch_before_is_in_flight(pkg):
+    """plan(k+1) under execute(k) on ONE handle (round 6): gal_synth_plan_async with a batch in flight stages the next plan on the host
+    only -- the arena, the device plan and everything gal_synth_finish reports still belong to the batch in flight --; the next
+    gal_synth_execute (behind that batch's finish) commits it: upload enqueued, walkers behind it.  Two handles, one thread, a new
+    scenario every step (other sizes, other channel counts, a bigger one that makes the arena grow at the commit): every batch
+    bit-exact, the statistics those of the batch that ran.  The synchronous gal_synth_plan with a batch in flight stays an error, and
+    so does an execute in front of the finish."""
+    import torch
+
+    n = 52000
+    sets = [pkg.workloads.make_synthetic(n_epochs=5 + (k * 7) % 23, n_chan=2 + (k * 5) % 13, n_slots=16, samples_per_epoch=n, seed=1500 + k)
+            for k in range(11)]
+    refs = [oracle_run(q, n, 2.6e6) for q in sets]
+    engines = [pkg.SynthEngine(samples_per_epoch=n, n_slots=16, device=0) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.empty(max(q.shape[0] for q in sets) * n * 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+    for e, st in zip(engines, streams):
+        e.set_stream(st.cuda_stream)
+    running, staged = [None, None], [None, None]
+
+    def reap(j):
+        k = running[j]
+        st, stats = engines[j].finish()
+        ref_iq, ref_st = refs[k]
+        assert stats["chain_mismatch"] == 0 and stats["n_epochs"] == sets[k].shape[0], k  # (of the batch that ran, not of the staged plan)
+        assert stats["n_active_max"] == int((sets[k]["prn"] > 0).sum(axis=1).max())
+        assert np.array_equal(outs[j][: ref_iq.size].cpu().numpy(), ref_iq), k
+        act = ref_st["prn"] > 0
+        assert np.array_equal(st["carr_phase"][act].view(np.uint64), ref_st["carr_phase"][act].view(np.uint64))
+        running[j] = None
+
+    order = list(range(len(sets))) * 2
+    for step, k in enumerate(order):
+        j = step % 2
+        if running[j] is not None:
+            with pytest.raises(pkg.GalSynthError):  # a batch in flight and a plan staged: execute must wait for the finish
+                engines[j].execute(outs[j].data_ptr())
+            reap(j)
+        if staged[j] is None:
+            engines[j].plan(sets[k], wait=False)
+            staged[j] = k
+        assert engines[j].output_bytes() == sets[staged[j]].shape[0] * n * 4
+        engines[j].execute(outs[j].data_ptr())  # commits the staged plan
+        running[j], staged[j] = staged[j], None
+        if step + 2 < len(order):
+            nxt = order[step + 2]
+            with pytest.raises(pkg.GalSynthError):
+                engines[j].plan(sets[nxt])  # the synchronous plan needs the handle idle
+            engines[j].plan(sets[nxt], wait=False)  # ... the asynchronous one stages beside the batch in flight
+            staged[j] = nxt
+            assert engines[j].output_bytes() == sets[nxt].shape[0] * n * 4
+    for j in range(2):
+        if running[j] is not None:
+            reap(j)
+    # a staged plan that is replaced before it ever ran, and one that is dropped by a synchronous plan after the finish
+    engines[0].plan(sets[0], wait=False)
+    engines[0].execute(outs[0].data_ptr())
+    engines[0].plan(sets[1], wait=False)
+    engines[0].plan(sets[2], wait=False)  # replaces the staged plan of set 1
+    running[0] = 0
+    reap(0)
+    engines[0].execute(outs[0].data_ptr())
+    running[0] = 2
+    engines[0].plan(sets[3], wait=False)
+    reap(0)
+    engines[0].plan(sets[4])  # synchronous: takes the place of the staged plan of set 3
+    engines[0].execute(outs[0].data_ptr())
+    running[0] = 4
+    reap(0)
+    for e in engines:
+        e.close()
+
+
 def test_ranges_of_one_plan_keep_the_stitch_records_apart(pkg, monkeypatch):
     """the stitch's look-back records (k_scanm) were laid out from the RANGE-CUT leg count, so executing ranges of
     different lengths on one plan moved the status words over former payload words (claim kinds 0..2, fold flags 0..7) that
