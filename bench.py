@@ -224,7 +224,7 @@ def leg_file_sink(pkg, seconds=120):
     return out
 
 
-def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0):
+def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0, solo_launches=0):
     """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
     bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode; "syn12_4msps" = 12 SVs at 4 MS/s, a rate
     between the reference's and config 4's: window form 4), pipelined like the headline, on the
@@ -264,6 +264,13 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert all(x["chain_mismatch"] == 0 for x in stats)
+    solo = None
+    if solo_launches:  # the kernel with ONE handle in flight (what `roofline.frac` is for the headline)
+        one = []
+        for _ in range(solo_launches):
+            engines[0].execute(outs[0].data_ptr())
+            one.append(engines[0].finish()[1]["ms_synth"])
+        solo = sum(one) / len(one)
     for e in engines:
         e.close()
     del outs[:]
@@ -271,7 +278,8 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0
     value = epochs * n_samp * steps / dt / 1e6
     return {"value": round(value, 1), "unit": "Msamples/s", "x_realtime": round(value * 1e6 / rate, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "epochs": epochs, "channels": n_chan, "samples_per_epoch": n_samp, "steps": steps,
-            "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3), "window_mode": stats[-1].get("window_mode")}
+            "avg_kernel_ms": round(sum(x["ms_synth"] for x in stats) / len(stats), 3), "window_mode": stats[-1].get("window_mode"),
+            **({"kernel_one_handle_ms": round(solo, 4)} if solo is not None else {})}
 
 
 def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms):
@@ -880,9 +888,13 @@ def main():
                                "syn12_4msps": leg_config(torch, pkg, "syn12_4msps", 1199, 20, local_rank, streams)}
             # the headline with the opt-in SAMPLED self-check (round 5's default: a rotating eighth of the leg positions per batch instead
             # of every leg of both chains in every batch), same run, same box: what full verification costs the step
-            vs = leg_config(torch, pkg, "syn12", 1199, max(args.steps, 20), local_rank, streams, flags=pkg.synth.GAL_CFG_VERIFY_SAMPLED)
+            vs = leg_config(torch, pkg, "syn12", 1199, max(args.steps, 20), local_rank, streams, flags=pkg.synth.GAL_CFG_VERIFY_SAMPLED, solo_launches=10)
             line["roofline"]["verify_sampled"] = {"ms_per_step": vs["ms_per_step"], "value": vs["value"], "unit": "Msamples/s",
                                                   "steps": vs["steps"], "avg_kernel_ms": vs["avg_kernel_ms"],
+                                                  # k_synth_g with one handle in flight and only the rotation's eighth of the verification
+                                                  # beside it: the kernel itself has not changed since round 5 (BENCH_r05: 0.8413 ms = 18.5 %)
+                                                  "kernel_one_handle_ms": vs["kernel_one_handle_ms"],
+                                                  "kernel_one_handle_frac": round(4.0 * 1199 * 260000 / (vs["kernel_one_handle_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                                   "what": "GAL_CFG_VERIFY_SAMPLED: every (epoch, leg) position re-walked once per 8 batches; "
                                                           "the headline re-walks every leg of both chains in every batch"}
         line["x_realtime"] = round(value * 1e6 / rate, 2)

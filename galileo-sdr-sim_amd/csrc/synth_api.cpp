@@ -144,6 +144,7 @@ constexpr int kVerifyRotation = 8;  // GAL_CFG_VERIFY_SAMPLED: k_verify_carr / k
                                     // all of them).  Same box, M-SYN12, pipelined step / one handle / k_synth_g beside it, carrier legs only
                                     // (profiles/r05f_verify_ab.log): none 0.974 / 1.230 / 0.842 ms; every leg 1.010 / 1.297 / 0.890; every 4th
                                     // 0.985 / 1.258 / 0.865; 8th 0.979 / 1.238 / 0.846; 16th 0.976 / 1.234 / 0.845
+constexpr int kSmallPlanEpochs = 32;  // plans up to here are latency-bound calls (see commit_staged: enqueued passes)
 constexpr int kDefaultPasses = 3;   // carrier passes enqueued up front for a NEW plan: walk + stitch (which translates on the spot), two spare --
                                     // no-op launches in front of k_synth when the chain is complete after one, as it is for four fresh
                                     // scenarios in five (tools/fresh_plan_probe.py, 32 seeds of M-SYN12: 26 x 1 pass, 4 x 2, 2 x 3; a batch that
@@ -294,6 +295,7 @@ struct gal_synth {
     bool state_fetched = false;           // h_state holds the state of the batch in flight
     gal_synth_stats_t stats{};
     int enq_passes = kDefaultPasses;  // carrier passes the next execute enqueues (see kDefaultPasses)
+    int small_need = 2;               // ... what the handle's last plan of <= kSmallPlanEpochs epochs needed (its first: one spare)
     // k_synth's resampled-window body: per slot the last code step whose hold-pattern thresholds were examined and
     // their smallest distance (rw_threshold_gap) -- reused only for the identical step
     std::vector<double> rw_s0, rw_g0, rw_e0;
@@ -655,7 +657,10 @@ static int commit_staged(gal_synth *h, const bool wait)
     h->stats.n_active_max = h->nact_max;
     h->stats.chunk_samples = sp.R;
     h->stats.chunks_per_epoch = sp.nchunks;
-    h->enq_passes = kDefaultPasses;
+    // carrier passes enqueued up front: kDefaultPasses for a new plan -- but a plan of a few epochs (one-epoch calls, INTEGRATION.md
+    // option B) is all latency, every no-op pass is two more launches in front of its synthesis, and no random small batch needs
+    // more than one pass (tools/find_multi_pass_batch.py: 0 of 3000): such plans enqueue what the handle's last small batch needed
+    h->enq_passes = h->P.E <= kSmallPlanEpochs ? std::max(1, h->small_need) : kDefaultPasses;
     h->planned = true;
     return GAL_OK;
 }
@@ -1588,6 +1593,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
         h->g_holdoff = 9;  // (this batch is exact like any other; the handle's next 8 go to the exact-replay kernel)
     h->stats.walk_passes = ctr_end[CTR_PASSES];
     h->enq_passes = std::max(1, std::min(ctr_end[CTR_PASSES], 8));  // (of THIS plan, executed again; a new plan starts from kDefaultPasses)
+    if (h->P.E <= kSmallPlanEpochs) h->small_need = h->enq_passes;
     h->h_ctr[CTR_MISMATCH] = ctr_end[CTR_MISMATCH];
     h->stats.chain_mismatch = h->h_ctr[CTR_MISMATCH];
     h->stats.ms_walk = ms_walk;

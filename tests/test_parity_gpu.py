@@ -307,38 +307,49 @@ def test_unconverged_speculation_is_repaired(pkg, monkeypatch):
 
 
 def test_enqueued_carrier_passes_belong_to_the_plan(pkg, monkeypatch):
-    """A NEW plan gets three carrier passes enqueued up front (a batch that needs more than were enqueued pays a second synthesis: a
-    scenario in which a satellite's Doppler passes through zero, one in six of the random M-SYN12 seeds, needs two); a plan that is
-    EXECUTED AGAIN enqueues what its last execute needed.  Rounds 3-5 kept the count per handle ("one after a batch that got by with
-    one"): right for a bench that re-executes one resident plan, wrong for a caller with new parameters every batch -- the hard batch
-    behind an easy one was repaired by a second synthesis (synth_runs == 2).  Now it never is."""
+    """A NEW plan of more than 32 epochs gets three carrier passes enqueued up front (a batch that needs more than were enqueued pays a
+    second synthesis: a scenario in which a satellite's Doppler passes through zero, one in eight of the random M-SYN12 seeds, needs
+    two); a plan that is EXECUTED AGAIN enqueues what its last execute needed.  Rounds 3-5 kept the count per handle ("one after a
+    batch that got by with one"): right for a bench that re-executes one resident plan, wrong for a caller with new parameters every
+    batch -- a hard batch behind an easy one was repaired by a second synthesis (synth_runs == 2).  Now it never is.  Plans of a few
+    epochs (one-epoch calls: all latency, every spare pass is two launches in front of the synthesis) keep the per-handle count."""
     import torch
 
-    hard, n_samp, rate, chunk = _hard_batch(pkg, monkeypatch)
-    easy = pkg.workloads.make_synthetic(n_epochs=3, n_chan=6, n_slots=8, samples_per_epoch=n_samp, seed=12)
-    ref_hard, _ = oracle_run(hard, n_samp, rate)
-    ref_easy, _ = oracle_run(easy, n_samp, rate)
-    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=8, device=0, chunk_samples=chunk, test_hooks=True) as eng:
-        for params, ref, spoil in ((hard, ref_hard, True), (easy, ref_easy, False), (hard, ref_hard, True), (hard, ref_hard, True)):
+    n = 52000
+    big = pkg.workloads.make_synthetic(n_epochs=40, n_chan=6, n_slots=8, samples_per_epoch=n, seed=12)
+    ref_big, _ = oracle_run(big, n, 2.6e6)
+    with pkg.SynthEngine(samples_per_epoch=n, n_slots=8, device=0, test_hooks=True) as eng:
+        for spoil in (True, False, True, True, False):  # (GAL_GUESS_SPOIL, read when the batch is planned: one leg walked again in pass two)
             if spoil:
-                monkeypatch.setenv("GAL_GUESS_SPOIL", "1")  # (read when the batch is planned)
+                monkeypatch.setenv("GAL_GUESS_SPOIL", "1")
             else:
                 monkeypatch.delenv("GAL_GUESS_SPOIL", raising=False)
-            iq, _, stats = eng.run_host(params)
-            assert np.array_equal(iq, ref) and stats["synth_runs"] == 1, (spoil, stats)
+            iq, _, stats = eng.run_host(big)
+            assert np.array_equal(iq, ref_big) and stats["synth_runs"] == 1, (spoil, stats)
             assert (stats["walk_passes"] >= 2) if spoil else (stats["walk_passes"] == 1)
         # the same plan executed again and again: same passes, one synthesis each
-        eng.plan(hard)
-        out = torch.empty(ref_hard.size, dtype=torch.int16, device="cuda")
+        monkeypatch.setenv("GAL_GUESS_SPOIL", "1")
+        eng.plan(big)
+        out = torch.empty(ref_big.size, dtype=torch.int16, device="cuda")
         for _ in range(3):
             eng.execute(out.data_ptr())
             _, stats = eng.finish()
             assert stats["walk_passes"] >= 2 and stats["synth_runs"] == 1
-            assert np.array_equal(out.cpu().numpy(), ref_hard)
-        monkeypatch.delenv("GAL_GUESS_SPOIL")
-        for params, ref in ((easy, ref_easy), (hard, ref_hard)):
-            iq, _, stats = eng.run_host(params)
-            assert np.array_equal(iq, ref) and stats["synth_runs"] == 1 and stats["walk_passes"] == 1
+            assert np.array_equal(out.cpu().numpy(), ref_big)
+    # small plans: the handle's first enqueues two, then what its last small batch needed
+    hard, n_samp, rate, chunk = _hard_batch(pkg, monkeypatch)
+    ref_hard, _ = oracle_run(hard, n_samp, rate)
+    with pkg.SynthEngine(sample_rate=rate, samples_per_epoch=n_samp, n_slots=8, device=0, chunk_samples=chunk, test_hooks=True) as eng:
+        runs = []
+        for spoil in (True, False, True, True):
+            if spoil:
+                monkeypatch.setenv("GAL_GUESS_SPOIL", "1")
+            else:
+                monkeypatch.delenv("GAL_GUESS_SPOIL", raising=False)
+            iq, _, stats = eng.run_host(hard)
+            assert np.array_equal(iq, ref_hard)
+            runs.append((stats["walk_passes"] >= 2, stats["synth_runs"]))
+        assert runs == [(True, 1), (False, 1), (True, 2), (True, 1)]  # (one enqueued behind the easy batch: repaired, then two again)
 
 
 def test_translated_legs_on_moving_receiver(pkg):

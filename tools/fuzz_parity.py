@@ -5,6 +5,9 @@ channels appearing, vanishing and being re-allocated, symbol counters near the p
 wrap).  Test infrastructure: uses the oracle as the checker.   python tools/fuzz_parity.py [n_cases] [seed] [big]
 GAL_FUZZ_HOOKS=1 runs the GAL_TEST_HOOKS build (e.g. with GAL_SCAN_BLOCK_LEGS=8: many blocks per slot in the carrier stitch of every batch, i.e. its look-back).
 GAL_FUZZ_CBOC=1 runs the opt-in CBOC(6,1,1/11) mode against the checker's CBOC loop.
+GAL_FUZZ_ASYNC=1 runs every case through gal_synth_plan_async / execute / finish on device buffers; a case that is cut in two STAGES its
+second part while the first is in flight (plan(k+1) under execute(k) on one handle: the staged plan is committed by the next execute).
+GAL_G_WIDE=1 with GAL_FUZZ_HOOKS=1: k_synth_g's wide instances (13-24 channels in one launch) for every batch that has more than 12.
 GAL_FUZZ_GROUP=1 draws batches the default kernel of the reference geometry (k_synth_g + k_repair_g) can take, and reports how
 many it took and how many 16-sample groups were replayed exactly."""
 import os
@@ -32,6 +35,36 @@ def random_case(rng, big=False):
     return _random_case(pkg, rng, big, group=GROUP)
 
 
+ASYNC = bool(os.environ.get("GAL_FUZZ_ASYNC"))
+
+
+def run_async(eng, parts, n_samp):
+    """plan_async / execute / finish over the parts of one run (device buffers).  While a part is in flight a copy of the FIRST part
+    is staged on the handle (plan(k+1) under execute(k)); the real next part -- which needs the carried state -- replaces it behind
+    the finish; the last staged copy is committed by one more execute and must give the first part's bits once more."""
+    outs, st, agg = [], None, None
+    bufs = [torch.empty(q.shape[0] * n_samp * 2, dtype=torch.int16, device="cuda") for q in parts]
+    eng.plan(parts[0], None, wait=False)
+    for k, q in enumerate(parts):
+        eng.execute(bufs[k].data_ptr())
+        eng.plan(parts[0], None, wait=False)  # staged beside the batch in flight
+        st, stats = eng.finish()
+        outs.append(bufs[k].cpu().numpy())
+        if agg is None:
+            agg = stats
+        else:
+            agg["chain_mismatch"] += stats["chain_mismatch"]
+            agg["repaired_groups"] += stats["repaired_groups"]
+        if k + 1 < len(parts):
+            eng.plan(parts[k + 1], st, wait=False)  # replaces the staged copy
+    again = torch.empty_like(bufs[0])
+    eng.execute(again.data_ptr())  # commits the staged copy of the first part
+    _, stats_again = eng.finish()
+    if stats_again["chain_mismatch"] or not np.array_equal(again.cpu().numpy(), outs[0]):
+        agg["chain_mismatch"] += 1000000  # (reported as a mismatch of the case)
+    return np.concatenate(outs), st, agg
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -51,7 +84,10 @@ def main():
                                  chunk_samples=chunk, test_hooks=bool(os.environ.get("GAL_FUZZ_HOOKS")),
                                  flags=pkg.synth.GAL_CFG_CBOC if CBOC else 0) as eng:
                 cut = int(rng.integers(1, p.shape[0])) if (p.shape[0] > 1 and rng.random() < 0.4) else 0
-                if cut:  # the same run in two calls, the channel state carried by the caller
+                if ASYNC:
+                    iq, st, stats = run_async(eng, [p[:cut], p[cut:]] if cut else [p], n_samp)
+                    stats2 = {"repaired_groups": 0}
+                elif cut:  # the same run in two calls, the channel state carried by the caller
                     iq1, st1, stats = eng.run_host(p[:cut])
                     fb_total += eng.walk_counts()[2]
                     iq2, st, stats2 = eng.run_host(p[cut:], st1)
