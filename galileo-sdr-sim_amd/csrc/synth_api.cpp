@@ -750,7 +750,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     //             a carrier step of 0 or in [2^-40, 120 / (16 x 511)] cycles per sample -- at most 120 table entries per group (the
     //             table's extension behind a wrap), and a phase that either moves or stands still for good: one that creeps past an
     //             index boundary would have thousands of groups in a row listed for the exact replay
-    std::vector<uint8_t> rec_mode((size_t)E * S, 0), rec_g((size_t)E * S, 0);
+    std::vector<uint8_t> rec_mode((size_t)E * S, 0), rec_gm((size_t)E * S, 0), rec_gb((size_t)E * S, 0);
     double cs2_max = 0.0;  // largest code step of the batch, half chips per sample
     if ((int)h->rw_s0.size() != S) { h->rw_s0.assign(S, 0.0); h->rw_g0.assign(S, 0.0); h->rw_e0.assign(S, 0.0); h->rw_rad.assign(S, 0.0); }
     int n_restart = 0;  // records with GAL_CH_RESTART: their page_init goes up in a compact table
@@ -830,9 +830,14 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
                     // (both gates pass with room: the verdict holds for every step this close; else only for this very step)
                     h->rw_rad[s] = rad > 0.0 ? 0.98 * rad : 0.0;
                 }
-                if (h->rw_g0[s] > min_gap) {
-                    rec_mode[(size_t)e * S + s] = (uint8_t)mode;
-                    rec_g[(size_t)e * S + s] = (carr_ok && h->rw_e0[s] > min_gap) ? 1 : 0;
+                const bool bins_ok = h->rw_g0[s] > min_gap && h->rw_e0[s] > min_gap;
+                if (h->rw_g0[s] > min_gap) rec_mode[i] = (uint8_t)mode;
+                // k_synth_g: through its bin tables where the thresholds are a bin apart from each other and from 0 and 1; where they
+                // crowd (round 6: 4.092 / 8.184 / 16.368 MS/s and other rates at which 2 f_code / fs is near a small fraction) through the
+                // bisection instances (BOC(1,1) only: the CBOC mode's second pattern has bin tables only)
+                if (carr_ok && (bins_ok || !cboc)) {
+                    rec_gm[i] = (uint8_t)mode;
+                    rec_gb[i] = bins_ok ? 1 : 0;
                 }
             }
             act_all[(size_t)e * S + n] = (uint8_t)s;
@@ -853,12 +858,17 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
             ++n_records;
             if (rec_mode[i] == 0 || (rw_mode != 0 && rec_mode[i] != rw_mode)) rw_ok = false;
             if (rw_mode == 0) rw_mode = rec_mode[i];
-            if (rec_g[i]) g_count[rec_mode[i]] += 1;
+            if (rec_gm[i]) g_count[rec_gm[i]] += 1;
         }
     int g_mode = 1;
     for (int m = 2; m <= 4; ++m)
         if (g_count[m] > g_count[g_mode]) g_mode = m;
     const long long n_grec = g_count[g_mode];
+    bool g_search = false;  // some record of the group kernel's has pattern thresholds that crowd: the bisection instances for the batch
+    for (size_t i = 0; i < (size_t)E * S && !g_search; ++i) g_search = rec_gm[i] == g_mode && !rec_gb[i];
+#ifdef GAL_TEST_HOOKS
+    if (getenv("GAL_G_SEARCH") && !cboc) g_search = true;  // (the soak runs every rate through the bisection instances this way)
+#endif
     // epochs in which some record is not fit for k_synth_g in that form: the accumulating exact-replay launch behind it costs about
     // what a whole k_synth_g launch costs PER EPOCH IT HAS WORK IN (its blocks run the slow body at this chunk length: measured 1.0 ms
     // over 1199 epochs for one channel, gated_cost.py (a tool of rounds 3-5: git history)), the other epochs' blocks leave at once
@@ -867,7 +877,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
         bool any = false;
         for (int k = 0; k < nact_all[e] && !any; ++k) {
             const size_t i = (size_t)e * S + act_all[(size_t)e * S + k];
-            any = !(rec_g[i] && rec_mode[i] == g_mode);
+            any = rec_gm[i] != g_mode;
         }
         n_exact_epochs += any ? 1 : 0;
     }
@@ -969,10 +979,10 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     // read-modify-write of the second launch costs an issue-bound kernel); 600 epochs 10.1-10.3 / 10.5-10.7 ms wide against 9.14 / 10.3
     // narrow -- one block of 16 waves per CU has nobody to hide its table build and its tail behind (two narrow launches overlap each
     // other's).  So: wide where a block is a whole long epoch and the launch has many rounds of them, narrow otherwise.
-    bool narrow_g = !(E >= 2048 && (N + kGroupChunk - 1) / kGroupChunk >= 1024);
+    bool narrow_g = !(E >= 2048 && (N + kGroupChunk - 1) / kGroupChunk >= 1024) || g_search;  // (no wide bisection instances)
 #ifdef GAL_TEST_HOOKS
     if (getenv("GAL_G_NARROW")) narrow_g = true;
-    if (getenv("GAL_G_WIDE")) narrow_g = false;
+    if (getenv("GAL_G_WIDE") && !g_search) narrow_g = false;
 #endif
     std::vector<uint8_t> act_g;
     std::vector<int> nact_g;
@@ -1012,8 +1022,8 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     };
     int n_exact_records = 0;
     if (fam_g) {
-        sp.n_groups = add_groups(1, [&](size_t i) { return rec_g[i] && rec_mode[i] == g_mode; });
-        sp.n_groups += add_groups(0, [&](size_t i) { return !(rec_g[i] && rec_mode[i] == g_mode); });
+        sp.n_groups = add_groups(1, [&](size_t i) { return rec_gm[i] == g_mode; });
+        sp.n_groups += add_groups(0, [&](size_t i) { return rec_gm[i] != g_mode; });
         n_exact_records = (int)(n_records - n_grec);
         sp.all_first = sp.n_groups;
         sp.all_count = n_exact_records ? add_groups(0, [](size_t) { return true; }) : 0;  // (no exact records: the kind-1 groups ARE all)
@@ -1115,6 +1125,7 @@ static int plan_impl(gal_synth_t *h, const gal_chan_epoch_t *params, int32_t n_e
     P.cp_x = (double *)(base + o_cpx); P.cp_p = (double *)(base + o_cpp); P.cp_ib = (uint32_t *)(base + o_cpi);
     P.ctr = (int *)(base + o_ctr);
     P.fam = fam_g ? 1 : 0;
+    P.rw_search = (fam_g && g_search) ? 1 : 0;
     P.gflist = (uint32_t *)(base + o_gflist);
     P.gflist_cap = (int)g_cap;
 #ifdef GAL_TEST_HOOKS
@@ -1219,6 +1230,8 @@ const void *gal_hooks_plan_host_array(const char *name)
         if (!strcmp(t.n, name)) return g->h_up + (size_t)(uintptr_t)t.p;
     if (!strcmp(name, "family")) return (const void *)(uintptr_t)(1 + P.fam);
     if (!strcmp(name, "groups")) return (const void *)(uintptr_t)(1 + g->n_groups);
+    if (!strcmp(name, "search")) return (const void *)(uintptr_t)(1 + P.rw_search);
+    if (!strcmp(name, "form")) return (const void *)(uintptr_t)(1 + P.rw);
     return nullptr;
 }
 #endif
@@ -1599,7 +1612,7 @@ int gal_synth_finish_n(gal_synth_t *h, gal_chan_state_t *state_out, void *stats,
     h->stats.ms_walk = ms_walk;
     h->stats.ms_synth = ms_synth;
     h->stats.ms_repair = h->stats.synth_runs == 1 ? ms_repair : 0.0f;
-    h->stats.window_mode = h->P.rw;
+    h->stats.window_mode = h->P.rw | ((h->P.fam == 1 && h->P.rw_search) ? 16 : 0);
     h->stats.ms_plan = h->ms_plan;
     if (h->upload_timed) {
         float ms = 0;

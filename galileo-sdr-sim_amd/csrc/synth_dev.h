@@ -90,6 +90,7 @@ struct DevPlan {
     int signal;           // 0 BOC(1,1) (the reference), 1 CBOC(6,1,1/11) (GAL_CFG_CBOC)
     int rw;               // resampled-window body of k_synth: 1 every code step has 0.74 <= 2 f_code / fs < 1 (holds),
                           // 2 / 3 every code step has 2 f_code / fs <= 0.133 / 0.266 (<= 2 / 4 advances), 0 classic per-sample window index
+    int rw_search;        // k_synth_g: 1 = find a group's pattern by bisection over the sorted thresholds (rates whose thresholds crowd), 0 = bin table
     int fam;              // synthesis kernel family: 0 k_synth (one chunk per lane, exact replay), 1 k_synth_g (one 16-sample group per
                           // lane from the chunk's checkpoint in closed form + k_repair_g for the undecided groups; synth_group.hip)
     int gbpe;             // k_synth_g: 0 (product): contiguous chunk ranges, see gslots / grounds; > 0 (GAL_TEST_HOOKS): blocks per epoch

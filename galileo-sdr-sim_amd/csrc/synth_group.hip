@@ -40,6 +40,19 @@
 using namespace galnco;
 using namespace galdev;
 
+// Compiled as three translation units, side by side under `make -j` (Makefile: -DGAL_GTU=0..2), because its instantiations take five
+// minutes in one go: 0 = the instances for up to 12 channels (BOC(1,1) and CBOC), k_repair_g and the launchers; 1 = the wide
+// instances (13-24 channels); 2 = the bisection instances (crowded pattern thresholds).  Without GAL_GTU everything is one unit.
+#if !defined(GAL_GTU)
+#define GAL_GTU_MAIN 1
+#define GAL_GTU_WIDE 1
+#define GAL_GTU_SEARCH 1
+#else
+#define GAL_GTU_MAIN (GAL_GTU == 0)
+#define GAL_GTU_WIDE (GAL_GTU == 1)
+#define GAL_GTU_SEARCH (GAL_GTU == 2)
+#endif
+
 #ifndef SG_THREADS
 #define SG_THREADS 1024  // largest block the kernel is compiled for (its waves' records are sized for 16); the launch takes 512
                          // threads: 8 waves share one epoch's tables (61 KB of LDS), two blocks per CU, four waves per SIMD
@@ -95,11 +108,16 @@ __device__ __forceinline__ double sg_f64(const uint32_t lo, const uint32_t hi) {
 // SIG: 0 = BOC(1,1) as the reference generates it; 1 = the opt-in CBOC(6,1,1/11) mode (GAL_CFG_CBOC; hold form only): a second
 // pattern look-up per group -- the PARITY of the BOC(6,1) half period of every sample, k_synth's rw_phase_a6 / b6 -- two chip words
 // (the (B - C) and the (B + C) factor of every sample), 8-byte table entries (TA[k], TB[k]) and two multiply-adds per sample
-template <int J0, int CNT, int MODE, int SIG, int BINS, int BPITCH>
+// SEARCH (round 6): the pattern of a group is found by a four-step bisection over the channel's 15 sorted thresholds instead of through
+// the bin table, which holds ONE threshold per bin -- sample rates at which 2 f_code / fs is close to a fraction with a small
+// denominator (4.092, 8.184, 16.368 MS/s: two, four, eight samples per half chip; 2.5, 2.728 ...) have thresholds that coincide or lie
+// 1e-6 apart (the Doppler's share of the step) and used to send the whole batch to the exact-replay kernel.  The fraction is known to
+// 2^-31, the undecided band stays 2^-22 around every threshold: a few groups in 10^5 more are listed.
+template <int J0, int CNT, int MODE, int SIG, int BINS, int BPITCH, bool SEARCH>
 __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &undec, const double g16, const SgRec *rec, const uint32_t *sya,
                                         const double *s_c511, const uint32_t *s_lutd,
                                         const uint32_t *s_str, const uint2 *s_bin, const uint4 *s_pat, const uint2 *s_bin6,
-                                        const uint32_t *s_pat6, const int nact)
+                                        const uint32_t *s_pat6, const float *s_thr, const int nact)
 {
     uint32_t X[CNT];
     [[maybe_unused]] uint32_t XB[CNT];
@@ -132,8 +150,10 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
             const double A = __builtin_fma(g16, sg_f64(r1.x, r1.y), sg_f64(r0.x, r0.y));
             ic0[q] = (int)A;  // < 8184 + 1008: the row continues behind the period's end (:491-507 is a matter of the signs)
             f[q] = (float)__builtin_amdgcn_fract(A);
-            const int bi = (int)(f[q] * (float)BINS);
-            be[q] = s_bin[j * BPITCH + bi];
+            if constexpr (!SEARCH) {
+                const int bi = (int)(f[q] * (float)BINS);
+                be[q] = s_bin[j * BPITCH + bi];
+            }
             if constexpr (SIG == 1) {  // the BOC(6,1) half period of sample u is (int)(6 y_u) = i12 + floor(f6 + u 6 s)
                 const double y6 = 6.0 * A;
                 i12[q] = (int)y6;
@@ -165,12 +185,26 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
                         (((uint32_t)i12[q] & 1u) ? 0xAAAAAAAAu : 0u);
                 undec |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(f6[q] - thr6) >= RW_DELTA));
             }
+            if constexpr (SEARCH) {
+                // id = the number of thresholds <= f (entry 15 of the sorted row is the sentinel 2.0); undecided within 2^-22 of the
+                // neighbours on either side, and of 0 and 1 (sample 0's own half chip hangs on the rounding history there)
+                const float *th = s_thr + j * 16;
+                int id = th[7] <= f[q] ? 8 : 0;
+                id += th[id + 3] <= f[q] ? 4 : 0;
+                id += th[id + 1] <= f[q] ? 2 : 0;
+                id += th[id] <= f[q] ? 1 : 0;
+                const float up = th[id], lo = th[id > 0 ? id - 1 : 0];
+                M[q] = s_pat[j * 16 + id];
+                const bool near = !(up - f[q] >= RW_DELTA) | ((id > 0) & !(f[q] - lo >= RW_DELTA)) | !(f[q] >= RW_DELTA) | !(f[q] <= 1.0f - RW_DELTA);
+                undec |= __builtin_amdgcn_ballot_w64(near);
+            } else {
             const float thr = __uint_as_float(be[q].x);
             const uint32_t po = be[q].y + (f[q] >= thr ? 16u : 0u);
             M[q] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_pat + j * 16) + po);
             // undecided: the fraction too close to its bin's threshold (a NaN threshold = a bin near two of them); 0 and 1 are
             // thresholds of the first and the last bin, because sample 0's own half chip hangs on the rounding history there
             undec |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(f[q] - thr) >= RW_DELTA));
+            }
             const double pg = praw[q] - __builtin_trunc(praw[q]);  // (a mirrored phase that is still negative stays negative)
             t[q] = __builtin_fma(511.0, pg, SG_BIAS);
         }
@@ -294,13 +328,14 @@ __device__ __forceinline__ void sg_part(int (&o)[16], uint32_t &amb, uint64_t &u
 }
 
 // ACC: add onto samples already in `iq` (second and later channel groups when more than 12 channels are active)
-template <int NCH, bool ACC, int MODE, int SIG = 0>
+template <int NCH, bool ACC, int MODE, int SIG = 0, bool SEARCH = false>
 __global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(SG_WAVES_PER_EU)))
 void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restrict__ act_all, const int *__restrict__ nact_all,
                uint32_t *__restrict__ iq, uint32_t *__restrict__ flist, const int flist_cap)
 {
     static_assert(NCH >= 1 && NCH <= SG_MAXCH_WIDE, "1..24 channel positions per launch");
     static_assert(SIG == 0 || NCH <= SG_MAXCH, "the CBOC mode is built for up to 12 positions per launch");
+    static_assert(!SEARCH || (SIG == 0 && NCH <= SG_MAXCH), "the threshold search is built for BOC(1,1), up to 12 positions per launch");
     constexpr int MC = NCH <= SG_MAXCH ? SG_MAXCH : SG_MAXCH_WIDE;  // positions the per-wave records are laid out for
     // CBOC keeps two bin tables per channel (chip holds, half-period parity) of 64 bins each, as in k_synth
     constexpr int BINS = SIG ? CB_BINS : RW_BINS, BPITCH = SIG ? CB_BIN_PITCH : RW_BIN_PITCH;
@@ -527,7 +562,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
             bins[j * pitch + b] = make_uint2(__float_as_uint(thr), off);
         }
     };
-    build_bins(s_bin, s_thr, BINS, BPITCH, 16u);
+    if constexpr (!SEARCH) build_bins(s_bin, s_thr, BINS, BPITCH, 16u);
     if constexpr (SIG == 1) {
         build_bins(s_bin6, s_thr6, CB_BINS, CB_BIN_PITCH, 4u);
         for (int t = tid; t < NCH * 16; t += nthr) {
@@ -690,7 +725,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
         const SgRec *rec = recw + buf * MC;
         const uint32_t *sya = syaw + buf * MC;
         // balanced parts: 5, 6, 7, 9, 10, 11 positions are cut 3+2, 3+3, 4+3, 3+3+3, 4+3+3, 4+4+3
-#define SG_PART(J0, CNT) sg_part<J0, CNT, MODE, SIG, BINS, BPITCH>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat, s_bin6, s_pat6, nact); \
+#define SG_PART(J0, CNT) sg_part<J0, CNT, MODE, SIG, BINS, BPITCH, SEARCH>(o, amb, undec, g16, rec, sya, s_c511, s_lutd, s_str, s_bin, s_pat, s_bin6, s_pat6, s_thr, nact); \
                          __builtin_amdgcn_sched_barrier(0);
         // (CBOC: parts of at most three -- a part's group start keeps 17 values per position alive, 13 in the BOC(1,1) form)
         if constexpr (SIG == 1 && NCH <= 3) { SG_PART(0, NCH) }
@@ -756,6 +791,7 @@ void k_synth_g(const DevPlan *__restrict__ Pd, SynGeom G, const uint8_t *__restr
     }  // segments
 }
 
+#if GAL_GTU_MAIN
 // ------------------------------------------------------------------------------------------------
 // k_repair_g: the listed groups once more, with the reference's statements (:489-533) from their EXACT start state -- the
 // chunk's checkpoint advanced by 16 g samples in closed form (nco_walk.h) -- for ALL active channels of the epoch (every
@@ -891,6 +927,8 @@ __global__ __launch_bounds__(256) void k_repair_g(DevPlan P, SynGeom G, uint32_t
     }
 }
 
+#endif  // GAL_GTU_MAIN (k_repair_g)
+
 // ------------------------------------------------------------------------------------------------
 // Blocks of a launch over `ne` epochs: every block takes a contiguous, equally long run of the launch's chunks (k_synth_g), cut so
 // that block boundaries fall on epoch boundaries: ne x bpe blocks.  One block per epoch where that fills the device (M-SYN12: 1199
@@ -929,34 +967,84 @@ static int sg_bpe(const DevPlan *P, int ne, int nch = 0)
     return sg_grid(P, ne, nch) / ne;
 }
 
+// the wide and the bisection instances live in translation units of their own (GAL_GTU 1 / 2): (acc, mode) dispatched there
+extern "C" int galk_launch_synth_g_wide(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, int mode, const uint8_t *act, const int *nact,
+                                        uint32_t *iq, const SynGeom *G, int grid, hipStream_t st);
+extern "C" int galk_launch_synth_g_search(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, int mode, const uint8_t *act, const int *nact,
+                                          uint32_t *iq, const SynGeom *G, int grid, hipStream_t st);
+
+#if GAL_GTU_WIDE
+template <bool ACC, int MODE>
+static int launch_wide_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, const SynGeom &G, int ngrid,
+                         hipStream_t st)
+{
+    const dim3 grid(ngrid), wblock(SG_THREADS);  // blocks of 1024 threads, one per CU
+#define GAL_WCASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, 0>), grid, wblock, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); return 0;
+    switch (nch) {
+        GAL_WCASE(13) GAL_WCASE(14) GAL_WCASE(15) GAL_WCASE(16) GAL_WCASE(17) GAL_WCASE(18)
+        GAL_WCASE(19) GAL_WCASE(20) GAL_WCASE(21) GAL_WCASE(22) GAL_WCASE(23) GAL_WCASE(24)
+    default: return -1;
+    }
+#undef GAL_WCASE
+}
+extern "C" int galk_launch_synth_g_wide(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, int mode, const uint8_t *act, const int *nact,
+                                        uint32_t *iq, const SynGeom *G, int grid, hipStream_t st)
+{
+#define GAL_MCASE(m) case m: return accumulate ? launch_wide_t<true, m>(P, Pd, nch, act, nact, iq, *G, grid, st) : launch_wide_t<false, m>(P, Pd, nch, act, nact, iq, *G, grid, st);
+    switch (mode) {
+        GAL_MCASE(1) GAL_MCASE(2) GAL_MCASE(3) GAL_MCASE(4)
+    default: return -3;
+    }
+#undef GAL_MCASE
+}
+#endif  // GAL_GTU_WIDE
+
+#if GAL_GTU_SEARCH
+template <bool ACC, int MODE>
+static int launch_search_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, const SynGeom &G, int ngrid,
+                           hipStream_t st)
+{
+    const dim3 grid(ngrid), block(512);
+#define GAL_SCASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, 0, true>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); return 0;
+    switch (nch) {
+        GAL_SCASE(1) GAL_SCASE(2) GAL_SCASE(3) GAL_SCASE(4) GAL_SCASE(5) GAL_SCASE(6)
+        GAL_SCASE(7) GAL_SCASE(8) GAL_SCASE(9) GAL_SCASE(10) GAL_SCASE(11) GAL_SCASE(12)
+    default: return -1;
+    }
+#undef GAL_SCASE
+}
+extern "C" int galk_launch_synth_g_search(const DevPlan *P, const DevPlan *Pd, int nch, int accumulate, int mode, const uint8_t *act, const int *nact,
+                                          uint32_t *iq, const SynGeom *G, int grid, hipStream_t st)
+{
+#define GAL_MCASE(m) case m: return accumulate ? launch_search_t<true, m>(P, Pd, nch, act, nact, iq, *G, grid, st) : launch_search_t<false, m>(P, Pd, nch, act, nact, iq, *G, grid, st);
+    switch (mode) {
+        GAL_MCASE(1) GAL_MCASE(2) GAL_MCASE(3) GAL_MCASE(4)
+    default: return -3;
+    }
+#undef GAL_MCASE
+}
+#endif  // GAL_GTU_SEARCH
+
+#if GAL_GTU_MAIN
 template <bool ACC, int MODE, int SIG>
 static int launch_synth_g_t(const DevPlan *P, const DevPlan *Pd, int nch, const uint8_t *act, const int *nact, uint32_t *iq, int e0,
                             int ne, hipStream_t st, const SynGeom &G)
 {
-#ifdef SG_FORCE_THREADS  // A/B builds (build_variant_g.sh (a tool of rounds 3-5: git history))
-    const dim3 grid(sg_grid(P, ne)), block(SG_FORCE_THREADS);
+    if constexpr (SIG == 0) {
+        // crowded pattern thresholds: the bisection instances (BOC(1,1), <= 12 channels per launch); 13-24 channels: the wide ones
+        if (P->rw_search) return galk_launch_synth_g_search(P, Pd, nch, ACC ? 1 : 0, MODE, act, nact, iq, &G, sg_grid(P, ne, nch), st);
+        if (nch > SG_MAXCH) return galk_launch_synth_g_wide(P, Pd, nch, ACC ? 1 : 0, MODE, act, nact, iq, &G, sg_grid(P, ne, nch), st);
+    }
+#ifdef SG_FORCE_THREADS  // A/B builds
+    const dim3 grid(sg_grid(P, ne, nch)), block(SG_FORCE_THREADS);
 #else
     const dim3 grid(sg_grid(P, ne, nch)), block(P->gthreads >= 64 && P->gthreads <= SG_THREADS && (P->gthreads & 63) == 0 ? P->gthreads : 512);
 #endif
 #define GAL_CASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, block, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
-    {  // one instance per channel count, in the CBOC mode too (round 4: 4 / 8 / 12 positions, a 9-SV batch paid for 12)
-        switch (nch) {
-            GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
-            GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
-        default:
-            if constexpr (SIG == 0) {  // the wide instances (BOC(1,1) only): 13 .. 24 positions, blocks of 1024 threads, one per CU
-                const dim3 wblock(SG_THREADS);
-#define GAL_WCASE(n) case n: hipLaunchKernelGGL((k_synth_g<n, ACC, MODE, SIG>), grid, wblock, 0, st, Pd, G, act, nact, iq, P->gflist, P->gflist_cap); break;
-                switch (nch) {
-                    GAL_WCASE(13) GAL_WCASE(14) GAL_WCASE(15) GAL_WCASE(16) GAL_WCASE(17) GAL_WCASE(18)
-                    GAL_WCASE(19) GAL_WCASE(20) GAL_WCASE(21) GAL_WCASE(22) GAL_WCASE(23) GAL_WCASE(24)
-                default: return -1;
-                }
-#undef GAL_WCASE
-                break;
-            }
-            return -1;
-        }
+    switch (nch) {  // one instance per channel count, in the CBOC mode too (round 4: 4 / 8 / 12 positions, a 9-SV batch paid for 12)
+        GAL_CASE(1) GAL_CASE(2) GAL_CASE(3) GAL_CASE(4) GAL_CASE(5) GAL_CASE(6)
+        GAL_CASE(7) GAL_CASE(8) GAL_CASE(9) GAL_CASE(10) GAL_CASE(11) GAL_CASE(12)
+    default: return -1;
     }
 #undef GAL_CASE
     return 0;
@@ -1008,3 +1096,4 @@ extern "C" void galk_launch_repair_g(const DevPlan *P, uint32_t *iq, int e0, hip
     // blocks without a group leave at once)
     hipLaunchKernelGGL(k_repair_g, dim3(512), dim3(256), 0, st, *P, G, iq, P->gflist, P->gflist_cap);
 }
+#endif  // GAL_GTU_MAIN (launchers)

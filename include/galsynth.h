@@ -129,16 +129,18 @@ typedef struct gal_synth_stats {
                                    <= 0.133, sample rates from 15.4 MS/s; 3: <= 0.266, from 7.7 MS/s; 4: what lies between,
                                    2.77 .. 7.7 MS/s (kernel_family 1 only); all need well separated pattern thresholds --
                                    a rate at which 2 f_code / fs is within 1e-3 of a fraction with a denominator up to 15,
-                                   e.g. 4.092 MS/s, has none), 0 per-sample window index (any rate).  Same bits either way.
-                                                                                                                            */
+                                   e.g. 4.092 MS/s, has none on the exact-replay kernel), 0 per-sample window index (any rate).
+                                   + 16 (0.4, kernel_family 1): the thresholds crowd and a group's pattern was found by bisection
+                                   over them instead of through the bin table.  Same bits either way.                       */
     int32_t synth_runs;         /* synthesis launches the last batch took: 1, or 2 when gal_synth_finish() had to repeat
                                    it (carrier chain not complete when the kernel was started, or the replay check failed) */
     int32_t kernel_family;      /* 0: exact replay, one chunk of ~1000 samples per lane (any rate, any signal); 1: one 16-sample
                                    group per lane, start states in closed form from the chunk's exact checkpoint, groups whose
                                    chip pattern or table index hangs on the rounding history replayed exactly afterwards -- the
                                    default wherever gal_synth_plan's gate admits the batch: automatic chunking, every code step
-                                   in one form of the resampled windows (window_mode 1 ... 4: any rate from 2.05 MS/s up) with
-                                   well separated thresholds, every carrier step 0 or in [2^-40, 0.0147] cycles per sample;
+                                   in one form of the resampled windows (window_mode 1 ... 4: any rate from 2.05 MS/s up; pattern
+                                   thresholds that crowd -- 4.092, 8.184 MS/s ... -- are searched by bisection since 0.4, BOC(1,1)
+                                   only), every carrier step 0 or in [2^-40, 0.0147] cycles per sample;
                                    BOC(1,1) and the CBOC mode in all four forms                                              */
     int32_t repaired_groups;    /* family 1: 16-sample groups that were replayed exactly (about 1 in 10 000)                */
     float   ms_repair;          /* family 1: device time of that replay (k_repair_g, behind the synthesis kernel; not in ms_synth) */

@@ -71,10 +71,11 @@ def test_group_kernel_gates(pkg):
     q["f_carr"][:, 1] = 30000.0  # 16 x 511 x 30e3 / 2.6e6 = 94 entries per group: inside
     _, _, stats = _compare(pkg, q, 52000)
     assert stats["kernel_family"] == 1 and stats["exact_records"] == 0
-    # 4.092 MS/s: 2 samples per half chip exactly -- all 15 pattern thresholds on top of each other: no bin table can hold them
+    # 4.092 MS/s: 2 samples per half chip exactly -- all 15 pattern thresholds on top of each other: no bin table can hold them; since
+    # round 6 the group kernel's bisection instances take such a batch (window_mode + 16), the CBOC mode stays on the exact-replay kernel
     r = pkg.workloads.make_synthetic(n_epochs=2, n_chan=4, n_slots=8, samples_per_epoch=50000, sample_rate=4.092e6, seed=3)
     _, _, stats = _compare(pkg, r, 50000, rate=4.092e6)
-    assert stats["kernel_family"] == 0
+    assert stats["kernel_family"] == 1 and stats["window_mode"] == 4 + 16
 
 
 def test_group_kernel_mixed_batches(pkg):
@@ -137,7 +138,7 @@ def test_group_kernel_general_hold_form_between_the_others(pkg, rate):
     """Code steps between 4/15 and 0.74 half chips per sample (2.77 .. 7.7 MS/s; rounds 2-4: the exact-replay kernel) -- 5 to 11
     holds per group, in any order: window form 4, the spread through a four-stage shift network whose masks are made with the
     patterns.  24 channels in two launches, page flips, code wraps inside a chunk, listed groups; 3.8 / 4.5 / 7.5 MS/s have
-    pattern thresholds closer than a bin (the step is within 1e-3 of 7/13, 5/11, 3/11) and stay on the exact-replay kernel."""
+    pattern thresholds closer than a bin (the step is within 1e-3 of 7/13, 5/11, 3/11): the bisection instances (round 6)."""
     n = 40000
     p = pkg.workloads.make_synthetic(n_epochs=3, n_chan=24, n_slots=24, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e5))
     p["ibit0"][0, :4] = [499, 498, 0, 250]
@@ -145,11 +146,9 @@ def test_group_kernel_general_hold_form_between_the_others(pkg, rate):
     p["code_phase0"][1, 3] = 6137.9                        # a pending wrap that lands mid-period
     p["carr_phase0"][0, 5:8] = 0.0                          # listed groups for certain
     _, _, stats = _compare(pkg, p, n, rate=rate)
-    if rate in (3.8e6, 4.5e6, 7.5e6):
-        assert stats["kernel_family"] == 0, stats
-    else:
-        assert stats["kernel_family"] == 1 and stats["window_mode"] == 4 and stats["chunk_samples"] == 1024, stats
-        assert stats["repaired_groups"] >= 1 and stats["exact_records"] == 0, stats
+    # (3.8 / 4.5 / 7.5 MS/s: thresholds closer than a bin -- the bisection instances since round 6, the exact-replay kernel before)
+    assert stats["kernel_family"] == 1 and stats["window_mode"] == (4 + 16 if rate in (3.8e6, 4.5e6, 7.5e6) else 4) and stats["chunk_samples"] == 1024, stats
+    assert stats["repaired_groups"] >= 1 and stats["exact_records"] == 0, stats
     _, _, stats = _compare(pkg, p, n, rate=rate, flags=EXACT)
     assert stats["kernel_family"] == 0
 
@@ -229,6 +228,49 @@ def test_group_kernel_wide_instances_other_rates_ranges_and_more_than_24(pkg, mo
             _, stats = eng.finish()
             assert stats["chain_mismatch"] == 0
             assert np.array_equal(out.cpu().numpy(), ref_iq[e0 * n * 2:(e0 + ne) * n * 2]), (e0, ne)
+
+
+@pytest.mark.parametrize("rate,form", [(2.0462e6, 1), (2.5e6, 1), (2.728e6, 1), (4.092e6, 4), (8.184e6, 3), (16.368e6, 2), (12.276e6, 3),
+                                       (20.46e6, 2), (3.069e6, 4), (6.138e6, 4)])
+def test_group_kernel_bisection_instances_at_commensurate_rates(pkg, rate, form, monkeypatch):
+    """Round 6 (VERDICT r5 "missing" 6): sample rates at which 2 f_code / fs is (close to) a fraction with a small denominator --
+    multiples of 1.023 MHz, the rates GNSS front-ends like best: 4.092, 8.184, 16.368 MS/s are exactly 2, 4, 8 samples per half chip --
+    have pattern thresholds that coincide but for the Doppler's 1e-6; the bin table (one threshold per bin) cannot hold them and such
+    batches ran on the exact-replay kernel.  k_synth_g's bisection instances find a group's pattern by a four-step search over the 15
+    sorted thresholds instead: bit-exact with page flips, wraps, a carrier standing still, listed groups, zero Doppler on some
+    channels (thresholds EXACTLY on top of each other), 20 channels (two launches); and every ordinary rate gives the same bits
+    through them (hooks: GAL_G_SEARCH)."""
+    n = int(rate * 0.012)
+    p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=20, n_slots=24, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e4) % 9973)
+    p["ibit0"][0, :3] = [499, 498, 0]
+    p["code_phase0"][0, :3] = [4091.9, 4090.0, 4085.0]
+    p["code_phase0"][1, 3] = 6137.9
+    p["carr_phase0"][0, 5:8] = 0.0
+    p["f_carr"][:, 9] = 0.0                     # no Doppler: the code step is the nominal one, the thresholds coincide exactly ...
+    p["f_code"][:, 9] = 1.023e6
+    p["f_carr"][2:, 10] = 0.0
+    p["f_code"][2:, 10] = 1.023e6
+    p["code_phase0"][:, 9] = 100.25              # ... and the code phase sits on their lattice: listed, replayed
+    _, _, stats = _compare(pkg, p, n, rate=rate)
+    assert stats["kernel_family"] == 1 and stats["window_mode"] == form + 16 and stats["exact_records"] == 0, stats
+    assert stats["repaired_groups"] >= 1
+    _, _, stats = _compare(pkg, p, n, rate=rate, flags=EXACT)
+    assert stats["kernel_family"] == 0
+
+
+def test_group_kernel_bisection_instances_give_the_bin_tables_bits(pkg, monkeypatch):
+    """Every window form at an ordinary rate through the bisection instances (hooks: GAL_G_SEARCH) and through the bin tables: the
+    same bits, the same undecided groups up to the few the bins' registration margin adds."""
+    for rate, n, n_chan in ((2.6e6, 52000, 12), (25e6, 100000, 9), (8e6, 60007, 11), (4e6, 40000, 7)):
+        p = pkg.workloads.make_synthetic(n_epochs=4, n_chan=n_chan, n_slots=16, samples_per_epoch=n, sample_rate=rate, seed=int(rate / 1e5))
+        p["carr_phase0"][0, :3] = 0.0
+        iq, _, stats = _compare(pkg, p, n, rate=rate)
+        assert stats["kernel_family"] == 1 and stats["window_mode"] < 16
+        monkeypatch.setenv("GAL_G_SEARCH", "1")
+        iq2, _, stats2 = _compare(pkg, p, n, rate=rate, test_hooks=True)
+        monkeypatch.delenv("GAL_G_SEARCH")
+        assert stats2["window_mode"] == stats["window_mode"] + 16 and np.array_equal(iq, iq2)
+        assert abs(stats2["repaired_groups"] - stats["repaired_groups"]) <= 2 + stats["repaired_groups"] // 4, (stats, stats2)
 
 
 def test_group_kernel_page_flip_code_wraps_and_state_carry(pkg):

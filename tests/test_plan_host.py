@@ -89,15 +89,19 @@ def test_window_gate_cache_agrees_with_a_fresh_evaluation(pkg):
     for rate in (2.6e6, 2.5e6, 2.728e6, 3.0e6, 3.8e6, 4.0e6, 4.092e6, 6.5e6, 16e6, 25e6):
         n = int(rate / 10)
         p = pkg.workloads.make_synthetic(n_epochs=60, n_chan=6, n_slots=8, samples_per_epoch=n, sample_rate=rate, seed=77, dyn_track=True)
+        def verdict():  # (kernel family, window form, bin tables or bisection)
+            return tuple(int(lib.gal_hooks_plan_host_array(k)) - 1 for k in (b"family", b"form", b"search"))
+
         _plan(pkg, lib, p, n_samp=n, rate=rate)
-        fam = int(lib.gal_hooks_plan_host_array(b"family")) - 1
+        fam = verdict()
         fams = set()
         for e in (0, 17, 59):
             q = p[e:e + 1].copy()
             q["flags"][0, :] |= 1
             _plan(pkg, lib, q, n_samp=n, rate=rate)
-            fams.add(int(lib.gal_hooks_plan_host_array(b"family")) - 1)
+            fams.add(verdict())
         assert fams == {fam}, (rate, fam, fams)
+        assert fam[0] == 1 and fam[2] == (1 if rate in (2.5e6, 2.728e6, 3.8e6, 4.092e6) else 0), (rate, fam)
 
 
 def test_host_plan_time_is_reported(pkg, capsys):

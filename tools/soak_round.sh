@@ -22,6 +22,8 @@ GAL_FUZZ_ASYNC=1 timeout 1500 python tools/fuzz_parity.py $((6000*k)) 308 2>&1 |
 GAL_FUZZ_ASYNC=1 timeout 1500 python tools/fuzz_parity.py $((200*k)) 309 big 2>&1 | tail -1
 echo "### round 6: k_synth_g's wide instances for every batch of more than 12 channels (hooks build, GAL_G_WIDE): fuzz_parity.py $((5000*k)) 310 group"
 GAL_FUZZ_HOOKS=1 GAL_G_WIDE=1 GAL_FUZZ_GROUP=1 timeout 1500 python tools/fuzz_parity.py $((5000*k)) 310 2>&1 | tail -1
+echo "### round 6: k_synth_g's bisection instances at every rate (hooks build, GAL_G_SEARCH): fuzz_parity.py $((5000*k)) 311 group"
+GAL_FUZZ_HOOKS=1 GAL_G_SEARCH=1 GAL_FUZZ_GROUP=1 timeout 1500 python tools/fuzz_parity.py $((5000*k)) 311 2>&1 | tail -1
 echo "### end to end (streamed in 1-3 calls per scenario): fuzz_scenarios.py $((40*k)) cases seed 31"
 timeout 900 python tools/fuzz_scenarios.py $((40*k)) 31 2>&1 | tail -1
 } > $out 2>&1
