@@ -227,13 +227,17 @@ def leg_file_sink(pkg, seconds=120):
 def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0, solo_launches=0):
     """A few steps of another BASELINE config at its real geometry (M-DYN = config 3, M-SYN24 = config 4 geometry with a
     bounded epoch count; "cboc" = the headline geometry in the opt-in CBOC mode; "syn12_4msps" = 12 SVs at 4 MS/s, a rate
-    between the reference's and config 4's: window form 4), pipelined like the headline, on the
+    between the reference's and config 4's: window form 4; "syn12_4092ksps" = 12 SVs at 4.092 MS/s, thresholds that coincide), pipelined like the headline, on the
     headline's two streams (new streams would get whatever hardware queues are left: DESIGN.md section 6)."""
     n_samp, rate, n_slots, n_chan = 260000, 2.6e6, 16, 12
     if workload in ("syn24", "syn24_full"):
         n_samp, rate, n_slots, n_chan = 2500000, 25e6, 24, 24
     if workload == "syn12_4msps":
         n_samp, rate = 400000, 4.0e6
+    if workload in ("syn12_4092ksps", "syn12_4092ksps_exact"):  # exactly two samples per half chip: the pattern thresholds coincide
+        n_samp, rate = 409200, 4.092e6
+        if workload.endswith("_exact"):
+            flags |= pkg.synth.GAL_CFG_EXACT_REPLAY
     params = pkg.shard.rank_workload(0, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate,
                                      dyn_track=(workload == "dyn"))
     engines, outs = [], []
@@ -885,7 +889,10 @@ def main():
                                # the opt-in CBOC(6,1,1/11) mode on the headline geometry (not the reference's signal)
                                "cboc": leg_config(torch, pkg, "cboc", 1199, 30, local_rank, streams),
                                # a sample rate between the window forms of rounds 2-4 (2.77 .. 7.7 MS/s): form 4
-                               "syn12_4msps": leg_config(torch, pkg, "syn12_4msps", 1199, 20, local_rank, streams)}
+                               "syn12_4msps": leg_config(torch, pkg, "syn12_4msps", 1199, 20, local_rank, streams),
+                               # a rate whose pattern thresholds crowd (4 x 1.023 MHz): k_synth_g's bisection instances (round 6; the
+                               # exact-replay kernel before)
+                               "syn12_4092ksps": leg_config(torch, pkg, "syn12_4092ksps", 1199, 20, local_rank, streams)}
             # the headline with the opt-in SAMPLED self-check (round 5's default: a rotating eighth of the leg positions per batch instead
             # of every leg of both chains in every batch), same run, same box: what full verification costs the step
             vs = leg_config(torch, pkg, "syn12", 1199, max(args.steps, 20), local_rank, streams, flags=pkg.synth.GAL_CFG_VERIFY_SAMPLED, solo_launches=10)

@@ -304,7 +304,13 @@ __global__ void k_walk_carr(DevPlan P, int first)
             p = P.gss_r[idx];
         }
 #ifdef GAL_TEST_HOOKS
-        if (P.hook_spoil && li == GAL_HOOK_BAD_LEG) cur += 1;  // a guessed wrap event that is off by one sample: walked again in pass two
+        if (P.hook_spoil && li == GAL_HOOK_BAD_LEG) {
+            // an anchor that is not a wrap EVENT: one sample further along the same trajectory.  The stitch re-anchors the leg at the
+            // true event and pass two walks it again -- its claim was right all along, so nothing behind it moves (what a natural
+            // misprediction of a wrap's sample index looks like; an anchor off the trajectory would poison one successor per pass)
+            p = carr_step(p, P.dstep[(int)(cur / P.N) * P.S + s]);
+            cur += 1;
+        }
 #endif
         P.anc_w[li] = cur;
         P.anc_r[li] = p;

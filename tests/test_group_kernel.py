@@ -230,7 +230,7 @@ def test_group_kernel_wide_instances_other_rates_ranges_and_more_than_24(pkg, mo
             assert np.array_equal(out.cpu().numpy(), ref_iq[e0 * n * 2:(e0 + ne) * n * 2]), (e0, ne)
 
 
-@pytest.mark.parametrize("rate,form", [(2.0462e6, 1), (2.5e6, 1), (2.728e6, 1), (4.092e6, 4), (8.184e6, 3), (16.368e6, 2), (12.276e6, 3),
+@pytest.mark.parametrize("rate,form", [(2.5e6, 1), (2.728e6, 1), (4.092e6, 4), (8.184e6, 3), (16.368e6, 2), (12.276e6, 3),
                                        (20.46e6, 2), (3.069e6, 4), (6.138e6, 4)])
 def test_group_kernel_bisection_instances_at_commensurate_rates(pkg, rate, form, monkeypatch):
     """Round 6 (VERDICT r5 "missing" 6): sample rates at which 2 f_code / fs is (close to) a fraction with a small denominator --
