@@ -148,29 +148,40 @@ def _recorded_300s():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", _recorded_300s(), ids=lambda k: "case%d_%ds" % (k["c"], k["dur"]))
-def test_cli_reproduces_recorded_reference_answers_of_300s_runs(k):
+def test_cli_reproduces_recorded_reference_answers_of_300s_runs():
     """30 random scenarios of 200-300 s -- up to the reference's cap of 3000 epochs (USER_MOTION_SIZE,
     include/constants.h:14), six to ten 30 s re-allocations and several TOC marks per run -- whose answers the reference program gave
     where it can be built (tools/ref_task_fuzz.py 30 606 6 --long300 --record ...): the product CLI on the same command line must
-    write the same bytes (md5 and count; 2-3 GB per case, into /dev/shm)."""
-    args = _case_args(k)
+    write the same bytes (md5 and count; 2-3 GB per case, into /dev/shm, four cases at a time: the runs are bound by the host's md5)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cases = _recorded_300s()
+    assert len(cases) >= 29
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    out = os.path.join(shm, "galtest_%d_300s_%d.ishort" % (os.getpid(), k["c"]))
-    try:
-        r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr
-        if "no ephemeris within an hour" in r.stderr:
-            pytest.skip("ephemeris gap: the reference's behaviour is undefined there")
-        h, n = hashlib.md5(), 0
-        with open(out, "rb") as fh:
-            for blk in iter(lambda: fh.read(1 << 24), b""):
-                h.update(blk)
-                n += len(blk)
-    finally:
-        if os.path.exists(out):
-            os.remove(out)
-    assert [h.hexdigest(), n] == k["recorded"][:2], args
+
+    def run(k):
+        args = _case_args(k)
+        out = os.path.join(shm, "galtest_%d_300s_%d.ishort" % (os.getpid(), k["c"]))
+        try:
+            r = subprocess.run([CLI, "-e", NAV] + args.split() + ["-P", "0", "-o", out], capture_output=True, text=True, timeout=900)
+            if r.returncode != 0:
+                return k["c"], args, "exit %d: %s" % (r.returncode, r.stderr[-300:])
+            if "no ephemeris within an hour" in r.stderr:
+                return k["c"], args, None  # ephemeris gap: the reference's behaviour is undefined there
+            h, n = hashlib.md5(), 0
+            with open(out, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(blk)
+                    n += len(blk)
+        finally:
+            if os.path.exists(out):
+                os.remove(out)
+        return k["c"], args, None if [h.hexdigest(), n] == k["recorded"][:2] else "md5 %s, %d bytes; the reference: %s" % (h.hexdigest(), n, k["recorded"][:2])
+
+    with ThreadPoolExecutor(4) as ex:
+        res = list(ex.map(run, cases))
+    bad = [r for r in res if r[2] is not None]
+    assert not bad, bad
 
 
 def test_front_end_and_oracle_reproduce_a_config5_unit_of_the_reference_program(pkg):
