@@ -286,7 +286,7 @@ def leg_config(torch, pkg, workload, epochs, steps, local_rank, streams, flags=0
             **({"kernel_one_handle_ms": round(solo, 4)} if solo is not None else {})}
 
 
-def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms):
+def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epochs, steps, resident_ms, dyn_track=False):
     """the engine on FRESH parameters.  The headline re-executes one resident plan; no caller runs the same 120 s
     twice -- the reference computes its parameters between epochs (src/galileo-sdr.cpp:450-479).  Here every step gets a scenario of
     its own (another seed: other Dopplers, code phases, pages) and is plan + execute + finish, on the headline's two handles and one
@@ -301,7 +301,7 @@ def leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, n_chan, epo
     depth = len(engines)
     warm = 2 * depth
     n_sets = min(steps + warm, 64)  # (beyond 64 steps the seeds repeat, 64 steps apart: 3.4 MB of records each)
-    sets = [pkg.shard.rank_workload(1000 + k, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate)
+    sets = [pkg.shard.rank_workload(1000 + k, epochs, n_chan=n_chan, n_slots=n_slots, samples_per_epoch=n_samp, sample_rate=rate, dyn_track=dyn_track)
             for k in range(n_sets)]
     out2 = [torch.empty_like(outs[0]) for _ in engines]  # (its own outputs: the headline's stay as they are for the oracle's verdict on them)
     which = [None] * depth
@@ -853,7 +853,7 @@ def main():
         if world == 1 and args.workload in ("syn12", "dyn") and not strong and args.signal == "boc11" and not args.no_fresh_plan:
             # the same step on FRESH parameters (plan + execute + finish, another scenario every step), on the headline's handles
             fp, pending = leg_fresh_plan(torch, pkg, engines, outs, n_samp, rate, n_slots, args.channels, args.epochs,
-                                         args.steps, elapsed / args.steps * 1e3)
+                                         args.steps, elapsed / args.steps * 1e3, dyn_track=(args.workload == "dyn"))
             line["configs"] = {"fresh_plan": fp}
             line["config"]["plan_ms"] = fp["plan_ms"]  # host time of one gal_synth_plan of this workload
         if world == 1 and not args.no_cpu_baseline:
