@@ -9,6 +9,7 @@
 # Output: gpurun_out/<tag>_scale_node.log (+ <tag>_scale_N<n>.json, one bench line per world size)
 #   1. weak scaling, the headline: `bench.py --gpus N` for N = 1, 2, 4, 8 -- M-SYN12, one independent scenario per rank, no data-path
 #      collective; per N: aggregate Msamples/s, ms per step, report backend (RCCL), rank count, rank_imbalance
+#   1b. strong split: ONE M-SYN12 scenario cut into epoch ranges over N = 2, 4, 8 ranks (`--shard scenario`), per-rank walker / kernel time
 #   2. config 5 literally: `bench.py --gpus 8 --workload locations` -- rank r = site r of shard.LOCATIONS, 300 s, host front-end rows
 #   3. the product: `galileo-sdr-sim --sites` -- the eight sites over the node's devices, one ishort file per site, each file's md5
 #      against THE REFERENCE PROGRAM's (tests/golden/ref_task_config5.json), per-site sink rate from the CLI's own lines
@@ -60,6 +61,16 @@ for n in 1 2 4 8; do
         port=$((port + 1))
     fi
     summ $out "weak M-SYN12 N=$n" | tee -a $log
+done
+# ---- 1b. ONE scenario cut into epoch ranges over the ranks (strong split, gal_synth_execute_range; no exchange): rank_imbalance is the
+#         figure of interest -- shard.epoch_range's cost model was fitted on ranks run alone on one GPU (tools/strong_split_alone.sh)
+for n in 2 4 8; do
+    [ $n -gt $ndev ] && break
+    out=gpurun_out/${tag}_scale_strong_N${n}.json
+    timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
+        bench.py --gpus $n --steps $steps --warmup 5 --shard scenario > $out 2>> $log.err
+    port=$((port + 1))
+    summ $out "strong (one M-SYN12 scenario) N=$n" | tee -a $log
 done
 # ---- 2. config 5: eight sites, one per rank (as many ranks as there are devices; fewer ranks = the first sites)
 n5=$ndev; [ $n5 -gt 8 ] && n5=8
