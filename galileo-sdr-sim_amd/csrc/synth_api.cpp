@@ -250,6 +250,8 @@ struct gal_synth {
     hipEvent_t ev_walk = nullptr;
     hipEvent_t ev_ver = nullptr;  // k_verify_carr done (k_synth_g batches)
     hipEvent_t ev_verc = nullptr; // k_verify_code done (k_synth_g batches; second walker stream)
+    hipEvent_t ev_ctr = nullptr;  // the first carrier walk of the batch in flight is done: it resets the batch's counters at its start, and
+                                  // k_verify_code, on the other walker stream, must not count a mismatch in front of that
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_prep = nullptr, ev_aux = nullptr;
     hipEvent_t ev_upd = nullptr;  // the plan's upload and memsets are complete (what the walkers of its first execute wait for)
@@ -444,6 +446,7 @@ int gal_synth_create(const gal_synth_cfg_t *cfg, gal_synth_t **out)
         hipEventCreateWithFlags(&h->ev_upd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_ver, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_verc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_ctr, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_aux, hipEventDisableTiming) != hipSuccess)
         return bail(fail(GAL_E_DEVICE, "hipEventCreate failed"));
     // (coherent = fine-grained: k_publish writes both from the device while the host polls the flag behind h_ctr)
@@ -552,6 +555,7 @@ int gal_synth_destroy(gal_synth_t *h)
     if (h->ev_walk) hipEventDestroy(h->ev_walk);
     if (h->ev_ver) hipEventDestroy(h->ev_ver);
     if (h->ev_verc) hipEventDestroy(h->ev_verc);
+    if (h->ev_ctr) hipEventDestroy(h->ev_ctr);
     if (h->walk_stream) hipStreamDestroy(h->walk_stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -1376,6 +1380,7 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
     }
     for (int pass = 0; pass < n_passes; ++pass) {
         galk_launch_walk_carr(P, pass == 0, ws);  // (the first one also resets the batch's counters)
+        if (pass == 0 && ws != st) HIP_TRY(hipEventRecord(h->ev_ctr, ws));
         galk_launch_carr_scan(P, ++h->scan_tag, ws);
     }
     // the code chain (restarts every epoch, no speculation) and the page resolution do not depend on the carrier chain:
@@ -1402,7 +1407,10 @@ int gal_synth_execute_range(gal_synth_t *h, int16_t *iq_dev, int32_t first_epoch
         if (verify_beside) {
             galk_launch_verify_carr(P, ws);
             HIP_TRY(hipEventRecord(h->ev_ver, ws));
-            // ... and the code checkpoints, on the second walker stream behind the code walk that wrote them (ev_aux is recorded)
+            // ... and the code checkpoints, on the second walker stream behind the code walk that wrote them (ev_aux is recorded):
+            // it does not wait for the carrier chain -- only for the first carrier walk, whose first block resets the counters
+            // this kernel counts its mismatches in
+            HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->ev_ctr, 0));
             galk_launch_verify_code(P, h->aux_stream);
             HIP_TRY(hipEventRecord(h->ev_verc, h->aux_stream));
         }
